@@ -1,0 +1,81 @@
+"""ctypes binding of libecc_hip.so (the C ABI in include/ecc_hip.h).
+
+The HIP extension is the product: if it has not been built this module raises -- there is no
+eager/CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libecc_hip.so")
+
+ECC_OK = 0
+FILTER_DERIVATIVE, FILTER_RAMP, FILTER_NONE = 0, 1, 2
+POST_IDENTITY, POST_SQUARE_ROOT, POST_LOGARITHM = 0, 1, 2
+
+
+class EccError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libecc_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/ecc_hip.h
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_pi, _pd, _pf = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float)
+SIGNATURES = {
+    "ecc_last_error": (C.c_char_p, []),
+    "ecc_version": (_i, []),
+    "ecc_device_count": (_i, []),
+    "ecc_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "ecc_ctx_destroy": (_i, [_vp]),
+    "ecc_ctx_synchronize": (_i, [_vp]),
+    "ecc_radon_compute": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_radon_compute_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_dtr_from_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_dtr_readback": (_i, [_vp, _vp]),
+    "ecc_dtr_info": (_i, [_vp, _pi, _pi, _pi, _pi, _pi, _pd, _pd]),
+    "ecc_dtr_device_view": (_i, [_vp, C.POINTER(_vp), _pi, _pi]),
+    "ecc_dtr_slab_floats": (_i64, [_i, _i]),
+    "ecc_dtr_wrap_device": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_dtr_destroy": (_i, [_vp]),
+    "ecc_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ecc_metric_destroy": (_i, [_vp]),
+    "ecc_metric_set_projections": (_i, [_vp, _vp, _i]),
+    "ecc_metric_set_params": (_i, [_vp, _d, _d, _i]),
+    "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
+    "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
+    "ecc_metric_evaluate_range": (_i, [_vp, _i64, _i64, _vp, _pd]),
+    "ecc_metric_evaluate_range_async": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "ecc_metric_evaluate_pairs": (_i, [_vp, _vp, _i, _vp, _pd]),
+    "ecc_metric_debug_K01": (_i, [_vp, _i64, _i64, _vp]),
+    "ecc_get_ij": (None, [_i64, _i, _pi, _pi]),
+    "ecc_host_pinvT": (None, [_vp, _vp]),
+    "ecc_host_source_position": (None, [_vp, _vp]),
+    "ecc_host_object_radius": (_d, [_vp, _i, _i]),
+    "ecc_ctx_enable_timing": (_i, [_vp, _i]),
+    "ecc_ctx_last_kernel_ms": (_i, [_vp, _i, _pf]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -m epipolarconsistency_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != ECC_OK:
+        raise EccError(code, lib().ecc_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's operator interface for the hot path, on top of the C ABI.
+
+Same names, argument meaning and error behaviour as
+  EpipolarConsistency::RadonIntermediate        ref: code/LibEpipolarConsistency/RadonIntermediate.h:18-128
+  EpipolarConsistency::MetricRadonIntermediate  ref: code/LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.h:21-106
+  EpipolarConsistency::Metric                   ref: code/LibEpipolarConsistency/EpipolarConsistency.h:49-94
+(the reference is C++; the C++ adapter with the same class names is cpp/EpipolarConsistencyHip.hxx --
+this module is the Python face used by tests/ and bench.py).  All arithmetic happens in
+libecc_hip.so; numpy/torch only carry buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FILTER_DERIVATIVE, FILTER_NONE, FILTER_RAMP, POST_IDENTITY, POST_LOGARITHM,
+                   POST_SQUARE_ROOT, EccError, check)
+
+
+def _Ps_colmajor(Ps):
+    """List/array of 3x4 matrices -> contiguous n x 12 float64, column-major per view (Eigen)."""
+    A = np.asarray(Ps, dtype=np.float64).reshape(-1, 3, 4)
+    return np.ascontiguousarray(A.transpose(0, 2, 1)).reshape(-1, 12)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Context:
+    """One (device, stream) pair; replaces the reference's implicit current device + default
+    stream + cudaDeviceSynchronize after each launch."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        check(_lib.lib().ecc_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+        self.device = int(device)
+
+    def synchronize(self):
+        check(_lib.lib().ecc_ctx_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        check(_lib.lib().ecc_ctx_enable_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self, which):
+        """which: 'pairs' or 'radon' -- HIP-event time of the last such kernel on this stream."""
+        ms = C.c_float()
+        check(_lib.lib().ecc_ctx_last_kernel_ms(self._h, {"pairs": 0, "radon": 1}[which], C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().ecc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RadonIntermediate:
+    """ref: class RadonIntermediate (RadonIntermediate.h:18-128)."""
+    Derivative, Ramp, None_ = FILTER_DERIVATIVE, FILTER_RAMP, FILTER_NONE
+    Identity, SquareRoot, Logarithm = POST_IDENTITY, POST_SQUARE_ROOT, POST_LOGARITHM
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        self._keep = None  # caller-owned device memory (torch tensor) when wrapping
+
+    # -- constructors --------------------------------------------------------------------------
+    @classmethod
+    def compute(cls, ctx, image, size_alpha, size_t, filter=FILTER_DERIVATIVE, post_process=POST_IDENTITY):
+        """ref: RadonIntermediate(projectionData, size_alpha, size_t, filter, post_process).
+        image: (n_v, n_u) float32 numpy array (host) or torch tensor on ctx's device."""
+        return cls.compute_batch(ctx, image[None] if not _is_torch(image) else image.unsqueeze(0),
+                                 size_alpha, size_t, filter, post_process)[0]
+
+    @classmethod
+    def compute_batch(cls, ctx, images, size_alpha, size_t, filter=FILTER_DERIVATIVE, post_process=POST_IDENTITY):
+        """images: (n, n_v, n_u) float32, numpy (host) or torch (device)."""
+        if _is_torch(images):
+            import torch
+            assert images.dtype == torch.float32 and images.is_contiguous() and images.is_cuda
+            n, n_v, n_u = images.shape
+            ptr, on_dev, keep = images.data_ptr(), 1, images
+        else:
+            keep = np.ascontiguousarray(images, np.float32)
+            n, n_v, n_u = keep.shape
+            ptr, on_dev = keep.ctypes.data, 0
+        hs = (C.c_void_p * n)()
+        check(_lib.lib().ecc_radon_compute_batch(ctx._h, C.c_void_p(ptr), on_dev, n, n_u, n_v, size_alpha,
+                                                 size_t, filter, post_process, hs))
+        if on_dev:
+            ctx.synchronize()  # the input tensor may be freed by the caller right after
+        return [cls(ctx, C.c_void_p(h)) for h in hs]
+
+    @classmethod
+    def from_host(cls, ctx, data, n_u, n_v, filter=FILTER_DERIVATIVE):
+        """ref: RadonIntermediate(const NRRD::ImageView<float>&) -- data is (n_t, n_alpha) float32."""
+        data = np.ascontiguousarray(data, np.float32)
+        n_t, n_alpha = data.shape
+        h = C.c_void_p()
+        check(_lib.lib().ecc_dtr_from_host(ctx._h, C.c_void_p(data.ctypes.data), n_alpha, n_t, n_u, n_v, filter,
+                                           C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def wrap_device(cls, ctx, slab, n_alpha, n_t, n_u, n_v, filter=FILTER_DERIVATIVE):
+        """Adopt a torch tensor that already holds a dtr in the private layout (e.g. after an all-gather)."""
+        h = C.c_void_p()
+        check(_lib.lib().ecc_dtr_wrap_device(ctx._h, C.c_void_p(slab.data_ptr()), n_alpha, n_t, n_u, n_v, filter,
+                                             C.byref(h)))
+        r = cls(ctx, h)
+        r._keep = slab
+        return r
+
+    # -- accessors -----------------------------------------------------------------------------
+    def _info(self):
+        a, t, u, v, f = (C.c_int() for _ in range(5))
+        ba, bd = C.c_double(), C.c_double()
+        check(_lib.lib().ecc_dtr_info(self._h, C.byref(a), C.byref(t), C.byref(u), C.byref(v), C.byref(f),
+                                      C.byref(ba), C.byref(bd)))
+        return a.value, t.value, u.value, v.value, f.value, ba.value, bd.value
+
+    def getRadonBinNumber(self, dim):
+        a, t = self._info()[:2]
+        return t if dim else a
+
+    def getOriginalImageSize(self, dim):
+        u, v = self._info()[2:4]
+        return v if dim else u
+
+    def getRadonBinSize(self, dim=1):
+        ba, bd = self._info()[5:7]
+        return bd if dim else ba
+
+    def getFilter(self):
+        return self._info()[4]
+
+    def isDerivative(self):
+        return self.getFilter() == FILTER_DERIVATIVE
+
+    def readback(self):
+        """ref: readback() + data(): (n_t, n_alpha) float32, alpha fastest."""
+        a, t = self._info()[:2]
+        out = np.empty((t, a), np.float32)
+        check(_lib.lib().ecc_dtr_readback(self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def device_view(self):
+        base, pitch, rows = C.c_void_p(), C.c_int(), C.c_int()
+        check(_lib.lib().ecc_dtr_device_view(self._h, C.byref(base), C.byref(pitch), C.byref(rows)))
+        return base.value, pitch.value, rows.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().ecc_dtr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MetricRadonIntermediate:
+    """ref: class MetricRadonIntermediate : public Metric."""
+
+    def __init__(self, ctx, Ps=None, dtrs=None):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self._dtrs = []
+        self._Ps = None
+        self._params = [0.0, 0.0, 0]
+        if dtrs is not None:
+            self.setRadonIntermediates(dtrs)
+        if Ps is not None:
+            self.setProjectionMatrices(Ps)
+
+    def setRadonIntermediates(self, dtrs):
+        if self._h:
+            _lib.lib().ecc_metric_destroy(self._h)
+            self._h = C.c_void_p()
+        self._dtrs = list(dtrs)  # borrowed, kept alive here
+        hs = (C.c_void_p * len(self._dtrs))(*[d._h for d in self._dtrs])
+        check(_lib.lib().ecc_metric_create(self.ctx._h, len(self._dtrs), hs, C.byref(self._h)))
+        check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
+        if self._Ps is not None:
+            self.setProjectionMatrices(self._Ps)
+        return self
+
+    def getRadonIntermediates(self):
+        return self._dtrs
+
+    def setProjectionMatrices(self, Ps):
+        self._Ps = _Ps_colmajor(Ps)
+        if self._h:
+            check(_lib.lib().ecc_metric_set_projections(self._h, C.c_void_p(self._Ps.ctypes.data), len(self._Ps)))
+        return self
+
+    def getProjectionMatrices(self):
+        return [] if self._Ps is None else [p.reshape(4, 3).T.copy() for p in self._Ps]
+
+    def getNumberOfProjetions(self):  # sic, ref: ...RadonIntermediate.h:64
+        return 0 if self._Ps is None else len(self._Ps)
+
+    def _push_params(self):
+        if self._h:
+            check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
+
+    def setObjectRadius(self, radius_mm=0.0):
+        self._params[0] = float(radius_mm)
+        self._push_params()
+        return self
+
+    def getObjectRadius(self):
+        r = C.c_double()
+        check(_lib.lib().ecc_metric_get_object_radius(self._h, C.byref(r)))
+        return r.value
+
+    def setEpipolarPlaneStep(self, dkappa_rad=0.0):
+        self._params[1] = float(dkappa_rad)
+        self._push_params()
+        return self
+
+    setdKappa = setEpipolarPlaneStep
+
+    def useCorrelation(self, corr=True):
+        self._params[2] = 1 if corr else 0
+        self._push_params()
+        return self
+
+    # -- evaluation ----------------------------------------------------------------------------
+    def evaluate(self, arg=None, out=None):
+        """evaluate()                      -> mean over all pairs
+        evaluate(cost)  cost: (n,n) float32 C-contiguous array, entry [j, i] (= index i + j*n), i<j, is written
+        evaluate(set_of_views[, out])   -> mean over all pairs inside the subset
+        evaluate(indices[, out])        -> mean over explicit (P0,P1,dtr0,dtr1) tuples
+        ref: ...RadonIntermediate.cpp:166-225, :228-245, :267-322."""
+        L = _lib.lib()
+        mean = C.c_double()
+        if arg is None or (isinstance(arg, np.ndarray) and arg.dtype == np.float32 and arg.ndim == 2
+                           and out is None and arg.shape[0] == arg.shape[1] == self.getNumberOfProjetions()):
+            cost = arg
+            if cost is not None and not cost.flags["C_CONTIGUOUS"]:
+                raise ValueError("cost image must be C-contiguous float32")
+            check(L.ecc_metric_evaluate_all(self._h, C.c_void_p(cost.ctypes.data if cost is not None else 0),
+                                            C.byref(mean)))
+            return mean.value
+        if isinstance(arg, (set, frozenset)):
+            views = sorted(arg)
+            idx = [(a, b, a, b) for k, a in enumerate(views) for b in views[k + 1:]]
+        else:
+            idx = arg
+        idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 4)
+        if out is None:
+            out = np.empty(len(idx), np.float32)
+        assert out.dtype == np.float32 and out.size >= len(idx)
+        check(L.ecc_metric_evaluate_pairs(self._h, C.c_void_p(idx.ctypes.data), len(idx),
+                                          C.c_void_p(out.ctypes.data), C.byref(mean)))
+        return mean.value
+
+    def evaluate_range(self, first, count, want_pairs=False):
+        """Partial sum over pairs [first, first+count) of the get_ij order (multi-GPU shard)."""
+        s = C.c_double()
+        vals = np.empty(count, np.float32) if want_pairs else None
+        check(_lib.lib().ecc_metric_evaluate_range(self._h, int(first), int(count),
+                                                   C.c_void_p(vals.ctypes.data if want_pairs else 0), C.byref(s)))
+        return (s.value, vals) if want_pairs else s.value
+
+    def evaluate_range_async(self, first, count, sum_tensor, pair_tensor=None):
+        """Device-resident, non-synchronising form: sum_tensor is a 1-element float64 torch tensor."""
+        check(_lib.lib().ecc_metric_evaluate_range_async(
+            self._h, int(first), int(count), C.c_void_p(pair_tensor.data_ptr() if pair_tensor is not None else 0),
+            C.c_void_p(sum_tensor.data_ptr())))
+
+    def debug_K01(self, first, count):
+        out = np.empty((count, 16), np.float32)
+        check(_lib.lib().ecc_metric_debug_K01(self._h, int(first), int(count), C.c_void_p(out.ctypes.data)))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().ecc_metric_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def get_ij(ij, n):
+    i, j = C.c_int(), C.c_int()
+    _lib.lib().ecc_get_ij(int(ij), int(n), C.byref(i), C.byref(j))
+    return i.value, j.value
+
+
+def host_pinvT(P):
+    P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, 4).T).reshape(12)
+    out = np.empty(12, np.float32)
+    _lib.lib().ecc_host_pinvT(C.c_void_p(P.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def host_source_position(P):
+    P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, 4).T).reshape(12)
+    out = np.empty(4, np.float32)
+    _lib.lib().ecc_host_source_position(C.c_void_p(P.ctypes.data), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def host_object_radius(P, n_u, n_v):
+    P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, 4).T).reshape(12)
+    return _lib.lib().ecc_host_object_radius(C.c_void_p(P.ctypes.data), int(n_u), int(n_v))

@@ -1,0 +1,50 @@
+"""Builds libecc_hip.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+`python -m epipolarconsistency_amd.build` or build_library() from __graft_entry__.build().
+hipcc cross-compiles without a GPU.  -ffp-contract=off: the Radon kernel's arithmetic is specified
+as unfused IEEE binary32 (bit parity with the oracle); the host geometry is specified in unfused
+binary64.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libecc_hip.so")
+SOURCES = ["radon_kernel.hip", "pairs_kernel.hip", "ecc_capi.hip"]
+HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", os.path.join("..", "..", "include", "ecc_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False, extra_flags=()):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv, verbose=True)
+    print("built", LIB)

@@ -1,0 +1,780 @@
+// ecc_capi.hip -- implementation of the C ABI declared in include/ecc_hip.h (host code only).
+//
+// Host-side flow of the reference that this replaces:
+//   RadonIntermediate ctor/compute   ref: LibEpipolarConsistency/RadonIntermediate.cpp:17-31,198-211
+//   MetricRadonIntermediate::*        ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cpp
+// Differences by design: one stream per context and no device-wide syncs between launches; K01 is
+// fused into the pair kernel; the mean is reduced on the device in float64 and 8 bytes come back.
+// There is NO CPU fallback: without a HIP device every compute entry point fails with
+// ECC_ERR_NO_DEVICE / ECC_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ecc_hip.h"
+#include "ecc_host_geometry.h"
+#include "ecc_layout.h"
+
+extern "C" hipError_t ecc_launch_radon(const EccRadonParams* p, int derivative, hipStream_t stream);
+extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n_alpha, int n_t, int pitch,
+                                            hipStream_t stream);
+extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
+                                            hipStream_t stream);
+extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
+extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
+
+#define ECC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            (void)hipGetLastError();                                                              \
+            return fail(_e == hipErrorOutOfMemory ? ECC_ERR_OUT_OF_MEMORY : ECC_ERR_HIP,          \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                       \
+        }                                                                                         \
+    } while (0)
+
+// Device slab shared by the dtrs of one batch; freed when the last handle goes away.
+struct Slab {
+    float* ptr = nullptr;
+    int device = 0;
+    ~Slab()
+    {
+        if (ptr) {
+            (void)hipSetDevice(device);
+            (void)hipFree(ptr);
+        }
+    }
+};
+
+}  // namespace
+
+struct ecc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // pair start/stop, radon start/stop
+    bool ev_valid[2] = {false, false};
+    // trig table cache for the Radon kernel
+    float* trig_d = nullptr;
+    int trig_n_alpha = 0;
+};
+
+struct ecc_dtr {
+    ecc_ctx* ctx = nullptr;
+    std::shared_ptr<Slab> owner;  // null when wrapping caller memory
+    float* base = nullptr;
+    int n_alpha = 0, n_t = 0, n_u = 0, n_v = 0, filter = 0, pitch = 0;
+};
+
+struct ecc_metric {
+    ecc_ctx* ctx = nullptr;
+    std::vector<ecc_dtr*> dtrs;
+    int n_alpha = 0, n_t = 0, n_u = 0, n_v = 0, pitch = 0;
+    bool is_derivative = true;
+    float step_alpha = 0, step_t = 0;
+    // parameters
+    double object_radius_mm = 0, dkappa = 0;
+    int use_corr = 0;
+    // projections
+    int n_views = 0;
+    std::vector<double> P_first;  // first projection matrix (object radius estimate)
+    // device state
+    const float** dtr_table_d = nullptr;
+    float* Cs_d = nullptr;
+    float* PinvTs_d = nullptr;
+    int geom_capacity = 0;
+    float* pair_values_d = nullptr;
+    int64_t pair_capacity = 0;
+    float* cost_d = nullptr;
+    int cost_capacity = 0;
+    int32_t* indices_d = nullptr;
+    int64_t indices_capacity = 0;
+    float* K01_d = nullptr;
+    int64_t K01_capacity = 0;
+    double* sum_d = nullptr;
+    // pinned host staging
+    float* geom_h = nullptr;  // 16 floats per view: 12 PinvT + 4 C
+    int geom_h_capacity = 0;
+    double* sum_h = nullptr;
+};
+
+namespace {
+
+int set_device(const ecc_ctx* ctx)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ECC_OK;
+}
+
+int ensure_trig(ecc_ctx* ctx, int n_alpha)
+{
+    if (ctx->trig_d && ctx->trig_n_alpha == n_alpha) return ECC_OK;
+    if (ctx->trig_d) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->trig_d));
+        ctx->trig_d = nullptr;
+    }
+    // alpha of angle bin ix, ref: RadonIntermediate.cu:46-50 (fp32, same expressions); the sine and
+    // cosine are taken once per angle on the host instead of once per thread on the device.
+    const float Pi = 3.14159265359f;
+    std::vector<float> t(2 * (size_t)n_alpha);
+    for (int ix = 0; ix < n_alpha; ++ix) {
+        float x_rel = (ix / (float)n_alpha - 0.5f);
+        float alpha = x_rel * Pi;
+        t[2 * ix] = sinf(alpha);
+        t[2 * ix + 1] = cosf(alpha);
+    }
+    HIP_TRY(hipMalloc((void**)&ctx->trig_d, t.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(ctx->trig_d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // t goes out of scope
+    ctx->trig_n_alpha = n_alpha;
+    return ECC_OK;
+}
+
+template <class T>
+int ensure_capacity(T** ptr, int64_t* cap, int64_t need, hipStream_t stream)
+{
+    if (*cap >= need && *ptr) return ECC_OK;
+    if (*ptr) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipFree(*ptr));
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    HIP_TRY(hipMalloc((void**)ptr, (size_t)need * sizeof(T)));
+    *cap = need;
+    return ECC_OK;
+}
+
+int radon_launch(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, int n_alpha, int n_t, int filter,
+                 int post, float* slabs, int64_t slab_stride)
+{
+    int rc = ensure_trig(ctx, n_alpha);
+    if (rc) return rc;
+    EccRadonParams p;
+    p.images = images_d;
+    p.out = slabs;
+    p.trig = ctx->trig_d;
+    p.image_stride = (int64_t)n_u * n_v;
+    p.out_stride = slab_stride;
+    p.n_img = n;
+    p.n_u = n_u;
+    p.n_v = n_v;
+    p.n_alpha = n_alpha;
+    p.n_t = n_t;
+    p.pitch = ecc_layout_pitch(n_t);
+    p.post_process = post;
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    // gridDim.z is limited to 65535; batches are far below that.
+    HIP_TRY(ecc_launch_radon(&p, filter == ECC_FILTER_DERIVATIVE ? 1 : 0, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+        ctx->ev_valid[1] = true;
+    }
+    return ECC_OK;
+}
+
+int check_radon_args(ecc_ctx* ctx, const float* image, int n, int n_u, int n_v, int n_alpha, int n_t, int filter,
+                     int post, ecc_dtr** out)
+{
+    if (!ctx || !image || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n <= 0 || n > 65535) return fail(ECC_ERR_INVALID_ARGUMENT, "batch size must be in [1, 65535]");
+    if (n_u < 2 || n_v < 2 || n_u > 16384 || n_v > 16384)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "image size must be in [2, 16384]");
+    if (n_alpha < 1 || n_t < 1 || n_alpha > 16384 || n_t > 16384)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "Radon bin counts must be in [1, 16384]");
+    if (filter == ECC_FILTER_RAMP) return fail(ECC_ERR_UNSUPPORTED, "Filter::Ramp is not implemented");
+    if (filter != ECC_FILTER_DERIVATIVE && filter != ECC_FILTER_NONE)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "unknown filter");
+    if (post < 0 || post > 2) return fail(ECC_ERR_INVALID_ARGUMENT, "unknown post-process");
+    return ECC_OK;
+}
+
+}  // namespace
+
+// ---- misc ------------------------------------------------------------------------------------
+ECC_EXPORT const char* ecc_last_error(void) { return g_last_error.c_str(); }
+ECC_EXPORT int ecc_version(void) { return ECC_HIP_VERSION; }
+ECC_EXPORT int ecc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+ECC_EXPORT void ecc_get_ij(int64_t ij, int n, int* i, int* j)
+{
+    // pairs before row r: r*n - r(r+1)/2   (ref: EpipolarConsistencyCommon.hxx:52-79 enumerates the same order)
+    double nn = (double)n - 0.5;
+    int64_t r = (int64_t)std::floor(nn - std::sqrt(nn * nn - 2.0 * (double)ij));
+    if (r < 0) r = 0;
+    if (r > n - 2) r = n - 2;
+    while (r > 0 && r * n - r * (r + 1) / 2 > ij) --r;
+    while ((r + 1) * n - (r + 1) * (r + 2) / 2 <= ij) ++r;
+    *i = (int)r;
+    *j = (int)(ij - (r * n - r * (r + 1) / 2) + r + 1);
+}
+ECC_EXPORT void ecc_host_pinvT(const double* P, float* PinvT12) { ecc_host::pinv_transpose(P, PinvT12); }
+ECC_EXPORT void ecc_host_source_position(const double* P, float* C4) { ecc_host::source_position(P, C4); }
+ECC_EXPORT double ecc_host_object_radius(const double* P, int n_u, int n_v)
+{
+    return ecc_host::object_radius(P, n_u, n_v);
+}
+
+// ---- context -----------------------------------------------------------------------------------
+ECC_EXPORT int ecc_ctx_create(int device, void* stream, ecc_ctx** out)
+{
+    if (!out) return fail(ECC_ERR_INVALID_ARGUMENT, "out is null");
+    int n = ecc_device_count();
+    if (n <= 0) return fail(ECC_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (device < 0 || device >= n) return fail(ECC_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    ecc_ctx* c = new (std::nothrow) ecc_ctx();
+    if (!c) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    *out = c;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_ctx_destroy(ecc_ctx* ctx)
+{
+    if (!ctx) return ECC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->trig_d) (void)hipFree(ctx->trig_d);
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete ctx;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_ctx_synchronize(ecc_ctx* ctx)
+{
+    if (!ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "ctx is null");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "ctx is null");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    if (enable)
+        for (auto& e : ctx->ev)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+    ctx->timing = enable != 0;
+    ctx->ev_valid[0] = ctx->ev_valid[1] = false;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_ctx_last_kernel_ms(ecc_ctx* ctx, int which, float* ms)
+{
+    if (!ctx || !ms || which < 0 || which > 1) return fail(ECC_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!ctx->timing || !ctx->ev_valid[which]) return fail(ECC_ERR_INVALID_ARGUMENT, "no timed launch recorded");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(ctx->ev[2 * which + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev[2 * which], ctx->ev[2 * which + 1]));
+    return ECC_OK;
+}
+
+// ---- Radon intermediate ------------------------------------------------------------------------
+ECC_EXPORT int64_t ecc_dtr_slab_floats(int n_alpha, int n_t) { return ecc_layout_floats(n_alpha, n_t); }
+
+ECC_EXPORT int ecc_radon_compute_batch(ecc_ctx* ctx, const float* images, int images_on_device, int n, int n_u,
+                                       int n_v, int n_alpha, int n_t, int filter, int post_process, ecc_dtr** out)
+{
+    int rc = check_radon_args(ctx, images, n, n_u, n_v, n_alpha, n_t, filter, post_process, out);
+    if (rc) return rc;
+    rc = set_device(ctx);
+    if (rc) return rc;
+    const int64_t slab = ecc_layout_floats(n_alpha, n_t);
+    auto owner = std::make_shared<Slab>();
+    owner->device = ctx->device;
+    HIP_TRY(hipMalloc((void**)&owner->ptr, (size_t)slab * n * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(owner->ptr, 0, (size_t)slab * n * sizeof(float), ctx->stream));
+    const float* images_d = images;
+    float* staging = nullptr;
+    if (!images_on_device) {
+        size_t bytes = (size_t)n * n_u * n_v * sizeof(float);
+        HIP_TRY(hipMalloc((void**)&staging, bytes));
+        hipError_t e = hipMemcpyAsync(staging, images, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(staging);
+            HIP_TRY(e);
+        }
+        images_d = staging;
+    }
+    rc = radon_launch(ctx, images_d, n, n_u, n_v, n_alpha, n_t, filter, post_process, owner->ptr, slab);
+    if (staging) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(staging);
+    }
+    if (rc) return rc;
+    for (int k = 0; k < n; ++k) {
+        ecc_dtr* d = new (std::nothrow) ecc_dtr();
+        if (!d) {
+            for (int q = 0; q < k; ++q) delete out[q];
+            return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
+        }
+        d->ctx = ctx;
+        d->owner = owner;
+        d->base = owner->ptr + slab * k;
+        d->n_alpha = n_alpha;
+        d->n_t = n_t;
+        d->n_u = n_u;
+        d->n_v = n_v;
+        d->filter = filter;
+        d->pitch = ecc_layout_pitch(n_t);
+        out[k] = d;
+    }
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_radon_compute(ecc_ctx* ctx, const float* image, int image_on_device, int n_u, int n_v,
+                                 int n_alpha, int n_t, int filter, int post_process, ecc_dtr** out)
+{
+    return ecc_radon_compute_batch(ctx, image, image_on_device, 1, n_u, n_v, n_alpha, n_t, filter, post_process, out);
+}
+
+ECC_EXPORT int ecc_dtr_from_host(ecc_ctx* ctx, const float* data, int n_alpha, int n_t, int n_u, int n_v, int filter,
+                                 ecc_dtr** out)
+{
+    if (!ctx || !data || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_alpha < 1 || n_t < 1 || n_alpha > 16384 || n_t > 16384)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "Radon bin counts must be in [1, 16384]");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const int64_t slab = ecc_layout_floats(n_alpha, n_t);
+    auto owner = std::make_shared<Slab>();
+    owner->device = ctx->device;
+    HIP_TRY(hipMalloc((void**)&owner->ptr, (size_t)slab * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(owner->ptr, 0, (size_t)slab * sizeof(float), ctx->stream));
+    float* staging = nullptr;
+    size_t bytes = (size_t)n_alpha * n_t * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&staging, bytes));
+    hipError_t e = hipMemcpyAsync(staging, data, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = ecc_launch_dtr_import(staging, owner->ptr, n_alpha, n_t, ecc_layout_pitch(n_t), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(staging);
+    HIP_TRY(e);
+    ecc_dtr* d = new (std::nothrow) ecc_dtr();
+    if (!d) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    d->ctx = ctx;
+    d->owner = owner;
+    d->base = owner->ptr;
+    d->n_alpha = n_alpha;
+    d->n_t = n_t;
+    d->n_u = n_u;
+    d->n_v = n_v;
+    d->filter = filter;
+    d->pitch = ecc_layout_pitch(n_t);
+    *out = d;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_dtr_wrap_device(ecc_ctx* ctx, float* base, int n_alpha, int n_t, int n_u, int n_v, int filter,
+                                   ecc_dtr** out)
+{
+    if (!ctx || !base || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_alpha < 1 || n_t < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "bad Radon bin counts");
+    ecc_dtr* d = new (std::nothrow) ecc_dtr();
+    if (!d) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    d->ctx = ctx;
+    d->base = base;
+    d->n_alpha = n_alpha;
+    d->n_t = n_t;
+    d->n_u = n_u;
+    d->n_v = n_v;
+    d->filter = filter;
+    d->pitch = ecc_layout_pitch(n_t);
+    *out = d;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_dtr_readback(ecc_dtr* dtr, float* host_out)
+{
+    if (!dtr || !host_out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    ecc_ctx* ctx = dtr->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    float* staging = nullptr;
+    size_t bytes = (size_t)dtr->n_alpha * dtr->n_t * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&staging, bytes));
+    hipError_t e = ecc_launch_dtr_export(dtr->base, staging, dtr->n_alpha, dtr->n_t, dtr->pitch, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host_out, staging, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(staging);
+    HIP_TRY(e);
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_dtr_info(const ecc_dtr* dtr, int* n_alpha, int* n_t, int* n_u, int* n_v, int* filter,
+                            double* bin_size_angle, double* bin_size_distance)
+{
+    if (!dtr) return fail(ECC_ERR_INVALID_ARGUMENT, "dtr is null");
+    if (n_alpha) *n_alpha = dtr->n_alpha;
+    if (n_t) *n_t = dtr->n_t;
+    if (n_u) *n_u = dtr->n_u;
+    if (n_v) *n_v = dtr->n_v;
+    if (filter) *filter = dtr->filter;
+    // ref: RadonIntermediate.cpp:204-206
+    if (bin_size_angle) *bin_size_angle = 3.1415926535897931 / dtr->n_alpha;
+    if (bin_size_distance)
+        *bin_size_distance = std::sqrt((double)dtr->n_v * dtr->n_v + (double)dtr->n_u * dtr->n_u) / dtr->n_t;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_dtr_device_view(const ecc_dtr* dtr, float** base, int* pitch, int* rows)
+{
+    if (!dtr) return fail(ECC_ERR_INVALID_ARGUMENT, "dtr is null");
+    if (base) *base = dtr->base;
+    if (pitch) *pitch = dtr->pitch;
+    if (rows) *rows = ecc_layout_rows(dtr->n_alpha);
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_dtr_destroy(ecc_dtr* dtr)
+{
+    if (!dtr) return ECC_OK;
+    if (dtr->owner && dtr->owner.use_count() == 1) {
+        (void)hipSetDevice(dtr->ctx->device);
+        (void)hipStreamSynchronize(dtr->ctx->stream);
+    }
+    delete dtr;
+    return ECC_OK;
+}
+
+// ---- metric ------------------------------------------------------------------------------------
+ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs, ecc_metric** out)
+{
+    if (!ctx || !dtrs || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_dtrs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least one Radon intermediate");
+    for (int k = 0; k < n_dtrs; ++k)
+        if (!dtrs[k]) return fail(ECC_ERR_INVALID_ARGUMENT, "null Radon intermediate in list");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    ecc_metric* m = new (std::nothrow) ecc_metric();
+    if (!m) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    m->ctx = ctx;
+    m->dtrs.assign(dtrs, dtrs + n_dtrs);
+    // sizes come from dtrs[0] only, ref: ...RadonIntermediate.cpp:92-98
+    const ecc_dtr* d0 = dtrs[0];
+    m->n_alpha = d0->n_alpha;
+    m->n_t = d0->n_t;
+    m->n_u = d0->n_u;
+    m->n_v = d0->n_v;
+    m->pitch = d0->pitch;
+    m->is_derivative = d0->filter == ECC_FILTER_DERIVATIVE;
+    m->step_alpha = (float)(3.1415926535897931 / d0->n_alpha);
+    m->step_t = (float)(std::sqrt((double)d0->n_v * d0->n_v + (double)d0->n_u * d0->n_u) / d0->n_t);
+    std::vector<const float*> table(n_dtrs);
+    for (int k = 0; k < n_dtrs; ++k) {
+        // unlike the reference (mixed sizes are "silently wrong") reject them
+        if (dtrs[k]->n_alpha != m->n_alpha || dtrs[k]->n_t != m->n_t) {
+            delete m;
+            return fail(ECC_ERR_INVALID_ARGUMENT, "all Radon intermediates must have the same bin counts");
+        }
+        table[k] = dtrs[k]->base;
+    }
+    hipError_t e = hipMalloc((void**)&m->dtr_table_d, sizeof(float*) * n_dtrs);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, sizeof(double));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->dtr_table_d, table.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ecc_metric_destroy(m);
+        HIP_TRY(e);
+    }
+    *out = m;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
+{
+    if (!m) return ECC_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->dtr_table_d) (void)hipFree((void*)m->dtr_table_d);
+    if (m->Cs_d) (void)hipFree(m->Cs_d);
+    if (m->PinvTs_d) (void)hipFree(m->PinvTs_d);
+    if (m->pair_values_d) (void)hipFree(m->pair_values_d);
+    if (m->cost_d) (void)hipFree(m->cost_d);
+    if (m->indices_d) (void)hipFree(m->indices_d);
+    if (m->K01_d) (void)hipFree(m->K01_d);
+    if (m->sum_d) (void)hipFree(m->sum_d);
+    if (m->geom_h) (void)hipHostFree(m->geom_h);
+    if (m->sum_h) (void)hipHostFree(m->sum_h);
+    delete m;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n_views)
+{
+    if (!m || !Ps) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least one projection matrix");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    if (n_views > m->geom_capacity) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (m->Cs_d) HIP_TRY(hipFree(m->Cs_d));
+        if (m->PinvTs_d) HIP_TRY(hipFree(m->PinvTs_d));
+        if (m->geom_h) HIP_TRY(hipHostFree(m->geom_h));
+        m->Cs_d = m->PinvTs_d = m->geom_h = nullptr;
+        m->geom_capacity = 0;
+        HIP_TRY(hipMalloc((void**)&m->Cs_d, sizeof(float) * 4 * n_views));
+        HIP_TRY(hipMalloc((void**)&m->PinvTs_d, sizeof(float) * 12 * n_views));
+        HIP_TRY(hipHostMalloc((void**)&m->geom_h, sizeof(float) * 16 * n_views));
+        m->geom_capacity = n_views;
+    } else {
+        // the pinned staging buffer may still be in flight from the previous call
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    float* PinvT_h = m->geom_h;
+    float* C_h = m->geom_h + 12 * (size_t)n_views;
+    for (int v = 0; v < n_views; ++v) {
+        ecc_host::pinv_transpose(Ps + 12 * (size_t)v, PinvT_h + 12 * (size_t)v);
+        ecc_host::source_position(Ps + 12 * (size_t)v, C_h + 4 * (size_t)v);
+    }
+    HIP_TRY(hipMemcpyAsync(m->PinvTs_d, PinvT_h, sizeof(float) * 12 * n_views, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(m->Cs_d, C_h, sizeof(float) * 4 * n_views, hipMemcpyHostToDevice, ctx->stream));
+    m->n_views = n_views;
+    m->P_first.assign(Ps, Ps + 12);
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa, int use_corr)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    m->object_radius_mm = object_radius_mm;
+    m->dkappa = dkappa;
+    m->use_corr = use_corr;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm)
+{
+    if (!m || !radius_mm) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (m->object_radius_mm > 0) *radius_mm = m->object_radius_mm;
+    else if (m->P_first.empty()) *radius_mm = 0;
+    else *radius_mm = ecc_host::object_radius(m->P_first.data(), m->n_u, m->n_v);
+    return ECC_OK;
+}
+
+namespace {
+
+int fill_pair_params(ecc_metric* m, EccPairParams* p)
+{
+    if (m->use_corr) return fail(ECC_ERR_UNSUPPORTED, "useCorrelation(true) is not implemented");
+    if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
+    double radius = 0;
+    ecc_metric_get_object_radius(m, &radius);
+    std::memset(p, 0, sizeof(*p));
+    p->dtrs = m->dtr_table_d;
+    p->Cs = m->Cs_d;
+    p->PinvTs = m->PinvTs_d;
+    p->n_views = m->n_views;
+    p->n_alpha = m->n_alpha;
+    p->n_t = m->n_t;
+    p->pitch = m->pitch;
+    // launcher arguments, ref: ...RadonIntermediate.cu:320-358 (fp32, same expressions)
+    p->n_x2 = m->n_u * 0.5f;
+    p->n_y2 = m->n_v * 0.5f;
+    p->object_radius_mm = (float)radius;
+    const float image_diagonal = m->n_t * m->step_t * 2.f;
+    p->num_samples = image_diagonal;
+    p->range_t = m->n_t * m->step_t;
+    p->dkappa_user = (float)m->dkappa;
+    const float Pi = 3.14159265359f;
+    int max_num_samples = p->dkappa_user <= 0.0f ? (int)image_diagonal : (int)(Pi * 0.5f / p->dkappa_user);
+    p->k_limit = (max_num_samples + 255) / 256 * 256;
+    p->is_derivative = m->is_derivative ? 1 : 0;
+    return ECC_OK;
+}
+
+int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d, float* cost_d, float* K01_d,
+                 double* sum_d)
+{
+    ecc_ctx* ctx = m->ctx;
+    const int64_t n = m->n_views;
+    const int64_t n_pairs = n * (n - 1) / 2;
+    if ((int)m->dtrs.size() < m->n_views)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "fewer Radon intermediates than projection matrices");
+    if (first < 0 || count < 0 || first + count > n_pairs)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "pair range outside [0, n(n-1)/2)");
+    EccPairParams p;
+    int rc = fill_pair_params(m, &p);
+    if (rc) return rc;
+    p.first = first;
+    p.count = count;
+    p.pair_values = pair_values_d;
+    p.cost = cost_d;
+    p.K01_out = K01_d;
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        ctx->ev_valid[0] = true;
+    }
+    if (sum_d) {
+        if (count > 0) HIP_TRY(ecc_launch_sum_pairs(pair_values_d, count, sum_d, ctx->stream));
+        else HIP_TRY(hipMemsetAsync(sum_d, 0, sizeof(double), ctx->stream));
+    }
+    return ECC_OK;
+}
+
+}  // namespace
+
+ECC_EXPORT int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d,
+                                               double* sum_d)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    int rc = set_device(m->ctx);
+    if (rc) return rc;
+    float* vals = pair_values_d;
+    if (!vals) {
+        rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count > 0 ? count : 1, m->ctx->stream);
+        if (rc) return rc;
+        vals = m->pair_values_d;
+    }
+    return launch_range(m, first, count, vals, nullptr, nullptr, sum_d);
+}
+
+ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values,
+                                         double* partial_sum)
+{
+    if (!m || !partial_sum) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count > 0 ? count : 1, ctx->stream);
+    if (rc) return rc;
+    rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_d);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(m->sum_h, m->sum_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (pair_values && count > 0)
+        HIP_TRY(hipMemcpyAsync(pair_values, m->pair_values_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *partial_sum = *m->sum_h;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean)
+{
+    if (!m || !mean) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const int64_t n = m->n_views;
+    const int64_t n_pairs = n * (n - 1) / 2;
+    if (n < 2) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least two views (the reference divides 0/0 here)");
+    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, n_pairs, ctx->stream);
+    if (rc) return rc;
+    float* cost_d = nullptr;
+    if (cost_nxn) {
+        if (m->cost_capacity < n * n) {
+            if (m->cost_d) {
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                HIP_TRY(hipFree(m->cost_d));
+                m->cost_d = nullptr;
+            }
+            HIP_TRY(hipMalloc((void**)&m->cost_d, sizeof(float) * n * n));
+            m->cost_capacity = (int)(n * n);
+        }
+        cost_d = m->cost_d;
+        // upload the caller's image so that untouched entries survive, ref: ...RadonIntermediate.cpp:183
+        HIP_TRY(hipMemcpyAsync(cost_d, cost_nxn, sizeof(float) * n * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_d);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(m->sum_h, m->sum_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (cost_nxn) HIP_TRY(hipMemcpyAsync(cost_nxn, cost_d, sizeof(float) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mean = *m->sum_h / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int n_pairs, float* out, double* mean)
+{
+    if (!m || !idx4 || !mean) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_pairs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "empty index list (the reference divides 0/0 here)");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    // range check in every build; the reference only does it under _DEBUG (...RadonIntermediate.cpp:248-275)
+    const int nP = m->n_views, nD = (int)m->dtrs.size();
+    for (int q = 0; q < n_pairs; ++q) {
+        const int32_t* t = idx4 + 4 * (size_t)q;
+        if (t[0] < 0 || t[0] >= nP || t[1] < 0 || t[1] >= nP || t[2] < 0 || t[2] >= nD || t[3] < 0 || t[3] >= nD)
+            return fail(ECC_ERR_INVALID_ARGUMENT, "index array contains invalid indices");
+    }
+    rc = ensure_capacity(&m->indices_d, &m->indices_capacity, (int64_t)4 * n_pairs, ctx->stream);
+    if (rc) return rc;
+    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, n_pairs, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(m->indices_d, idx4, sizeof(int32_t) * 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    EccPairParams p;
+    rc = fill_pair_params(m, &p);
+    if (rc) return rc;
+    p.indices = m->indices_d;
+    p.first = 0;
+    p.count = n_pairs;
+    p.pair_values = m->pair_values_d;
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        ctx->ev_valid[0] = true;
+    }
+    HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_d, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(m->sum_h, m->sum_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (out) HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mean = *m->sum_h / (double)n_pairs;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_debug_K01(ecc_metric* m, int64_t first, int64_t count, float* K01s)
+{
+    if (!m || !K01s) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (count < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "empty range");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count, ctx->stream);
+    if (rc) return rc;
+    rc = ensure_capacity(&m->K01_d, &m->K01_capacity, 16 * count, ctx->stream);
+    if (rc) return rc;
+    rc = launch_range(m, first, count, m->pair_values_d, nullptr, m->K01_d, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(K01s, m->K01_d, sizeof(float) * 16 * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ECC_OK;
+}

@@ -1,0 +1,174 @@
+// ecc_host_geometry.h -- per-view host pre-compute (E1) and default object radius (E5), float64.
+//
+// Implements what MetricRadonIntermediate::setProjectionMatrices computes per view
+// (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cpp:134-163):
+//   (P^+)^T  = ((P P^T)^-1 P)  as 3x4 column-major float   (ref: culaut/xprojectionmatrix.hxx:20-52)
+//   C        = null vector of P scaled to w = 1, float       (ref: culaut/xprojectionmatrix.hxx:93-105)
+// and Metric::getObjectRadius' estimate (ref: EpipolarConsistency.cpp:35-47,76-84).
+//
+// P P^T of a C-arm projection matrix has a condition number of ~1e11, so the float32 results
+// depend on HOW the inverse is formed.  To be a drop-in, this code performs the same Householder
+// QR factorisation + back substitution, with the same operation order in binary64, as the
+// reference's culaut routines (xgeinv.hxx:40-168); it is written from that arithmetic
+// specification, not from the reference text, and is checked bit-for-bit against the
+// reference headers in tests/test_oracle_pins.py.
+#ifndef ECC_HOST_GEOMETRY_H
+#define ECC_HOST_GEOMETRY_H
+
+#include <cmath>
+
+namespace ecc_host {
+
+// In-place Householder QR of the column-major N x N matrix M (M becomes R) with explicit Q.
+// Arithmetic contract (must not be re-ordered):
+//   * column scale = running maximum of |M(i,k)|, i >= k, over columns 0..k (never reset);
+//   * reflector k: v = M(k:N,k)/scale, sigma = sign(v_k)*||v||, v_k += sigma, c_k = sigma*v_k,
+//     diag_k = -scale*sigma; trailing columns j: M(k:N,j) -= (v.M(k:N,j) / c_k) * v;
+//   * last diagonal entry is negated; Q accumulates reflectors 0..N-2 applied to the identity.
+template <int N>
+inline void householder_qr(double* M, double* Q)
+{
+    double diag[N], c[N];
+    double scale = 0.0;
+    for (int k = 0; k < N; ++k) {
+        double* vk = M + N * k;
+        for (int i = k; i < N; ++i) {
+            const double a = std::fabs(vk[i]);
+            if (scale < a) scale = a;
+        }
+        if (scale == 0.0) {
+            c[k] = diag[k] = 0.0;
+            continue;
+        }
+        for (int i = k; i < N; ++i) vk[i] /= scale;
+        double nrm2 = 0.0;
+        for (int i = k; i < N; ++i) nrm2 += vk[i] * vk[i];
+        const double sigma = vk[k] > 0.0 ? std::sqrt(nrm2) : -std::sqrt(nrm2);
+        vk[k] += sigma;
+        c[k] = sigma * vk[k];
+        diag[k] = -scale * sigma;
+        for (int j = k + 1; j < N; ++j) {
+            double* vj = M + N * j;
+            double dot = 0.0;
+            for (int i = k; i < N; ++i) dot += vk[i] * vj[i];
+            const double tau = dot / c[k];
+            for (int i = k; i < N; ++i) vj[i] -= tau * vk[i];
+        }
+    }
+    diag[N - 1] *= -1;
+    for (int i = 0; i < N; ++i) {
+        for (int j = 0; j < N; ++j) Q[i + N * j] = 0.0;
+        Q[i + N * i] = 1.0;
+    }
+    for (int k = 0; k < N - 1; ++k) {
+        if (c[k] == 0.0) continue;
+        const double* vk = M + N * k;
+        for (int j = 0; j < N; ++j) {
+            double dot = 0.0;
+            for (int i = k; i < N; ++i) dot += vk[i] * Q[j + N * i];
+            dot /= c[k];
+            for (int i = k; i < N; ++i) Q[j + N * i] -= dot * vk[i];
+        }
+    }
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) {
+            if (i == j) M[i + N * i] = diag[i];
+            else if (i > j) M[i + N * j] = 0.0;
+        }
+}
+
+// x = R^-1 b for upper-triangular column-major R (back substitution, last row first).
+template <int N>
+inline void back_substitute(const double* R, const double* b, double* x)
+{
+    x[N - 1] = b[N - 1] / R[(N - 1) * N + (N - 1)];
+    for (int i = N - 2; i >= 0; --i) {
+        x[i] = b[i];
+        for (int j = i + 1; j < N; ++j) x[i] -= R[j * N + i] * x[j];
+        x[i] = x[i] / R[i * N + i];
+    }
+}
+
+// (P^+)^T, 3x4 column-major, double in -> float out.  P: 3x4 column-major.
+inline void pinv_transpose(const double* P, float* out12)
+{
+    double G[9];  // Gram matrix P P^T (symmetric)
+    G[0] = P[0] * P[0] + P[3] * P[3] + P[6] * P[6] + P[9] * P[9];
+    G[1] = P[0] * P[1] + P[3] * P[4] + P[6] * P[7] + P[9] * P[10];
+    G[2] = P[0] * P[2] + P[3] * P[5] + P[6] * P[8] + P[9] * P[11];
+    G[4] = P[1] * P[1] + P[4] * P[4] + P[7] * P[7] + P[10] * P[10];
+    G[5] = P[1] * P[2] + P[4] * P[5] + P[7] * P[8] + P[10] * P[11];
+    G[8] = P[2] * P[2] + P[5] * P[5] + P[8] * P[8] + P[11] * P[11];
+    G[3] = G[1];
+    G[6] = G[2];
+    G[7] = G[5];
+    double Q[9], Ginv[9];
+    householder_qr<3>(G, Q);  // G := R
+    for (int col = 0; col < 3; ++col) {
+        double e[3] = {0.0, 0.0, 0.0}, qtb[3];
+        e[col] = 1.0;
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int i = 0; i < 3; ++i) s += e[i] * Q[i + 3 * j];
+            qtb[j] = s;
+        }
+        back_substitute<3>(G, qtb, Ginv + 3 * col);
+    }
+    for (int c4 = 0; c4 < 4; ++c4) {
+        const double* p = P + 3 * c4;
+        for (int r = 0; r < 3; ++r)
+            out12[3 * c4 + r] = (float)(p[0] * Ginv[3 * r + 0] + p[1] * Ginv[3 * r + 1] + p[2] * Ginv[3 * r + 2]);
+    }
+}
+
+// Source position: last column of Q in the QR of the 4x4 matrix (P^T | 0), scaled to w = 1.
+inline void source_position(const double* P, float* out4)
+{
+    double A[16], Q[16];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) A[c + 4 * r] = P[r + 3 * c];
+    for (int c = 0; c < 4; ++c) A[c + 12] = 0.0;
+    householder_qr<4>(A, Q);
+    for (int i = 0; i < 4; ++i) out4[i] = (float)(Q[i + 12] / Q[15]);
+}
+
+inline void cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline double det3(const double* a, const double* b, const double* c)
+{
+    return a[0] * (b[1] * c[2] - b[2] * c[1]) - b[0] * (a[1] * c[2] - a[2] * c[1]) +
+           c[0] * (a[1] * b[2] - a[2] * b[1]);
+}
+
+// ref: EpipolarConsistency.cpp:35-47 with getCameraFocalLengthPx (ProjectionMatrix.cpp:104-112)
+// and getCameraCenter (:70-76; the reference uses an SVD null space, any float64 null space
+// agrees to ~1e-13 -- here signed 3x3 minors).
+inline double object_radius(const double* P, int n_u, int n_v)
+{
+    const double m1[3] = {P[0], P[3], P[6]}, m2[3] = {P[1], P[4], P[7]}, m3[3] = {P[2], P[5], P[8]};
+    double U[3], V[3], t[3];
+    cross3(m3, m2, U);
+    double n = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+    U[0] /= n; U[1] /= n; U[2] /= n;
+    cross3(m3, m1, V);
+    n = std::sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+    V[0] /= n; V[1] /= n; V[2] /= n;
+    cross3(V, m3, t);
+    const double fu = m1[0] * t[0] + m1[1] * t[1] + m1[2] * t[2];
+    cross3(U, m3, t);
+    const double fv = m2[0] * t[0] + m2[1] * t[1] + m2[2] * t[2];
+    const double a = std::fabs(std::atan(0.5 * n_u / fu)), b = std::fabs(std::atan(0.5 * n_v / fv));
+    const double fov = a > b ? a : b;
+    double C[4] = {det3(P + 3, P + 6, P + 9), -det3(P, P + 6, P + 9), det3(P, P + 3, P + 9), -det3(P, P + 3, P + 6)};
+    if (C[3] < -1e-12 || C[3] > 1e-12) {
+        C[0] /= C[3]; C[1] /= C[3]; C[2] /= C[3];
+    }
+    return std::sin(fov) * std::sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+}
+
+}  // namespace ecc_host
+#endif

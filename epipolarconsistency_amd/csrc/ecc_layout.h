@@ -1,0 +1,65 @@
+// ecc_layout.h -- private HBM layout of one Radon intermediate ("dtr") and shared kernel params.
+//
+// The reference keeps a dtr as a CUDA texture over an n_t x n_alpha, alpha-fast array
+// (ref: LibEpipolarConsistency/RadonIntermediate.cu:44, RadonIntermediate.cpp:188-196) and lets the
+// texture unit do clamp addressing + bilinear filtering.  Here a dtr is a plain float slab laid
+// out for the pair kernel's gather pattern:
+//
+//   element (ix = angle bin, iy = distance bin)  ->  base[(ix + 1) * pitch + (iy + 1)]
+//
+//   * t (distance) is the FAST axis: along one epipolar-plane sweep the sampled line moves mostly
+//     in distance, so the 64 lanes of a wave (consecutive kappa samples) read a handful of
+//     contiguous 128-B lines instead of 64 different ones;
+//   * one replicated border row/column on every side (rows -1, n_alpha; columns -1, n_t) turns
+//     the texture unit's clamp addressing into plain in-bounds loads: a bilinear footprint never
+//     needs per-tap index clamps;
+//   * pitch is a multiple of 32 floats so every angle row starts on a 128-B line.
+#ifndef ECC_LAYOUT_H
+#define ECC_LAYOUT_H
+
+#include <stdint.h>
+
+static inline int ecc_layout_pitch(int n_t) { return ((n_t + 2) + 31) / 32 * 32; }
+static inline int ecc_layout_rows(int n_alpha) { return n_alpha + 2; }
+static inline int64_t ecc_layout_floats(int n_alpha, int n_t)
+{
+    return (int64_t)ecc_layout_rows(n_alpha) * ecc_layout_pitch(n_t);
+}
+
+// ---- Radon-intermediate kernel -------------------------------------------------------------
+struct EccRadonParams {
+    const float* images;   // n_img * n_v * n_u floats (row-major, x fastest)
+    float* out;            // n_img slabs in the private layout
+    const float* trig;     // 2 * n_alpha floats: (sinf(alpha), cosf(alpha)), alpha = (ix/n_alpha - .5)*Pi
+    int64_t image_stride;  // floats between images
+    int64_t out_stride;    // floats between slabs
+    int n_img;
+    int n_u, n_v;
+    int n_alpha, n_t;
+    int pitch;
+    int post_process;
+};
+
+// ---- pair kernel ---------------------------------------------------------------------------
+struct EccPairParams {
+    const float* const* dtrs;  // device table of slab base pointers, one per dtr
+    const float* Cs;           // 4 floats per view  (source positions, w = 1)
+    const float* PinvTs;       // 12 floats per view ((P^+)^T, 3x4 column-major)
+    const int32_t* indices;    // optional n_pairs x 4 (P0, P1, dtr0, dtr1); null = all pairs
+    float* pair_values;        // optional, `count` floats (local pair order)
+    float* cost;               // optional n x n cost image (index i + j*n)
+    float* K01_out;            // optional debug output, 16 floats per pair
+    int64_t first;             // first pair (get_ij order) handled by this launch
+    int64_t count;             // pairs handled by this launch
+    int n_views;
+    int n_alpha, n_t, pitch;
+    float n_x2, n_y2;          // half image size
+    float object_radius_mm;
+    float num_samples;         // n_t*step_t*2.f  (ref: ...RadonIntermediate.cu:320)
+    float range_t;             // n_t*step_t      (ref: ...RadonIntermediate.cu:372)
+    float dkappa_user;         // <=0: automatic
+    int k_limit;               // launch bound on the kappa index (ref: ...RadonIntermediate.cu:348-358)
+    int is_derivative;
+};
+
+#endif

@@ -1,0 +1,251 @@
+// pairs_kernel.hip -- all-pairs / index-list epipolar-consistency kernel for gfx950.
+//
+// One launch does what the reference needs two kernels, two device-wide syncs and N_kappa float
+// atomics per pair for (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cu):
+//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> computed in-kernel by the workgroup that owns
+//                                                    the pair, kept in LDS, never written to HBM;
+//   kernelEpipolarCosistency<deriv,false> (:152-276) -> one 256-thread workgroup per pair, kappa
+//                                                    samples strided over the lanes, wave64
+//                                                    shuffle + LDS reduction, ONE plain store.
+// Sampling replaces tex2D on a normalised, clamped, bilinear texture (ref: RadonIntermediate.cpp:192)
+// by the exact fp32 rule of SURVEY.md 8c on the padded, distance-fast slab of ecc_layout.h: two
+// 8-byte loads per sample (taps (i,j),(i,j+1) are adjacent), no index clamps.
+// The per-pair sum is carried in binary64 (the reference's atomicAdd order is arbitrary; the oracle
+// does the same), so results do not depend on the reduction tree.
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#include "ecc_layout.h"
+
+namespace {
+
+constexpr int PK_THREADS = 256;
+
+// ref: EpipolarConsistencyCommon.hxx:52-79 (get_ij), closed form: pairs before row i = i*n - i(i+1)/2.
+__device__ __forceinline__ void get_ij_closed(long long ij, int n, int& i, int& j)
+{
+    double nn = (double)n - 0.5;
+    int r = (int)floor(nn - sqrt(nn * nn - 2.0 * (double)ij));
+    r = max(0, min(r, n - 2));
+    // fix-up against rounding of the square root
+    while (r > 0 && (long long)r * n - (long long)r * (r + 1) / 2 > ij) --r;
+    while ((long long)(r + 1) * n - (long long)(r + 1) * (r + 2) / 2 <= ij) ++r;
+    i = r;
+    j = (int)(ij - ((long long)r * n - (long long)r * (r + 1) / 2)) + r + 1;
+}
+
+// ref: EpipolarConsistencyCommon.hxx:82-90 (shiftOriginAndNormlaize)
+__device__ __forceinline__ void shift_origin_and_normalize(float x, float y, float* Ki)
+{
+    Ki[2] += x * Ki[0] + y * Ki[1];
+    Ki[5] += x * Ki[3] + y * Ki[4];
+    float s0 = sqrtf(Ki[0] * Ki[0] + Ki[1] * Ki[1]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) Ki[i] /= s0;
+}
+
+// ref: EpipolarConsistencyCommon.hxx:93-149 (computeK01), same expressions in fp32.
+__device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0, const float* __restrict__ C1,
+                            const float* __restrict__ P0invT, const float* __restrict__ P1invT,
+                            float object_radius_mm, float num_samples, float dkappa, float* K0, float* K1)
+{
+    float B01 = C0[0] * C1[1] - C0[1] * C1[0];
+    float B02 = C0[0] * C1[2] - C0[2] * C1[0];
+    float B03 = C0[0] * C1[3] - C0[3] * C1[0];
+    float B12 = C0[1] * C1[2] - C0[2] * C1[1];
+    float B13 = C0[1] * C1[3] - C0[3] * C1[1];
+    float B23 = C0[2] * C1[3] - C0[3] * C1[2];
+    const float s2 = sqrtf(B12 * B12 + B02 * B02 + B01 * B01);
+    const float s3 = sqrtf(B03 * B03 + B13 * B13 + B23 * B23);
+    float K[8] = {+B12 / s2, -B02 / s2, +B01 / s2, 0,
+                  (-B01 * B13 - B02 * B23) / (s2 * s3), (+B01 * B03 - B12 * B23) / (s2 * s3),
+                  (+B02 * B03 + B12 * B13) / (s2 * s3), -s2 / s3};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float s0 = 0, s1 = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                s0 += P0invT[s * 3 + i] * K[j * 4 + s];
+                s1 += P1invT[s * 3 + i] * K[j * 4 + s];
+            }
+            K0[j * 3 + i] = s0;
+            K1[j * 3 + i] = s1;
+        }
+    shift_origin_and_normalize(n_x2, n_y2, K0);
+    shift_origin_and_normalize(n_x2, n_y2, K1);
+    K0[6] = s2 / s3;
+    K0[7] = -2.0f * atan2f(-0.5f * s3, s2 / s3);
+    const float Pi = 3.14159265359f;
+    if (K0[6] <= object_radius_mm) K1[7] = 0.5f * Pi;
+    else K1[7] = asinf(object_radius_mm / K0[6]);
+    if (dkappa <= 0.f) K1[6] = 2.f * K1[7] / num_samples;
+    else K1[6] = dkappa;
+}
+
+// Bilinear sample of a dtr slab at normalised texture coordinates (a, d) with clamp addressing
+// (SURVEY.md 8c): texel position a*n_alpha-.5, d*n_t-.5.  The replicated border of the slab stands
+// in for the per-tap index clamps.
+__device__ __forceinline__ float sample_dtr(const float* __restrict__ slab, int pitch, float n_alpha_f,
+                                            float n_t_f, float a, float d)
+{
+    float xa = a * n_alpha_f - 0.5f;
+    float yd = d * n_t_f - 0.5f;
+    xa = fminf(fmaxf(xa, -1.f), n_alpha_f - 1.f);
+    yd = fminf(fmaxf(yd, -1.f), n_t_f - 1.f);
+    float fi = floorf(xa), fj = floorf(yd);
+    float fx = xa - fi, fy = yd - fj;
+    int idx = ((int)fi + 1) * pitch + ((int)fj + 1);
+    float T00 = slab[idx], T01 = slab[idx + 1];                    // (i, j), (i, j+1)
+    float T10 = slab[idx + pitch], T11 = slab[idx + pitch + 1];    // (i+1, j), (i+1, j+1)
+    float r0 = (1.f - fx) * T00 + fx * T10;
+    float r1 = (1.f - fx) * T01 + fx * T11;
+    return (1.f - fy) * r0 + fy * r1;
+}
+
+// ref: ...RadonIntermediate.cu:71-84 (getRedundancy) + EpipolarConsistencyCommon.hxx:152-171
+// (lineToSampleDtr), same expressions.
+template <bool DERIV>
+__device__ __forceinline__ float redundancy(const float* K, const float* __restrict__ slab, int pitch,
+                                            float n_alpha_f, float n_t_f, float range_t, float x0, float x1)
+{
+    const float Pi = 3.14159265359f;
+    float l0 = K[0] * x0 + K[3] * x1;
+    float l1 = K[1] * x0 + K[4] * x1;
+    float l2 = K[2] * x0 + K[5] * x1;
+    float length = sqrtf(l0 * l0 + l1 * l1);
+    float a = atan2f(l1, l0) / Pi;
+    if (a < 0) a += 2;
+    float d = -(l2 / length) / range_t + 0.5f;
+    bool moved = false;
+    if (a > 1) {
+        a = a - 1.f;
+        d = 1.f - d;
+        moved = true;
+    }
+    float v = sample_dtr(slab, pitch, n_alpha_f, n_t_f, a, d);
+    return (DERIV && moved) ? -v : v;
+}
+
+template <bool DERIV>
+__global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
+{
+    __shared__ float sK[16];
+    __shared__ double s_part[PK_THREADS / 64];
+
+    // XCD-aware block -> pair mapping: blocks b and b+8 share an XCD (round-robin dispatch), so each
+    // XCD walks one contiguous eighth of the pair range and keeps view i's slab hot in its own L2.
+    const long long b = blockIdx.x;
+    const long long per_xcd = (p.count + 7) / 8;
+    const long long local = (b & 7) * per_xcd + (b >> 3);
+    if (local >= p.count) return;  // whole workgroup leaves together (before any barrier)
+
+    int iP0, iP1, iD0, iD1, ci = 0, cj = 0;
+    if (p.indices) {
+        const int32_t* q = p.indices + 4 * (p.first + local);
+        iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
+    } else {
+        get_ij_closed(p.first + local, p.n_views, ci, cj);
+        iP0 = iD0 = ci;
+        iP1 = iD1 = cj;
+    }
+
+    if (threadIdx.x == 0) {
+        float K0[8], K1[8];
+        if (iP0 == iP1) {  // same-pointer guard, ref: EpipolarConsistencyCommon.hxx:108-113
+            for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
+        } else {
+            compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0,
+                        p.PinvTs + 12 * iP1, p.object_radius_mm, p.num_samples, p.dkappa_user, K0, K1);
+        }
+        for (int i = 0; i < 8; i++) {
+            sK[i] = K0[i];
+            sK[8 + i] = K1[i];
+        }
+        if (p.K01_out)
+            for (int i = 0; i < 8; i++) {
+                p.K01_out[16 * local + i] = K0[i];
+                p.K01_out[16 * local + 8 + i] = K1[i];
+            }
+    }
+    __syncthreads();
+
+    float K0[8], K1[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        K0[i] = sK[i];
+        K1[i] = sK[8 + i];
+    }
+    const float* __restrict__ slab0 = p.dtrs[iD0];
+    const float* __restrict__ slab1 = p.dtrs[iD1];
+    const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
+    const float dkappa = K1[6], kappa_max = K1[7];
+
+    // ref: ...RadonIntermediate.cu:257-270 and :87-113
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < p.k_limit; k += PK_THREADS) {
+        float kappa = dkappa * 0.5f + dkappa * k;
+        if (kappa >= kappa_max) break;
+        float x0, x1;
+        sincosf(kappa, &x1, &x0);
+        float vp = redundancy<DERIV>(K0, slab0, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1) -
+                   redundancy<DERIV>(K1, slab1, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1);
+        x0 *= -1;
+        float vm = redundancy<DERIV>(K0, slab0, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1) -
+                   redundancy<DERIV>(K1, slab1, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1);
+        float consistency = (vp * vp + vm * vm) * K0[6];
+        acc += (double)(consistency * dkappa);
+    }
+
+    // wave64 shuffle reduction, then one LDS hop across the 4 waves
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < PK_THREADS / 64; w++) tot += s_part[w];
+        float val = (float)tot;
+        if (p.pair_values) p.pair_values[local] = val;
+        if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
+    }
+}
+
+// Deterministic float64 sum of `count` pair values (single workgroup, fixed tree).
+// ref: ...RadonIntermediate.cpp:216-224 (host loop; weights are all 1).
+__global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict__ vals, long long count,
+                                                         double* __restrict__ out)
+{
+    __shared__ double s[1024 / 64];
+    double acc = 0.0;
+    for (long long k = threadIdx.x; k < count; k += 1024) acc += (double)vals[k];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 1024 / 64; w++) tot += s[w];
+        *out = tot;
+    }
+}
+
+}  // namespace
+
+extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream)
+{
+    if (p->count <= 0) return hipSuccess;
+    long long per_xcd = (p->count + 7) / 8;
+    dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
+    if (p->is_derivative)
+        hipLaunchKernelGGL(pairs_kernel<true>, grid, block, 0, stream, *p);
+    else
+        hipLaunchKernelGGL(pairs_kernel<false>, grid, block, 0, stream, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, stream, vals, count, out);
+    return hipGetLastError();
+}

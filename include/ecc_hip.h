@@ -1,0 +1,168 @@
+/*
+ * ecc_hip.h -- C ABI of the MI355X-native epipolar-consistency hot path (libecc_hip.so).
+ *
+ * Drop-in boundary for the reference's Radon-intermediate + pair-consistency path
+ * (aaichert/EpipolarConsistency 1.2.2).  Plain C: opaque handles, raw pointers, int32 sizes,
+ * every function returns an int status (0 = ECC_OK), no exceptions, no exit().  Citations are
+ * relative to /root/reference/code/.  The reference-side bindings (what a maintainer adds to
+ * RadonIntermediate.cpp / EpipolarConsistencyRadonIntermediate.cpp) are shown in INTEGRATION.md;
+ * a header-only C++ adapter with the reference's class names lives in
+ * epipolarconsistency_amd/cpp/EpipolarConsistencyHip.hxx.
+ *
+ * Layout contracts (same as the reference unless stated):
+ *   - projection images: row-major float32, x (u) fastest, n_u x n_v;
+ *   - Radon intermediate ("dtr") as seen through this API: n_t rows x n_alpha columns float32,
+ *     alpha fastest, idx = iy*n_alpha + ix            (ref: LibEpipolarConsistency/RadonIntermediate.cu:44);
+ *   - projection matrices: 3x4 float64 column-major, 12 doubles per view (Eigen default; the
+ *     reference passes Ps[i].data(), ref: ...RadonIntermediate.cpp:148);
+ *   - cost image: n x n float32, entry (i,j), i<j at index i + j*n; other entries untouched
+ *     (ref: EpipolarConsistencyRadonIntermediate.cu:250,269; .cpp:183,214-221);
+ *   - index lists: int32 x 4 per pair = (P0, P1, dtr0, dtr1)    (ref: ...RadonIntermediate.cu:49-50,202).
+ * Device-resident dtrs are kept in a private transposed+padded layout (ECC_LAYOUT_T_FAST, see
+ * DESIGN.md "Data layout in HBM"); ecc_dtr_readback/ecc_dtr_from_host convert.
+ */
+#ifndef ECC_HIP_H
+#define ECC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECC_HIP_VERSION 100 /* 1.0.0 */
+
+/* status codes */
+enum {
+    ECC_OK = 0,
+    ECC_ERR_INVALID_ARGUMENT = 1,
+    ECC_ERR_HIP = 2,          /* a HIP runtime call failed: see ecc_last_error() */
+    ECC_ERR_OUT_OF_MEMORY = 3,
+    ECC_ERR_NO_DEVICE = 4,
+    ECC_ERR_UNSUPPORTED = 5
+};
+
+/* RadonIntermediate::Filter / ::PostProcess (ref: LibEpipolarConsistency/RadonIntermediate.h:21-29) */
+enum { ECC_FILTER_DERIVATIVE = 0, ECC_FILTER_RAMP = 1, ECC_FILTER_NONE = 2 };
+enum { ECC_POST_IDENTITY = 0, ECC_POST_SQUARE_ROOT = 1, ECC_POST_LOGARITHM = 2 };
+
+typedef struct ecc_ctx ecc_ctx;       /* one per (device, stream) */
+typedef struct ecc_dtr ecc_dtr;       /* one Radon intermediate  (ref: class RadonIntermediate) */
+typedef struct ecc_metric ecc_metric; /* ref: class MetricRadonIntermediate */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* ecc_last_error(void);
+int ecc_version(void);
+/* Number of HIP devices visible (0 when there is none; never fails). */
+int ecc_device_count(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* `stream` is a hipStream_t (may be NULL = the device's default stream).  All launches and
+ * copies of objects created from this context are ordered on it.  Replaces the reference's
+ * implicit "current device, default stream, cudaDeviceSynchronize after every launch". */
+int ecc_ctx_create(int device, void* stream, ecc_ctx** out);
+int ecc_ctx_destroy(ecc_ctx* ctx);
+int ecc_ctx_synchronize(ecc_ctx* ctx);
+
+/* ---- Radon intermediate (R1/R2) ------------------------------------------------------------ */
+/* Replaces computeDerivLineIntegrals(tex, n_x, n_y, n_alpha, n_t, filter, post, out_d)
+ * (ref: LibEpipolarConsistency/RadonIntermediate.cu:149-170) and the ctor
+ * RadonIntermediate(ImageView<float>, size_alpha, size_t, filter, post) (ref: RadonIntermediate.cpp:17-31).
+ * `image` is n_u*n_v floats on the host (image_on_device = 0) or on ctx's device (= 1).
+ * ECC_FILTER_RAMP is not implemented in this round (returns ECC_ERR_UNSUPPORTED). */
+int ecc_radon_compute(ecc_ctx* ctx, const float* image, int image_on_device, int n_u, int n_v,
+                      int n_alpha, int n_t, int filter, int post_process, ecc_dtr** out);
+
+/* Same for a stack of n images (n*n_u*n_v floats); writes n handles to out[0..n).  The n dtrs
+ * share one device slab; each handle is destroyed separately.  Work is asynchronous on the
+ * context's stream. */
+int ecc_radon_compute_batch(ecc_ctx* ctx, const float* images, int images_on_device, int n, int n_u,
+                            int n_v, int n_alpha, int n_t, int filter, int post_process,
+                            ecc_dtr** out);
+
+/* Wraps existing host data (alpha-fast, n_t x n_alpha), ref: RadonIntermediate(ImageView<float>)
+ * + replaceRadonIntermediateData (RadonIntermediate.cpp:69-80,105-123). */
+int ecc_dtr_from_host(ecc_ctx* ctx, const float* data, int n_alpha, int n_t, int n_u, int n_v,
+                      int filter, ecc_dtr** out);
+/* ref: RadonIntermediate::readback (RadonIntermediate.cpp:148-163); host gets alpha-fast data. */
+int ecc_dtr_readback(ecc_dtr* dtr, float* host_out);
+/* Getters, ref: RadonIntermediate.cpp:130-133,165-178.  bin_size_angle = Pi/n_alpha,
+ * bin_size_distance = sqrt(n_u^2+n_v^2)/n_t (RadonIntermediate.cpp:204-206). */
+int ecc_dtr_info(const ecc_dtr* dtr, int* n_alpha, int* n_t, int* n_u, int* n_v, int* filter,
+                 double* bin_size_angle, double* bin_size_distance);
+/* Device pointer + pitch of the private layout: element (ix, iy) lives at
+ * base[(ix + 1) * pitch + (iy + 1)], rows -1 and n_alpha and columns -1 and n_t replicate the
+ * border (clamp addressing).  For callers that want to all-gather dtrs between GPUs. */
+int ecc_dtr_device_view(const ecc_dtr* dtr, float** base, int* pitch, int* rows);
+/* Size in floats of one dtr in the private layout, so that a caller (e.g. torch) can own the slab. */
+int64_t ecc_dtr_slab_floats(int n_alpha, int n_t);
+/* Adopt caller-owned device memory already holding a dtr in the private layout (no copy, no free). */
+int ecc_dtr_wrap_device(ecc_ctx* ctx, float* base, int n_alpha, int n_t, int n_u, int n_v, int filter,
+                        ecc_dtr** out);
+int ecc_dtr_destroy(ecc_dtr* dtr);
+
+/* ---- metric (E1..E5) ----------------------------------------------------------------------- */
+/* ref: MetricRadonIntermediate(Ps, dtrs) / setRadonIntermediates (…RadonIntermediate.cpp:53-66,87-106).
+ * The metric borrows the dtrs ("DO NOT delete or change _dtrs during lifetime", .h:45).  Sizes and
+ * the derivative flag are taken from dtrs[0] only, as the reference does (.cpp:92-98). */
+int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs, ecc_metric** out);
+int ecc_metric_destroy(ecc_metric* m);
+
+/* ref: MetricRadonIntermediate::setProjectionMatrices (…RadonIntermediate.cpp:134-163): per view
+ * (P^+)^T and the source position in float64 (same Householder-QR arithmetic as
+ * culaut/xprojectionmatrix.hxx:20-52,93-105), cast to float32 and uploaded asynchronously. */
+int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n_views);
+
+/* ref: Metric::setObjectRadius / setEpipolarPlaneStep / MetricRadonIntermediate::useCorrelation
+ * (EpipolarConsistency.cpp:70-90, …RadonIntermediate.cpp:80-85).  0 = automatic for both scalars.
+ * use_corr != 0 is not implemented in this round (ECC_ERR_UNSUPPORTED at evaluate). */
+int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa, int use_corr);
+/* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
+ * from the FIRST projection matrix. */
+int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);
+
+/* All-pairs evaluate, ref: double MetricRadonIntermediate::evaluate(float* out)
+ * (…RadonIntermediate.cpp:166-225) = K01 + pair kernel + host mean.  cost_nxn (host, nullable) is
+ * read-modify-written exactly like the reference's `out`.  *mean = sum_pairs / n_pairs. */
+int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean);
+
+/* Multi-GPU building block: evaluate only pairs ij in [first, first+count) of the get_ij order
+ * (ref: EpipolarConsistencyCommon.hxx:52-79); returns the partial sum (float64) -- the caller
+ * all-reduces {sum, count}.  pair_values (host, nullable) receives `count` floats. */
+int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values,
+                              double* partial_sum);
+
+/* Asynchronous form for callers that own the device buffers (torch): nothing is copied to the
+ * host and the call does not synchronise.  pair_values_d: `count` floats on the device
+ * (nullable); sum_d: one double on the device, overwritten with the partial sum. */
+int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int64_t count,
+                                    float* pair_values_d, double* sum_d);
+
+/* Index-list evaluate, ref: evaluate(const std::vector<Eigen::Vector4i>&, float*)
+ * (…RadonIntermediate.cpp:267-322).  idx4: n_pairs x 4 int32 on the host.  Indices are range
+ * checked in every build (the reference only checks under _DEBUG, .cpp:248-264). */
+int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int n_pairs, float* out,
+                              double* mean);
+
+/* Debug: the 16 K01 floats per pair the kernel used (ref: kernelEpipolarConsistencyComputeK01,
+ * …RadonIntermediate.cu:13-67), for ij in [first, first+count).  Host output. */
+int ecc_metric_debug_K01(ecc_metric* m, int64_t first, int64_t count, float* K01s);
+
+/* ---- helpers shared with callers ------------------------------------------------------------ */
+/* ref: get_ij (EpipolarConsistencyCommon.hxx:52-79), closed form. */
+void ecc_get_ij(int64_t ij, int n, int* i, int* j);
+/* Host-side E1/E5 pieces, exported for tests and for callers that shard work themselves. */
+void ecc_host_pinvT(const double* P, float* PinvT12);
+void ecc_host_source_position(const double* P, float* C4);
+double ecc_host_object_radius(const double* P, int n_u, int n_v);
+
+/* Last kernel timings measured with HIP events on the context's stream (ms), for bench.py:
+ * which = 0 pair kernel of the last evaluate, 1 Radon kernel of the last radon_compute[_batch].
+ * Timing is off by default (no events recorded); enable with ecc_ctx_enable_timing. */
+int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable);
+int ecc_ctx_last_kernel_ms(ecc_ctx* ctx, int which, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECC_HIP_H */

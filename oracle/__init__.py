@@ -1,0 +1,221 @@
+"""ctypes doorway onto the CPU oracle (oracle/ecc_oracle.c) and, when built, onto the reference's
+own headers (oracle/_ref/libecc_ref.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under epipolarconsistency_amd/ imports this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(native=False):
+    """(Re)build the oracle with oracle/Makefile.  Building the checker is not using it."""
+    target = ["native"] if native else []
+    subprocess.run(["make", "-s", "-C", _HERE] + target, check=True)
+
+
+def _load(name, native=False):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build(native=native)
+    return C.CDLL(path)
+
+
+_lib = None
+_ref = None
+
+
+def lib(native=False):
+    """The oracle shared library (portable build, or -march=native for CPU-baseline timing)."""
+    global _lib
+    if native:
+        return _bind(_load("libecc_oracle_native.so", native=True))
+    if _lib is None:
+        _lib = _bind(_load("libecc_oracle.so"))
+    return _lib
+
+
+def _bind(L):
+    L.eccor_pinvT.argtypes = [_f64p, _f32p]
+    L.eccor_source_position.argtypes = [_f64p, _f32p]
+    L.eccor_camera_center.argtypes = [_f64p, _f64p]
+    L.eccor_focal_length_px.argtypes = [_f64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.eccor_object_radius.argtypes = [_f64p, C.c_int, C.c_int]
+    L.eccor_object_radius.restype = C.c_double
+    L.eccor_get_ij.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.eccor_computeK01.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_void_p, _f32p, _f32p,
+                                   C.c_float, C.c_float, C.c_float, _f32p, _f32p]
+    L.eccor_line_to_sample_dtr.argtypes = [_f32p, C.c_float]
+    L.eccor_line_to_sample_dtr.restype = C.c_int
+    L.eccor_tex2d.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.eccor_tex2d.restype = C.c_float
+    L.eccor_tex2d_norm.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.eccor_tex2d_norm.restype = C.c_float
+    L.eccor_radon.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
+                              C.POINTER(C.c_longlong)]
+    L.eccor_radon_bins.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _i32p, C.c_int, _f32p]
+    L.eccor_evaluate_all.argtypes = [C.c_int, _f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_longlong)]
+    L.eccor_evaluate_all.restype = C.c_double
+    L.eccor_evaluate_pairs.argtypes = [C.c_int, _f64p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _i32p,
+                                       C.c_int, _f32p, C.c_void_p]
+    L.eccor_evaluate_pairs.restype = C.c_double
+    L.eccor_num_threads.restype = C.c_int
+    return L
+
+
+def ref():
+    """The reference's own headers behind extern "C" (oracle/ref_shim.cpp), or None if the
+    prebuilt oracle/_ref/libecc_ref.so is absent and the reference tree is not present."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libecc_ref.so")
+        if not os.path.exists(path):
+            if not os.path.isdir("/root/reference/code"):
+                return None
+            build()
+        R = C.CDLL(path)
+        R.ref_pinvT.argtypes = [_f64p, _f32p]
+        R.ref_source_position.argtypes = [_f64p, _f32p]
+        R.ref_get_ij.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        R.ref_computeK01.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_void_p, _f32p, _f32p,
+                                     C.c_float, C.c_float, C.c_float, _f32p, _f32p]
+        R.ref_line_to_sample_dtr.argtypes = [_f32p, C.c_float]
+        R.ref_line_to_sample_dtr.restype = C.c_int
+        R.ref_weighting.argtypes = [C.c_float]
+        R.ref_weighting.restype = C.c_float
+        _ref = R
+    return _ref
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy-level helpers
+# ---------------------------------------------------------------------------------------------
+
+def _P(P):
+    """3x4 matrix (any layout numpy gives) -> 12 doubles column-major (Eigen default)."""
+    P = np.asarray(P, dtype=np.float64).reshape(3, 4)
+    return np.ascontiguousarray(P.T).reshape(12)
+
+
+def pack_Ps(Ps):
+    return np.ascontiguousarray(np.stack([_P(P) for P in Ps]).reshape(-1))
+
+
+def pinvT(P, use_ref=False):
+    out = np.zeros(12, np.float32)
+    (ref().ref_pinvT if use_ref else lib().eccor_pinvT)(_P(P), out)
+    return out
+
+
+def source_position(P, use_ref=False):
+    out = np.zeros(4, np.float32)
+    (ref().ref_source_position if use_ref else lib().eccor_source_position)(_P(P), out)
+    return out
+
+
+def object_radius(P, n_u, n_v):
+    return lib().eccor_object_radius(_P(P), int(n_u), int(n_v))
+
+
+def get_ij(ij, n, use_ref=False):
+    i, j = C.c_int(), C.c_int()
+    (ref().ref_get_ij if use_ref else lib().eccor_get_ij)(ij, n, C.byref(i), C.byref(j))
+    return i.value, j.value
+
+
+def computeK01(n_x2, n_y2, C0, C1, P0invT, P1invT, object_radius_mm, num_samples, dkappa=0.0,
+               use_ref=False):
+    C0 = np.ascontiguousarray(C0, np.float32)
+    C1 = np.ascontiguousarray(C1, np.float32)
+    P0 = np.ascontiguousarray(P0invT, np.float32)
+    P1 = np.ascontiguousarray(P1invT, np.float32)
+    K0 = np.zeros(8, np.float32)
+    K1 = np.zeros(8, np.float32)
+    f = ref().ref_computeK01 if use_ref else lib().eccor_computeK01
+    f(n_x2, n_y2, C0.ctypes.data, C1.ctypes.data, P0, P1, object_radius_mm, num_samples, dkappa,
+      K0, K1)
+    return K0, K1
+
+
+def line_to_sample_dtr(line, range_t, use_ref=False):
+    l = np.ascontiguousarray(line, np.float32).copy()
+    f = ref().ref_line_to_sample_dtr if use_ref else lib().eccor_line_to_sample_dtr
+    moved = f(l, range_t)
+    return l, bool(moved)
+
+
+def radon(img, n_alpha, n_t, filter=0, post=0, count_fetches=False):
+    """img: (n_v, n_u) float32.  Returns (n_t, n_alpha) float32 [, fetch count]."""
+    img = np.ascontiguousarray(img, np.float32)
+    n_v, n_u = img.shape
+    out = np.zeros((n_t, n_alpha), np.float32)
+    nf = C.c_longlong(0)
+    lib().eccor_radon(img, n_u, n_v, n_alpha, n_t, filter, post, out, C.byref(nf))
+    return (out, nf.value) if count_fetches else out
+
+
+def radon_bins(img, n_alpha, n_t, bins, filter=0, post=0):
+    img = np.ascontiguousarray(img, np.float32)
+    n_v, n_u = img.shape
+    bins = np.ascontiguousarray(bins, np.int32)
+    out = np.zeros(len(bins), np.float32)
+    lib().eccor_radon_bins(img, n_u, n_v, n_alpha, n_t, filter, post, bins, len(bins), out)
+    return out
+
+
+def _dtr_ptrs(dtrs):
+    keep = [np.ascontiguousarray(d, np.float32) for d in dtrs]
+    arr = (C.c_void_p * len(keep))(*[d.ctypes.data for d in keep])
+    return keep, arr
+
+
+def evaluate_all(Ps, dtrs, n_u, n_v, object_radius_mm=0.0, dkappa=0.0, is_derivative=True,
+                 cost=None, want_K01=False, native=False):
+    """All-pairs ECC.  dtrs: list of (n_t, n_alpha) float32.  Returns dict(mean, pairs, cost, K01s,
+    n_kappa)."""
+    n = len(dtrs)
+    n_t, n_alpha = dtrs[0].shape
+    keep, arr = _dtr_ptrs(dtrs)
+    n_pairs = n * (n - 1) // 2
+    pairs = np.zeros(n_pairs, np.float32)
+    if cost is None:
+        cost = np.zeros((n, n), np.float32)
+    cost = np.ascontiguousarray(cost, np.float32)
+    K01s = np.zeros((n_pairs, 16), np.float32) if want_K01 else None
+    nk = C.c_longlong(0)
+    mean = lib(native).eccor_evaluate_all(
+        n, pack_Ps(Ps), arr, n_u, n_v, n_alpha, n_t, float(object_radius_mm), float(dkappa),
+        1 if is_derivative else 0, cost.ctypes.data, pairs.ctypes.data,
+        K01s.ctypes.data if want_K01 else None, C.byref(nk))
+    return dict(mean=mean, pairs=pairs, cost=cost, K01s=K01s, n_kappa=nk.value)
+
+
+def evaluate_pairs(Ps, dtrs, n_u, n_v, idx4, object_radius_mm=0.0, dkappa=0.0, is_derivative=True,
+                   native=False):
+    n_t, n_alpha = dtrs[0].shape
+    keep, arr = _dtr_ptrs(dtrs)
+    idx4 = np.ascontiguousarray(idx4, np.int32).reshape(-1, 4)
+    out = np.zeros(len(idx4), np.float32)
+    mean = lib(native).eccor_evaluate_pairs(
+        len(Ps), pack_Ps(Ps), len(dtrs), arr, n_u, n_v, n_alpha, n_t, float(object_radius_mm),
+        float(dkappa), 1 if is_derivative else 0, idx4.reshape(-1), len(idx4), out, None)
+    return dict(mean=mean, pairs=out)
+
+
+def set_variant(v):
+    """0 = normative fp32 path; 1 = line->(angle,distance) mapping in binary64 (noise-floor probe)."""
+    L = lib()
+    L.eccor_set_variant.argtypes = [C.c_int]
+    L.eccor_set_variant(int(v))

@@ -1,0 +1,637 @@
+/*
+ * ecc_oracle.c -- CPU ORACLE for the epipolar-consistency hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the reference's algorithm (aaichert/EpipolarConsistency,
+ * lib 1.2.2) for the Radon-intermediate + all-pairs ECC path.  It is the checker the HIP path is
+ * compared against.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it; the product library (epipolarconsistency_amd/csrc) never links, includes or calls it.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle"):
+ *   - E1/E2 geometry (pseudo-inverse, source position, computeK01, lineToSampleDtr, get_ij) is
+ *     PINNED: tests compare it against the reference's own host-compilable headers built into
+ *     oracle/_ref/libecc_ref.so (oracle/Makefile) and against the known-answer scalars of the
+ *     example pair recorded in SURVEY.md 8c.
+ *   - R1 (radonDerivative) and E3 (kernelEpipolarCosistency) exist in the reference only as CUDA
+ *     kernels that cannot be compiled or run here and the reference ships no tests or golden
+ *     vectors for them: for those two bodies PARITY IS UNPINNED -- this restatement follows the
+ *     reference source line by line and is the normative definition.
+ *
+ * Arithmetic convention: every float expression is the reference's C++ source expression
+ * evaluated in IEEE-754 binary32, left to right, WITHOUT fused contraction (build with
+ * -ffp-contract=off; see oracle/Makefile).  CUDA's hardware bilinear filter (9-bit weights)
+ * is replaced by the exact fp32 rule of SURVEY.md 8c ("normative sampling rule").
+ * Per-pair sums (atomicAdd in arbitrary order in the reference) are accumulated in binary64
+ * and rounded once to float.
+ *
+ * All "ref:" citations are relative to /root/reference/code/.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ECCOR_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* E1: per-view pre-compute (double in, float out)                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Householder QR of a square N x N column-major matrix, A := R, Q explicit.
+ * ref: LibUtilsCuda/culaut/xgeinv.hxx:40-105 (xsqqr).  Quirk kept: `scale` is a running
+ * maximum over all columns processed so far (initialised once, :47).  abs() is taken as the
+ * floating-point absolute value (what nvcc/MSVC resolve it to). */
+static void or_sqqr(int N, double *A, double *Q)
+{
+    double d[4], c[4];
+    double scale = 0.0, sigma = 0.0, sum = 0.0, tau = 0.0;
+    int i, j, k;
+    for (k = 0; k < N; k++) {
+        for (i = k; i < N; i++)
+            if (scale < fabs(A[i + N * k])) scale = fabs(A[i + N * k]);
+        if (scale == 0.0) {
+            c[k] = d[k] = 0.0;
+        } else {
+            for (i = k; i < N; i++) A[i + N * k] /= scale;
+            for (sum = 0.0, i = k; i < N; i++) sum += A[i + N * k] * A[i + N * k];
+            sigma = A[k + N * k] > 0.0 ? sqrt(sum) : -sqrt(sum);
+            A[k + N * k] += sigma;
+            c[k] = sigma * A[k + N * k];
+            d[k] = -scale * sigma;
+            for (j = k + 1; j < N; j++) {
+                for (sum = 0.0, i = k; i < N; i++) sum += A[i + N * k] * A[i + N * j];
+                tau = sum / c[k];
+                for (i = k; i < N; i++) A[i + N * j] -= tau * A[i + N * k];
+            }
+        }
+    }
+    d[N - 1] *= -1;
+    if (Q) {
+        for (i = 0; i < N; i++) {
+            for (j = 0; j < N; j++) Q[i + N * j] = 0.0;
+            Q[i + N * i] = 1.0;
+        }
+        for (k = 0; k < N - 1; k++)
+            if (c[k] != 0.0)
+                for (j = 0; j < N; j++) {
+                    sum = 0.0;
+                    for (i = k; i < N; i++) sum += A[i + N * k] * Q[j + N * i];
+                    sum /= c[k];
+                    for (i = k; i < N; i++) Q[j + N * i] -= sum * A[i + N * k];
+                }
+    }
+    for (i = 0; i < N; i++)
+        for (j = 0; j < N; j++) {
+            if (i == j) A[i + N * i] = d[i];
+            else if (i < j) { /* keep */ }
+            else A[i + N * j] = 0;
+        }
+}
+
+/* ref: xgeinv.hxx:108-119 (xutsolve) */
+static void or_utsolve(int N, const double *A, const double *b, double *x)
+{
+    int i, j;
+    x[N - 1] = b[N - 1] / A[(N - 1) * N + (N - 1)];
+    for (i = N - 2; i >= 0; i--) {
+        x[i] = b[i];
+        for (j = i + 1; j < N; j++) x[i] -= A[j * N + i] * x[j];
+        x[i] = x[i] / A[i * N + i];
+    }
+}
+
+/* ref: xgeinv.hxx:137-168 (xsqqrsolve + xgeinv), N = 3 */
+static void or_geinv3(const double *Ain, double *Ainv)
+{
+    double Q[9], R[9], unit[3] = {0, 0, 0}, Qtb[3];
+    int i, j, c;
+    for (i = 0; i < 9; i++) R[i] = Ain[i];
+    or_sqqr(3, R, Q);
+    for (c = 0; c < 3; c++) {
+        unit[c] = 1;
+        for (j = 0; j < 3; j++) {
+            double sum = 0;
+            for (i = 0; i < 3; i++) sum += unit[i] * Q[i + 3 * j];
+            Qtb[j] = sum;
+        }
+        or_utsolve(3, R, Qtb, Ainv + c * 3);
+        unit[c] = 0;
+    }
+}
+
+/* (P^+)^T as 3x4 column-major float.  P is 3x4 column-major double.
+ * ref: LibUtilsCuda/culaut/xprojectionmatrix.hxx:20-52 */
+ECCOR_API void eccor_pinvT(const double *P, float *PinvT)
+{
+    double PPT[9], PPTinv[9];
+    int r;
+    PPT[0] = P[0] * P[0] + P[3] * P[3] + P[6] * P[6] + P[9] * P[9];
+    PPT[1] = P[0] * P[1] + P[3] * P[4] + P[6] * P[7] + P[9] * P[10];
+    PPT[2] = P[0] * P[2] + P[3] * P[5] + P[6] * P[8] + P[9] * P[11];
+    PPT[4] = P[1] * P[1] + P[4] * P[4] + P[7] * P[7] + P[10] * P[10];
+    PPT[5] = P[1] * P[2] + P[4] * P[5] + P[7] * P[8] + P[10] * P[11];
+    PPT[8] = P[2] * P[2] + P[5] * P[5] + P[8] * P[8] + P[11] * P[11];
+    PPT[3] = PPT[1]; PPT[6] = PPT[2]; PPT[7] = PPT[5];
+    or_geinv3(PPT, PPTinv);
+    for (r = 0; r < 4; r++) {
+        const double *p = P + 3 * r;
+        PinvT[3 * r + 0] = (float)(p[0] * PPTinv[0] + p[1] * PPTinv[1] + p[2] * PPTinv[2]);
+        PinvT[3 * r + 1] = (float)(p[0] * PPTinv[3] + p[1] * PPTinv[4] + p[2] * PPTinv[5]);
+        PinvT[3 * r + 2] = (float)(p[0] * PPTinv[6] + p[1] * PPTinv[7] + p[2] * PPTinv[8]);
+    }
+}
+
+/* Homogeneous source position (w = 1) via QR of (P^T | 0).
+ * ref: LibUtilsCuda/culaut/xprojectionmatrix.hxx:93-105 */
+ECCOR_API void eccor_source_position(const double *P, float *C)
+{
+    double Q[16], R[16];
+    int i, j;
+    for (i = 0; i < 3; i++)
+        for (j = 0; j < 4; j++) R[j + 4 * i] = P[i + 3 * j];
+    for (j = 0; j < 4; j++) R[j + 4 * 3] = 0;
+    or_sqqr(4, R, Q);
+    for (i = 0; i < 4; i++) C[i] = (float)(Q[i + 4 * 3] / Q[3 + 4 * 3]);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* E5: default object radius                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+static void or_cross(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static double or_det3(const double *a, const double *b, const double *c) /* columns */
+{
+    return a[0] * (b[1] * c[2] - b[2] * c[1]) - b[0] * (a[1] * c[2] - a[2] * c[1]) +
+           c[0] * (a[1] * b[2] - a[2] * b[1]);
+}
+
+/* Camera centre, normalised to w = 1 when |w| > 1e-12.  The reference takes the SVD null space
+ * (Eigen, absent here); any f64 null space agrees to ~1e-13 -- here: signed 3x3 minors.
+ * ref: LibProjectiveGeometry/ProjectionMatrix.cpp:70-76 */
+ECCOR_API void eccor_camera_center(const double *P, double *C)
+{
+    const double *c0 = P, *c1 = P + 3, *c2 = P + 6, *c3 = P + 9;
+    C[0] = or_det3(c1, c2, c3);
+    C[1] = -or_det3(c0, c2, c3);
+    C[2] = or_det3(c0, c1, c3);
+    C[3] = -or_det3(c0, c1, c2);
+    if (C[3] < -1e-12 || C[3] > 1e-12) {
+        C[0] /= C[3]; C[1] /= C[3]; C[2] /= C[3]; C[3] = 1.0;
+    }
+}
+
+/* ref: LibProjectiveGeometry/ProjectionMatrix.cpp:104-112 (getCameraFocalLengthPx) */
+ECCOR_API void eccor_focal_length_px(const double *P, double *fu, double *fv)
+{
+    double m1[3] = {P[0], P[3], P[6]}, m2[3] = {P[1], P[4], P[7]}, m3[3] = {P[2], P[5], P[8]};
+    double U[3], V[3], t[3], n;
+    or_cross(m3, m2, U); n = sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+    U[0] /= n; U[1] /= n; U[2] /= n;
+    or_cross(m3, m1, V); n = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+    V[0] /= n; V[1] /= n; V[2] /= n;
+    or_cross(V, m3, t); *fu = m1[0] * t[0] + m1[1] * t[1] + m1[2] * t[2];
+    or_cross(U, m3, t); *fv = m2[0] * t[0] + m2[1] * t[1] + m2[2] * t[2];
+}
+
+/* ref: LibEpipolarConsistency/EpipolarConsistency.cpp:35-47 (estimateObjectRadius) */
+ECCOR_API double eccor_object_radius(const double *P, int n_u, int n_v)
+{
+    double fu, fv, C[4], fov, a, b, sid;
+    eccor_focal_length_px(P, &fu, &fv);
+    a = fabs(atan(0.5 * n_u / fu));
+    b = fabs(atan(0.5 * n_v / fv));
+    fov = a > b ? a : b;
+    eccor_camera_center(P, C);
+    sid = sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+    return sin(fov) * sid;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* E2: pair geometry                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ref: LibEpipolarConsistency/EpipolarConsistencyCommon.hxx:52-79 (get_ij) */
+ECCOR_API void eccor_get_ij(int ij, int n, int *pi, int *pj)
+{
+    int i = 0, k = ij + 1;
+    while (k > n - i - 1) { i++; k -= (n - i); }
+    *pi = i; *pj = k + i;
+}
+
+/* ref: EpipolarConsistencyCommon.hxx:82-90 (shiftOriginAndNormlaize) */
+static void or_shift_origin_and_normalize(float x, float y, float *Ki)
+{
+    float s0;
+    int i;
+    Ki[2] += x * Ki[0] + y * Ki[1];
+    Ki[5] += x * Ki[3] + y * Ki[4];
+    s0 = sqrtf(Ki[0] * Ki[0] + Ki[1] * Ki[1]);
+    for (i = 0; i < 6; i++) Ki[i] /= s0;
+}
+
+/* C(3x2) = A(3x4) * B(4x2), column-major, sum starts at 0 and adds s = 0..3 in order.
+ * ref: EpipolarConsistencyCommon.hxx:39-50 (xgemm<float,3,4,2>) */
+static void or_gemm_3_4_2(const float *A, const float *B, float *C)
+{
+    int i, j, s;
+    for (i = 0; i < 3; i++)
+        for (j = 0; j < 2; j++) {
+            float sum = 0;
+            for (s = 0; s < 4; s++) sum += A[s * 3 + i] * B[j * 4 + s];
+            C[j * 3 + i] = sum;
+        }
+}
+
+/* ref: EpipolarConsistencyCommon.hxx:93-149 (computeK01).  K0[6] baseline distance,
+ * K0[7] view angle, K1[6] dkappa, K1[7] kappa_max. */
+ECCOR_API void eccor_computeK01(float n_x2, float n_y2, const float *C0, const float *C1,
+                                const float *P0invT, const float *P1invT, float object_radius_mm,
+                                float num_samples, float dkappa, float *K0, float *K1)
+{
+    int i;
+    if (C0 == C1) {
+        for (i = 0; i < 8; i++) K0[i] = 0;
+        for (i = 0; i < 8; i++) K1[i] = 0;
+        return;
+    }
+    {
+        float B01 = C0[0] * C1[1] - C0[1] * C1[0];
+        float B02 = C0[0] * C1[2] - C0[2] * C1[0];
+        float B03 = C0[0] * C1[3] - C0[3] * C1[0];
+        float B12 = C0[1] * C1[2] - C0[2] * C1[1];
+        float B13 = C0[1] * C1[3] - C0[3] * C1[1];
+        float B23 = C0[2] * C1[3] - C0[3] * C1[2];
+        const float s2 = sqrtf(B12 * B12 + B02 * B02 + B01 * B01);
+        const float s3 = sqrtf(B03 * B03 + B13 * B13 + B23 * B23);
+        float K[8];
+        const float Pi = 3.14159265359f;
+        K[0] = +B12 / s2; K[1] = -B02 / s2; K[2] = +B01 / s2; K[3] = 0;
+        K[4] = (-B01 * B13 - B02 * B23) / (s2 * s3);
+        K[5] = (+B01 * B03 - B12 * B23) / (s2 * s3);
+        K[6] = (+B02 * B03 + B12 * B13) / (s2 * s3);
+        K[7] = -s2 / s3;
+        or_gemm_3_4_2(P0invT, K, K0);
+        or_gemm_3_4_2(P1invT, K, K1);
+        or_shift_origin_and_normalize(n_x2, n_y2, K0);
+        or_shift_origin_and_normalize(n_x2, n_y2, K1);
+        K0[6] = s2 / s3;
+        K0[7] = -2.0f * atan2f(-0.5f * s3, s2 / s3);
+        if (K0[6] <= object_radius_mm) K1[7] = 0.5f * Pi;
+        else K1[7] = asinf(object_radius_mm / K0[6]);
+        if (dkappa <= 0.f) K1[6] = 2.f * K1[7] / num_samples;
+        else K1[6] = dkappa;
+    }
+}
+
+/* ref: EpipolarConsistencyCommon.hxx:152-171 (lineToSampleDtr).  line[0] <- angle/Pi in [0,1],
+ * line[1] <- distance in [0,1]; returns 1 when the (alpha+Pi, -t) periodicity was used. */
+ECCOR_API int eccor_line_to_sample_dtr(float *line, float range_t)
+{
+    const float Pi = 3.14159265359f;
+    float length = sqrtf(line[0] * line[0] + line[1] * line[1]);
+    line[0] = atan2f(line[1], line[0]) / Pi;
+    if (line[0] < 0) line[0] += 2;
+    line[1] = -(line[2] / length) / range_t + 0.5f;
+    if (line[0] > 1) {
+        line[0] = line[0] - 1.f;
+        line[1] = 1.f - line[1];
+        return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Normative sampling rule replacing CUDA texture hardware                      */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline int or_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* Un-normalised coordinates, linear filter, clamp addressing; img is row-major, x fastest.
+ * Models cudaTextureObject_t built at ref: LibUtilsCuda/CudaBindlessTexture.cpp:25-39. */
+ECCOR_API float eccor_tex2d(const float *img, int W, int H, float x, float y)
+{
+    float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float fx = xb - fi, fy = yb - fj;
+    int i = (int)fi, j = (int)fj;
+    int i0 = or_clampi(i, 0, W - 1), i1 = or_clampi(i + 1, 0, W - 1);
+    int j0 = or_clampi(j, 0, H - 1), j1 = or_clampi(j + 1, 0, H - 1);
+    float T00 = img[(size_t)j0 * W + i0], T10 = img[(size_t)j0 * W + i1];
+    float T01 = img[(size_t)j1 * W + i0], T11 = img[(size_t)j1 * W + i1];
+    float r0 = (1.f - fx) * T00 + fx * T10;
+    float r1 = (1.f - fx) * T01 + fx * T11;
+    return (1.f - fy) * r0 + fy * r1;
+}
+
+/* Normalised coordinates (dtr textures, ref: RadonIntermediate.cpp:192). */
+ECCOR_API float eccor_tex2d_norm(const float *img, int W, int H, float s, float t)
+{
+    return eccor_tex2d(img, W, H, s * (float)W, t * (float)H);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* R1: Radon intermediate                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ref: RadonIntermediate.cu:18-29 (sort4) */
+static void or_sort4(float *v)
+{
+    int i, j;
+    for (j = 0; j < 3; j++)
+        for (i = 0; i < 3; i++)
+            if (v[i] > v[i + 1]) { float tmp = v[i]; v[i] = v[i + 1]; v[i + 1] = tmp; }
+}
+
+/* One Radon bin.  filter: 0 Derivative, 1 Ramp (unfiltered here), 2 None; post: 0/1/2.
+ * ref: RadonIntermediate.cu:32-143 (radonDerivative<derivative>); *fetches += #bilinear fetches. */
+static float or_radon_bin(const float *img, int W, int H, int n_alpha, int n_t, int ix, int iy,
+                          int filter, int post, long long *fetches)
+{
+    const float Pi = 3.14159265359f; /* __constant__ float Pi, RadonIntermediate.cu:8 */
+    const float n_u = (float)W, n_v = (float)H;
+    float l[3], o[2], d[2], ts[4], t, t_max, sum = 0;
+    const float step = .66f;
+    long long nf = 0;
+    float x_rel = (ix / (float)n_alpha - 0.5f);
+    float y_rel = (iy / (float)n_t - 0.5f);
+    float diag = sqrtf(n_u * n_u + n_v * n_v);
+    float alpha = x_rel * Pi;
+    float tau = y_rel * diag;
+    l[0] = -sinf(alpha);
+    l[1] = cosf(alpha);
+    l[2] = -tau;
+    l[2] += -0.5f * n_u * l[0] - 0.5f * n_v * l[1];
+    o[0] = -l[2] * l[0];
+    o[1] = -l[2] * l[1];
+    d[0] = l[1];
+    d[1] = -l[0];
+    ts[0] = (1.f - o[0]) / d[0];
+    ts[1] = (n_u - 1.f - o[0]) / d[0];
+    ts[2] = (1.f - o[1]) / d[1];
+    ts[3] = (n_v - 1.f - o[1]) / d[1];
+    if (d[0] * d[0] < 1e-12f) ts[0] = -(ts[1] = 1e10f);
+    if (d[1] * d[1] < 1e-12f) ts[2] = -(ts[3] = 1e10f);
+    or_sort4(ts);
+    t = ts[1];
+    t_max = ts[2];
+    {
+        float u = o[0] + t * d[0], v = o[1] + t * d[1];
+        int inb = (u <= n_u && v <= n_v && u >= 0 && v >= 0);
+        if (!inb || t_max <= t) return 0.f;
+    }
+    o[0] += .5f;
+    o[1] += .5f;
+    if (filter != 0) {
+        for (; t <= t_max; t += step) {
+            sum += eccor_tex2d(img, W, H, o[0] + t * d[0], o[1] + t * d[1]);
+            nf++;
+        }
+        if (fetches) *fetches += nf;
+        return sum * step;
+    } else {
+        float sumo = 0, result;
+        o[0] -= .5f * d[1];
+        o[1] += .5f * d[0];
+        for (; t <= t_max; t += step) {
+            sum += eccor_tex2d(img, W, H, o[0] + t * d[0], o[1] + t * d[1]);
+            sumo += eccor_tex2d(img, W, H, o[0] + t * d[0] + d[1], o[1] + t * d[1] - d[0]);
+            nf += 2;
+        }
+        if (fetches) *fetches += nf;
+        result = (sum - sumo) * step;
+        if (post == 1) return result < 0 ? -sqrtf(-result) : sqrtf(result);
+        if (post == 2) return result < 0 ? -logf(-result + 1) : logf(result + 1);
+        return result;
+    }
+}
+
+/* Full Radon intermediate, output n_t rows x n_alpha columns, alpha fastest (idx = iy*n_alpha+ix).
+ * ref: RadonIntermediate.cu:149-170 (computeDerivLineIntegrals), without the ramp filter. */
+ECCOR_API void eccor_radon(const float *img, int n_u, int n_v, int n_alpha, int n_t, int filter,
+                           int post, float *out, long long *fetches)
+{
+    long long total = 0;
+    int iy;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+    for (iy = 0; iy < n_t; iy++) {
+        int ix;
+        long long f = 0;
+        for (ix = 0; ix < n_alpha; ix++)
+            out[(size_t)iy * n_alpha + ix] =
+                or_radon_bin(img, n_u, n_v, n_alpha, n_t, ix, iy, filter, post, &f);
+        total += f;
+    }
+    if (fetches) *fetches = total;
+}
+
+/* Selected bins only (bins[k] = iy*n_alpha+ix): spot checks at full problem sizes. */
+ECCOR_API void eccor_radon_bins(const float *img, int n_u, int n_v, int n_alpha, int n_t,
+                                int filter, int post, const int *bins, int n_bins, float *out)
+{
+    int k;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (k = 0; k < n_bins; k++)
+        out[k] = or_radon_bin(img, n_u, n_v, n_alpha, n_t, bins[k] % n_alpha, bins[k] / n_alpha,
+                              filter, post, 0);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* E3/E4: pair consistency                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Sensitivity probe (NOT the normative path): variant 1 evaluates the line -> (angle, distance)
+ * mapping in binary64 and rounds the two texture coordinates to float.  Tests use the distance
+ * between variant 0 and variant 1 as the fp32 "noise floor" of the pair values. */
+static int g_variant = 0;
+ECCOR_API void eccor_set_variant(int v) { g_variant = v; }
+
+static float or_redundancy_f64(const float *K, const float *dtr, int n_alpha, int n_t,
+                               float range_t, double x0, double x1, int is_derivative)
+{
+    const double Pi = 3.14159265358979323846;
+    double l0 = K[0] * x0 + K[3] * x1, l1 = K[1] * x0 + K[4] * x1, l2 = K[2] * x0 + K[5] * x1;
+    double len = sqrt(l0 * l0 + l1 * l1);
+    double a = atan2(l1, l0) / Pi, d;
+    int moved = 0;
+    if (a < 0) a += 2;
+    d = -(l2 / len) / (double)range_t + 0.5;
+    if (a > 1) { a -= 1; d = 1 - d; moved = 1; }
+    if (is_derivative && moved) return -eccor_tex2d_norm(dtr, n_alpha, n_t, (float)a, (float)d);
+    return +eccor_tex2d_norm(dtr, n_alpha, n_t, (float)a, (float)d);
+}
+
+/* ref: EpipolarConsistencyRadonIntermediate.cu:71-84 (getRedundancy) */
+static float or_redundancy(const float *K, const float *dtr, int n_alpha, int n_t, float range_t,
+                           float x0, float x1, int is_derivative)
+{
+    float line[3];
+    int moved;
+    line[0] = K[0] * x0 + K[3] * x1;
+    line[1] = K[1] * x0 + K[4] * x1;
+    line[2] = K[2] * x0 + K[5] * x1;
+    moved = eccor_line_to_sample_dtr(line, range_t);
+    if (is_derivative && moved) return -eccor_tex2d_norm(dtr, n_alpha, n_t, line[0], line[1]);
+    return +eccor_tex2d_norm(dtr, n_alpha, n_t, line[0], line[1]);
+}
+
+typedef struct {
+    int n_u, n_v, n_alpha, n_t;
+    float step_alpha, step_t;
+    float object_radius_mm, dkappa;
+    int is_derivative;
+} eccor_params;
+
+/* One pair: K01 (launcher arguments of ref: ...RadonIntermediate.cu:320-338) then the kappa loop
+ * of ref: ...RadonIntermediate.cu:257-270 + :87-113.  Returns the pair value (float), i.e.
+ * sum_k ((vp^2+vm^2)*K0[6])*dkappa; the sum itself is carried in double (atomics in the ref). */
+static float or_pair(const eccor_params *p, const float *C0, const float *C1, const float *P0invT,
+                     const float *P1invT, const float *dtr0, const float *dtr1, float *K01_out,
+                     long long *n_kappa)
+{
+    float K0[8], K1[8];
+    float image_diagonal = p->n_t * p->step_t * 2.f;
+    float range_t = p->n_t * p->step_t;
+    float dkappa, kappa_max;
+    double acc = 0.0;
+    int k, k_limit;
+    const float Pi = 3.14159265359f;
+    eccor_computeK01(p->n_u * 0.5f, p->n_v * 0.5f, C0, C1, P0invT, P1invT, p->object_radius_mm,
+                     image_diagonal, p->dkappa, K0, K1);
+    if (K01_out) { memcpy(K01_out, K0, 32); memcpy(K01_out + 8, K1, 32); }
+    dkappa = K1[6];
+    kappa_max = K1[7];
+    /* launch bound on idx_y: grid.y*256 threads, ref: ...RadonIntermediate.cu:348-358 */
+    {
+        int max_num_samples = p->dkappa <= 0.0f ? (int)image_diagonal : (int)(Pi * 0.5f / p->dkappa);
+        k_limit = ((max_num_samples + 255) / 256) * 256;
+    }
+    for (k = 0; k < k_limit; k++) {
+        float kappa = dkappa * 0.5f + dkappa * k;
+        float x0, x1, vp, vm, consistency;
+        if (kappa >= kappa_max) break;
+        if (g_variant == 1) {
+            double c = cos((double)kappa), s = sin((double)kappa);
+            vp = or_redundancy_f64(K0, dtr0, p->n_alpha, p->n_t, range_t, c, s, p->is_derivative) -
+                 or_redundancy_f64(K1, dtr1, p->n_alpha, p->n_t, range_t, c, s, p->is_derivative);
+            vm = or_redundancy_f64(K0, dtr0, p->n_alpha, p->n_t, range_t, -c, s, p->is_derivative) -
+                 or_redundancy_f64(K1, dtr1, p->n_alpha, p->n_t, range_t, -c, s, p->is_derivative);
+            consistency = (vp * vp + vm * vm) * K0[6];
+            acc += (double)(consistency * dkappa);
+            continue;
+        }
+        x0 = cosf(kappa);
+        x1 = sinf(kappa);
+        vp = or_redundancy(K0, dtr0, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative) -
+             or_redundancy(K1, dtr1, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
+        x0 *= -1;
+        vm = or_redundancy(K0, dtr0, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative) -
+             or_redundancy(K1, dtr1, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
+        consistency = (vp * vp + vm * vm) * K0[6];
+        acc += (double)(consistency * dkappa);
+    }
+    if (n_kappa) *n_kappa += k;
+    return (float)acc;
+}
+
+/* All-pairs evaluate.  Ps: n x 12 doubles (3x4 column-major each).  dtrs: n pointers to n_t x n_alpha
+ * floats (alpha fastest).  cost: n x n floats in/out (index i + j*n, only i<j written) or NULL.
+ * pair_values: n(n-1)/2 floats in get_ij order or NULL.  K01s: 16 floats/pair or NULL.
+ * Returns sum/n_pairs in double.
+ * ref: EpipolarConsistencyRadonIntermediate.cpp:134-163 (pre-compute) + :166-225 (evaluate). */
+ECCOR_API double eccor_evaluate_all(int n, const double *Ps, const float *const *dtrs, int n_u,
+                                    int n_v, int n_alpha, int n_t, double object_radius_mm,
+                                    double dkappa, int is_derivative, float *cost,
+                                    float *pair_values, float *K01s, long long *n_kappa_total)
+{
+    eccor_params p;
+    float *Cs = (float *)malloc(sizeof(float) * 4 * n);
+    float *PinvTs = (float *)malloc(sizeof(float) * 12 * n);
+    int n_pairs = n * (n - 1) / 2, ij, v;
+    float *vals = (float *)malloc(sizeof(float) * (n_pairs > 0 ? n_pairs : 1));
+    double diagonal = sqrt((double)n_v * n_v + (double)n_u * n_u);
+    double sum = 0;
+    long long nk = 0;
+    p.n_u = n_u; p.n_v = n_v; p.n_alpha = n_alpha; p.n_t = n_t;
+    p.step_alpha = (float)(3.1415926535897931 / n_alpha); /* ref: RadonIntermediate.cpp:204-206 */
+    p.step_t = (float)(diagonal / n_t);
+    p.object_radius_mm = (float)(object_radius_mm > 0 ? object_radius_mm
+                                                       : eccor_object_radius(Ps, n_u, n_v));
+    p.dkappa = (float)dkappa;
+    p.is_derivative = is_derivative;
+    for (v = 0; v < n; v++) {
+        eccor_pinvT(Ps + 12 * v, PinvTs + 12 * v);
+        eccor_source_position(Ps + 12 * v, Cs + 4 * v);
+    }
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : nk)
+    for (ij = 0; ij < n_pairs; ij++) {
+        int i, j;
+        long long c = 0;
+        eccor_get_ij(ij, n, &i, &j);
+        vals[ij] = or_pair(&p, Cs + 4 * i, Cs + 4 * j, PinvTs + 12 * i, PinvTs + 12 * j, dtrs[i],
+                           dtrs[j], K01s ? K01s + 16 * ij : 0, &c);
+        nk += c;
+    }
+    for (ij = 0; ij < n_pairs; ij++) {
+        int i, j;
+        eccor_get_ij(ij, n, &i, &j);
+        if (cost) cost[i + j * n] = vals[ij];
+        if (pair_values) pair_values[ij] = vals[ij];
+        sum += vals[ij]; /* weights are all 1, ref: ...RadonIntermediate.cu:254, .cpp:216-224 */
+    }
+    if (n_kappa_total) *n_kappa_total = nk;
+    free(Cs); free(PinvTs); free(vals);
+    return sum / n_pairs;
+}
+
+/* Index-list evaluate: idx4[4p..4p+3] = (P0, P1, dtr0, dtr1); out: n_pairs floats.
+ * ref: EpipolarConsistencyRadonIntermediate.cpp:267-322 and .cu:152-211 (without the
+ * idx_x>num_pairs off-by-one, SURVEY.md E3'). */
+ECCOR_API double eccor_evaluate_pairs(int n_P, const double *Ps, int n_dtr, const float *const *dtrs,
+                                      int n_u, int n_v, int n_alpha, int n_t,
+                                      double object_radius_mm, double dkappa, int is_derivative,
+                                      const int *idx4, int n_pairs, float *out, float *K01s)
+{
+    eccor_params p;
+    float *Cs = (float *)malloc(sizeof(float) * 4 * n_P);
+    float *PinvTs = (float *)malloc(sizeof(float) * 12 * n_P);
+    double diagonal = sqrt((double)n_v * n_v + (double)n_u * n_u);
+    double sum = 0;
+    int q, v;
+    (void)n_dtr;
+    p.n_u = n_u; p.n_v = n_v; p.n_alpha = n_alpha; p.n_t = n_t;
+    p.step_alpha = (float)(3.1415926535897931 / n_alpha);
+    p.step_t = (float)(diagonal / n_t);
+    p.object_radius_mm = (float)(object_radius_mm > 0 ? object_radius_mm
+                                                       : eccor_object_radius(Ps, n_u, n_v));
+    p.dkappa = (float)dkappa;
+    p.is_derivative = is_derivative;
+    for (v = 0; v < n_P; v++) {
+        eccor_pinvT(Ps + 12 * v, PinvTs + 12 * v);
+        eccor_source_position(Ps + 12 * v, Cs + 4 * v);
+    }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (q = 0; q < n_pairs; q++) {
+        const int *t = idx4 + 4 * q;
+        out[q] = or_pair(&p, Cs + 4 * t[0], Cs + 4 * t[1], PinvTs + 12 * t[0], PinvTs + 12 * t[1],
+                         dtrs[t[2]], dtrs[t[3]], K01s ? K01s + 16 * q : 0, 0);
+    }
+    for (q = 0; q < n_pairs; q++) sum += out[q];
+    free(Cs); free(PinvTs);
+    return sum / n_pairs;
+}
+
+ECCOR_API int eccor_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
