@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- ECC evaluations/s on the BASELINE workload (400 projections, 1024x1024, 768x768 Radon bins).
+
+One "step" = one all-pairs evaluation as an optimiser iteration pays for it
+(ref: Gui/SingleImageMotion.h:84-90 -> MetricRadonIntermediate::setProjectionMatrices + evaluate):
+new projection matrices come from the host, the per-view pre-compute + upload, the pair kernel over
+all n(n-1)/2 pairs, the float64 reduction and the scalar back on the host.  Radon intermediates are
+resident in HBM when the timed region starts (they are computed once per data set, before it, and
+that cost is reported separately as ms_per_radon_intermediate).
+
+N GPUs: one process per GPU (torchrun), dtr stack produced data-parallel + all-gathered once,
+contiguous shards of the pair range per rank, one 8-byte RCCL all-reduce per evaluation.  The total
+work per evaluation is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--views", type=int, default=400)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--bins", type=int, default=768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-stride", type=int, default=1,
+                    help="CPU baseline evaluates all pairs among every k-th view")
+    return ap.parse_args()
+
+
+def n_kappa_auto(n_u, n_v, n_t):
+    """#{k >= 0 : dkappa*(k+1/2) < kappa_max} with dkappa = 2*kappa_max/num_samples,
+    num_samples = n_t*step_t*2 (ref: ...RadonIntermediate.cu:320,337; .cu:257-263) = ceil(D - 1/2)."""
+    import numpy as np
+    step_t = np.float32(np.sqrt(float(n_v) ** 2 + float(n_u) ** 2) / n_t)
+    D = float(np.float32(n_t) * step_t)
+    return int(np.ceil(D - 0.5))
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import geometry, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, S, B = args.views, args.size, args.bins
+    pixel_mm = 0.308 * 1024.0 / S
+    Ps = synthetic.short_scan(n, S, S, pixel_mm)
+    phantom = synthetic.sphere_phantom()
+
+    stream = torch.cuda.current_stream()
+    ctx = E.Context(local_rank, stream=stream.cuda_stream)
+    ctx.enable_timing(True)
+
+    # ---- Radon intermediates: data-parallel over views, then one all-gather ---------------------
+    slab = E.slab_floats(B, B)
+    chunk = (n + world - 1) // world
+    lo, hi = min(rank * chunk, n), min((rank + 1) * chunk, n)
+    slabs_all = torch.zeros((chunk * world, slab), dtype=torch.float32, device=dev)
+    local = slabs_all[rank * chunk:(rank + 1) * chunk]
+    radon_ms = 0.0
+    sub = 50  # images generated and transformed 50 at a time (200 MB of projections in flight)
+    for a in range(lo, hi, sub):
+        b = min(a + sub, hi)
+        imgs = synthetic.projections_torch(Ps[a:b], S, S, phantom, dev)
+        keep = E.RadonIntermediate.compute_into(ctx, imgs, local[a - lo:b - lo], B, B)
+        ctx.synchronize()
+        radon_ms += ctx.last_kernel_ms("radon")
+        del keep, imgs
+    ms_per_radon = radon_ms / max(hi - lo, 1)
+    if world > 1:
+        gathered = torch.empty_like(slabs_all)
+        dist.all_gather_into_tensor(gathered, local.contiguous())
+        slabs_all = gathered
+    dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
+    metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
+
+    # ---- shard of the pair range --------------------------------------------------------------
+    n_pairs = n * (n - 1) // 2
+    first = rank * n_pairs // world
+    count = (rank + 1) * n_pairs // world - first
+    sum_t = torch.zeros(1, dtype=torch.float64, device=dev)
+    moving = n // 2  # view perturbed per step, like SingleImageMotion does for its input view
+
+    def step(k):
+        P_k = list(Ps)
+        P_k[moving] = Ps[moving] @ geometry.rigid_transform(tx=0.01 * (k % 50), rz=1e-4 * (k % 7))
+        metric.setProjectionMatrices(P_k)
+        if world == 1:
+            return metric.evaluate()
+        metric.evaluate_range_async(first, count, sum_t)
+        dist.all_reduce(sum_t)
+        return sum_t.item() / n_pairs
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    pair_ms = 0.0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        last = step(k)
+        pair_ms += ctx.last_kernel_ms("pairs")
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = e.item()
+    pair_ms /= max(args.steps, 1)
+
+    n_kappa = n_kappa_auto(S, S, B)
+    bytes_per_pair = 64 * n_kappa + 68            # 2 views x 2 signs x 4 taps x 4 B + K01 + result
+    launch_bytes = bytes_per_pair * count         # one launch = this rank's shard of pairs
+    achieved = launch_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+
+    out = {
+        "metric": "ECC evaluations/sec (N=%d, %d^2 projections)" % (n, S),
+        "value": args.steps / elapsed,
+        "unit": "evaluations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%d-projection %dx%d circular short scan, %dx%d Radon bins, all %d pairs"
+                               % (n, S, S, B, B, n_pairs),
+                   "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "pairs_kernel<true>", "kernel_ms": pair_ms,
+                     "algorithmic_bytes_per_launch": launch_bytes},
+        "ms_per_radon_intermediate": ms_per_radon,
+        "pairs_per_s": n_pairs * args.steps / elapsed,
+        "kappa_samples_per_s": n_pairs * n_kappa * args.steps / elapsed,
+        "last_value": last,
+    }
+
+    # measured HBM traffic per launch (rocprofv3 PMC pass, committed under profiles/), if it matches
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            t = json.load(open(tfile))
+            if t.get("views") == n and t.get("size") == S and t.get("bins") == B and t.get("n_gpus", 1) == world:
+                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    # ---- CPU baseline: the oracle timed on this box's host cores (rank 0, N = 1 only) -----------
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build(native=True)
+        views = list(range(0, n, args.cpu_sample_stride))
+        host_dtrs = [dtrs[v].readback() for v in views]
+        Psub = [Ps[v] for v in views]
+        oracle.evaluate_all(Psub[:8], host_dtrs[:8], S, S, native=True)  # warm-up (thread pool, page-in)
+        reps, cpu_s, ref = 0, 0.0, None
+        while reps < 3 or (cpu_s < 5.0 and reps < 40):  # bounded: a few seconds of wall time
+            t1 = time.perf_counter()
+            ref = oracle.evaluate_all(Psub, host_dtrs, S, S, native=True)
+            cpu_s += time.perf_counter() - t1
+            reps += 1
+        sub_pairs = len(views) * (len(views) - 1) // 2
+        cpu_evals = (sub_pairs * reps / cpu_s) / n_pairs
+        # the same sub-problem on the GPU doubles as a full-size parity check
+        metric.setProjectionMatrices(Ps)
+        gpu_mean = metric.evaluate(set(views)) if args.cpu_sample_stride > 1 else metric.evaluate()
+        out["cpu_baseline"] = {
+            "value": cpu_evals, "unit": "evaluations/s", "cores": oracle.lib().eccor_num_threads(), "kind": "port",
+            "sample": "%d x all %d pairs among every %d-th view (%d of %d pairs per evaluation) in %.1f s, "
+                      "scaled by pair count; oracle/ecc_oracle.c -O3 -march=native -fopenmp"
+                      % (reps, sub_pairs, args.cpu_sample_stride, sub_pairs, n_pairs, cpu_s),
+        }
+        out["parity_rel_err_vs_oracle_on_sample"] = abs(gpu_mean - ref["mean"]) / abs(ref["mean"])
+        # Radon baseline: 1/4 of the bins of one image
+        img = synthetic.projections_numpy([Ps[n // 3]], S, S, phantom)[0]
+        bins = np.arange(0, B * B, 4, dtype=np.int32)
+        t1 = time.perf_counter()
+        oracle.radon_bins(img, B, B, bins, native=True)
+        out["cpu_baseline"]["ms_per_radon_intermediate"] = 1e3 * (time.perf_counter() - t1) * 4
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ecc_ctx_synchronize": (_i, [_vp]),
     "ecc_radon_compute": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_radon_compute_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_radon_compute_into": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ecc_dtr_from_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_dtr_readback": (_i, [_vp, _vp]),
     "ecc_dtr_info": (_i, [_vp, _pi, _pi, _pi, _pi, _pi, _pd, _pd]),

@@ -98,6 +98,18 @@ class RadonIntermediate:
         return [cls(ctx, C.c_void_p(h)) for h in hs]
 
     @classmethod
+    def compute_into(cls, ctx, images, slabs, size_alpha, size_t, filter=FILTER_DERIVATIVE,
+                     post_process=POST_IDENTITY):
+        """Device-resident, asynchronous form: images (n, n_v, n_u) and slabs (n, slab_floats) are
+        float32 torch tensors on ctx's device; returns handles that alias `slabs`."""
+        n, n_v, n_u = images.shape
+        assert images.is_contiguous() and slabs.is_contiguous()
+        assert slabs.shape[0] == n and slabs.shape[1] == slab_floats(size_alpha, size_t)
+        check(_lib.lib().ecc_radon_compute_into(ctx._h, C.c_void_p(images.data_ptr()), n, n_u, n_v, size_alpha,
+                                                size_t, filter, post_process, C.c_void_p(slabs.data_ptr())))
+        return [cls.wrap_device(ctx, slabs[k], size_alpha, size_t, n_u, n_v, filter) for k in range(n)]
+
+    @classmethod
     def from_host(cls, ctx, data, n_u, n_v, filter=FILTER_DERIVATIVE):
         """ref: RadonIntermediate(const NRRD::ImageView<float>&) -- data is (n_t, n_alpha) float32."""
         data = np.ascontiguousarray(data, np.float32)
@@ -293,6 +305,11 @@ class MetricRadonIntermediate:
             self.close()
         except Exception:
             pass
+
+
+def slab_floats(n_alpha, n_t):
+    """Floats per dtr in the private device layout (csrc/ecc_layout.h)."""
+    return _lib.lib().ecc_dtr_slab_floats(int(n_alpha), int(n_t))
 
 
 def get_ij(ij, n):

@@ -356,6 +356,20 @@ ECC_EXPORT int ecc_radon_compute_batch(ecc_ctx* ctx, const float* images, int im
     return ECC_OK;
 }
 
+ECC_EXPORT int ecc_radon_compute_into(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, int n_alpha,
+                                      int n_t, int filter, int post_process, float* slabs_d)
+{
+    ecc_dtr* dummy = nullptr;
+    int rc = check_radon_args(ctx, images_d, n, n_u, n_v, n_alpha, n_t, filter, post_process, &dummy);
+    if (rc) return rc;
+    if (!slabs_d) return fail(ECC_ERR_INVALID_ARGUMENT, "slabs_d is null");
+    rc = set_device(ctx);
+    if (rc) return rc;
+    const int64_t slab = ecc_layout_floats(n_alpha, n_t);
+    HIP_TRY(hipMemsetAsync(slabs_d, 0, (size_t)slab * n * sizeof(float), ctx->stream));
+    return radon_launch(ctx, images_d, n, n_u, n_v, n_alpha, n_t, filter, post_process, slabs_d, slab);
+}
+
 ECC_EXPORT int ecc_radon_compute(ecc_ctx* ctx, const float* image, int image_on_device, int n_u, int n_v,
                                  int n_alpha, int n_t, int filter, int post_process, ecc_dtr** out)
 {

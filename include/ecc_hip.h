@@ -80,6 +80,13 @@ int ecc_radon_compute_batch(ecc_ctx* ctx, const float* images, int images_on_dev
                             int n_v, int n_alpha, int n_t, int filter, int post_process,
                             ecc_dtr** out);
 
+/* Device-to-device form for callers that own both buffers (e.g. torch tensors): images_d holds n
+ * images, slabs_d receives n dtrs in the private layout (ecc_dtr_slab_floats(n_alpha, n_t) floats
+ * each, written completely incl. the replicated border).  Asynchronous on the context's stream;
+ * adopt the result with ecc_dtr_wrap_device. */
+int ecc_radon_compute_into(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, int n_alpha,
+                           int n_t, int filter, int post_process, float* slabs_d);
+
 /* Wraps existing host data (alpha-fast, n_t x n_alpha), ref: RadonIntermediate(ImageView<float>)
  * + replaceRadonIntermediateData (RadonIntermediate.cpp:69-80,105-123). */
 int ecc_dtr_from_host(ecc_ctx* ctx, const float* data, int n_alpha, int n_t, int n_u, int n_v,

@@ -166,12 +166,12 @@ def radon(img, n_alpha, n_t, filter=0, post=0, count_fetches=False):
     return (out, nf.value) if count_fetches else out
 
 
-def radon_bins(img, n_alpha, n_t, bins, filter=0, post=0):
+def radon_bins(img, n_alpha, n_t, bins, filter=0, post=0, native=False):
     img = np.ascontiguousarray(img, np.float32)
     n_v, n_u = img.shape
     bins = np.ascontiguousarray(bins, np.int32)
     out = np.zeros(len(bins), np.float32)
-    lib().eccor_radon_bins(img, n_u, n_v, n_alpha, n_t, filter, post, bins, len(bins), out)
+    lib(native).eccor_radon_bins(img, n_u, n_v, n_alpha, n_t, filter, post, bins, len(bins), out)
     return out
 
 
