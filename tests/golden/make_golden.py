@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the CPU oracle (run from the repo root, in the
+container that has /root/reference):
+
+  example_pair_256.npz  the reference's example pair (config/example_data/proj000.nrrd, proj040.nrrd;
+                        data files, not source) box-averaged 4x4 to 256x190 with P' = diag(1/4,1/4,1) P
+                        (the MATLAB demo rescales the same way, ref: matlab/ecc_demo.m:10-17), plus the
+                        oracle's outputs on it: K01, pair value, dtr checksums and sparse dtr samples.
+  synthetic8_128.npz    8-view 128x128 synthetic scan (tests/conftest.py:make_small_scan): oracle pair
+                        values, mean, K01s and per-dtr checksums.
+
+The reference has no golden vectors for this path: these pin the ORACLE against
+regressions and travel to the GPU box, where /root/reference does not exist.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle  # noqa: E402
+from epipolarconsistency_amd import nrrd  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/config/example_data"
+
+
+def checksum(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return np.array([a.astype(np.float64).sum(), np.abs(a).astype(np.float64).sum(),
+                     float(np.bitwise_xor.reduce(a.view(np.uint32).reshape(-1)))])
+
+
+def example_pair():
+    imgs, Ps = [], []
+    for name in ("proj000.nrrd", "proj040.nrrd"):
+        img, _, meta = nrrd.read(os.path.join(REF, name))
+        P = nrrd.parse_matrix(meta["Projection Matrix"])
+        small = img.reshape(190, 4, 256, 4).astype(np.float64).mean(axis=(1, 3)).astype(np.float32)
+        imgs.append(small)
+        Ps.append(np.diag([0.25, 0.25, 1.0]) @ P)
+    imgs = np.stack(imgs)
+    n_u, n_v, n_alpha, n_t = 256, 190, 192, 192
+    dtrs = [oracle.radon(im, n_alpha, n_t) for im in imgs]
+    res = oracle.evaluate_all(Ps, dtrs, n_u, n_v, want_K01=True)
+    rng = np.random.default_rng(42)
+    bins = rng.integers(0, n_alpha * n_t, size=256).astype(np.int32)
+    np.savez_compressed(
+        os.path.join(HERE, "example_pair_256.npz"), images=imgs, Ps=np.stack(Ps), n_alpha=n_alpha, n_t=n_t,
+        K01=res["K01s"][0], pair_value=res["pairs"][0], mean=res["mean"], n_kappa=res["n_kappa"],
+        object_radius=oracle.object_radius(Ps[0], n_u, n_v),
+        dtr_checksums=np.stack([checksum(d) for d in dtrs]), sample_bins=bins,
+        dtr_samples=np.stack([d.reshape(-1)[bins] for d in dtrs]))
+    print("example pair: value %.9g, n_kappa %d" % (res["pairs"][0], res["n_kappa"]))
+
+
+def synthetic8():
+    from conftest import make_small_scan
+    Ps, imgs = make_small_scan()
+    dtrs = [oracle.radon(im, 96, 96) for im in imgs]
+    res = oracle.evaluate_all(Ps, dtrs, 128, 128, want_K01=True)
+    np.savez_compressed(
+        os.path.join(HERE, "synthetic8_128.npz"), Ps=np.stack(Ps), image_checksums=np.stack([checksum(i) for i in imgs]),
+        dtr_checksums=np.stack([checksum(d) for d in dtrs]), pairs=res["pairs"], mean=res["mean"], K01s=res["K01s"],
+        n_kappa=res["n_kappa"])
+    print("synthetic8: mean %.9g" % res["mean"])
+
+
+if __name__ == "__main__":
+    example_pair()
+    synthetic8()

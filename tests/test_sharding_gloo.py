@@ -1,0 +1,64 @@
+"""Multi-rank path on CPU: world_size-2 gloo.  The data path has no collective except the 8-byte
+all-reduce of partial sums, so the test exercises the shard arithmetic + all-reduce with the
+oracle's pair values standing in for what each rank's GPU shard would produce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, pairs, n_views, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from epipolarconsistency_amd import sharding
+    n_pairs = n_views * (n_views - 1) // 2
+    first, count = sharding.pair_range(rank, world, n_pairs)
+    part = torch.tensor([float(np.sum(pairs[first:first + count].astype(np.float64)))], dtype=torch.float64)
+    mean = sharding.allreduce_mean(part, n_pairs)
+    out_q.put((rank, first, count, mean))
+    dist.destroy_process_group()
+
+
+def test_pair_ranges_partition_everything():
+    from epipolarconsistency_amd import sharding
+    for n_pairs in (1, 7, 28, 79800):
+        for world in (1, 2, 3, 8):
+            got = [sharding.pair_range(r, world, n_pairs) for r in range(world)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == n_pairs
+            for (f0, c0), (f1, _) in zip(got, got[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    assert [sharding.view_range(r, 8, 400)[:2] for r in (0, 7)] == [(0, 50), (350, 400)]
+    assert sharding.view_range(3, 4, 10) == (9, 10, 3)
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_allreduce_mean(oracle_mod, small_scan):
+    s = small_scan
+    ref = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ref["pairs"], 8, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert res[0][1:3] == (0, 14) and res[1][1:3] == (14, 14)
+    for _, _, _, mean in res:
+        assert abs(mean - ref["mean"]) <= 1e-12 * abs(ref["mean"])
