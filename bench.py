@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--bins", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="pair kernel: 0 fast (default), 1 reference-order")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
                     help="CPU baseline evaluates all pairs among every k-th view")
     return ap.parse_args()
@@ -57,7 +58,7 @@ def main():
     import torch.distributed as dist
 
     import epipolarconsistency_amd as E
-    from epipolarconsistency_amd import geometry, synthetic
+    from epipolarconsistency_amd import geometry, sharding, synthetic
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,23 +103,25 @@ def main():
         slabs_all = gathered
     dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
     metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
+    metric.setKernelVariant(args.variant)
 
     # ---- shard of the pair range --------------------------------------------------------------
     n_pairs = n * (n - 1) // 2
-    first = rank * n_pairs // world
-    count = (rank + 1) * n_pairs // world - first
+    first, count = sharding.pair_range(rank, world, n_pairs)
     sum_t = torch.zeros(1, dtype=torch.float64, device=dev)
     moving = n // 2  # view perturbed per step, like SingleImageMotion does for its input view
 
+    P_pack = E.pack_projection_matrices(Ps)  # (n, 12) float64, what Eigen's Ps[i].data() holds
+    P_moving = Ps[moving].copy()
+
     def step(k):
-        P_k = list(Ps)
-        P_k[moving] = Ps[moving] @ geometry.rigid_transform(tx=0.01 * (k % 50), rz=1e-4 * (k % 7))
-        metric.setProjectionMatrices(P_k)
+        # the optimiser hands over new matrices: view `moving` perturbed by a small rigid motion
+        T = geometry.rigid_transform(tx=0.01 * (k % 50), rz=1e-4 * (k % 7))
+        P_pack[moving] = (P_moving @ T).T.reshape(12)
+        metric.setProjectionMatrices(P_pack)
         if world == 1:
             return metric.evaluate()
-        metric.evaluate_range_async(first, count, sum_t)
-        dist.all_reduce(sum_t)
-        return sum_t.item() / n_pairs
+        return sharding.distributed_evaluate(metric, n, sum_t, rank, world)
 
     def fence():
         torch.cuda.synchronize()

@@ -17,6 +17,11 @@ from ._lib import (FILTER_DERIVATIVE, FILTER_NONE, FILTER_RAMP, POST_IDENTITY, P
                    POST_SQUARE_ROOT, EccError, check)
 
 
+def pack_projection_matrices(Ps):
+    """Public alias: list of 3x4 -> (n, 12) float64 column-major per view."""
+    return _Ps_colmajor(Ps)
+
+
 def _Ps_colmajor(Ps):
     """List/array of 3x4 matrices -> contiguous n x 12 float64, column-major per view (Eigen)."""
     A = np.asarray(Ps, dtype=np.float64).reshape(-1, 3, 4)
@@ -201,6 +206,7 @@ class MetricRadonIntermediate:
         hs = (C.c_void_p * len(self._dtrs))(*[d._h for d in self._dtrs])
         check(_lib.lib().ecc_metric_create(self.ctx._h, len(self._dtrs), hs, C.byref(self._h)))
         check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
+        check(_lib.lib().ecc_metric_set_kernel_variant(self._h, getattr(self, '_variant', 0)))
         if self._Ps is not None:
             self.setProjectionMatrices(self._Ps)
         return self
@@ -209,7 +215,13 @@ class MetricRadonIntermediate:
         return self._dtrs
 
     def setProjectionMatrices(self, Ps):
-        self._Ps = _Ps_colmajor(Ps)
+        """Ps: list of 3x4 matrices, or (fast path) an (n, 12) float64 C-contiguous array that is
+        already column-major per view (what Eigen's Ps[i].data() holds)."""
+        if isinstance(Ps, np.ndarray) and Ps.ndim == 2 and Ps.shape[1] == 12 and Ps.dtype == np.float64 \
+                and Ps.flags["C_CONTIGUOUS"]:
+            self._Ps = Ps
+        else:
+            self._Ps = _Ps_colmajor(Ps)
         if self._h:
             check(_lib.lib().ecc_metric_set_projections(self._h, C.c_void_p(self._Ps.ctypes.data), len(self._Ps)))
         return self
@@ -240,6 +252,13 @@ class MetricRadonIntermediate:
         return self
 
     setdKappa = setEpipolarPlaneStep
+
+    def setKernelVariant(self, variant):
+        """0 = fast kernel (default), 1 = reference-order kernel (diagnostics / A-B runs)."""
+        self._variant = int(variant)
+        if self._h:
+            check(_lib.lib().ecc_metric_set_kernel_variant(self._h, self._variant))
+        return self
 
     def useCorrelation(self, corr=True):
         self._params[2] = 1 if corr else 0
@@ -289,6 +308,12 @@ class MetricRadonIntermediate:
         check(_lib.lib().ecc_metric_evaluate_range_async(
             self._h, int(first), int(count), C.c_void_p(pair_tensor.data_ptr() if pair_tensor is not None else 0),
             C.c_void_p(sum_tensor.data_ptr())))
+
+    def debug_geometry(self):
+        n = self.getNumberOfProjetions()
+        PinvTs, Cs = np.empty((n, 12), np.float32), np.empty((n, 4), np.float32)
+        check(_lib.lib().ecc_metric_debug_geometry(self._h, C.c_void_p(PinvTs.ctypes.data), C.c_void_p(Cs.ctypes.data)))
+        return PinvTs, Cs
 
     def debug_K01(self, first, count):
         out = np.empty((count, 16), np.float32)

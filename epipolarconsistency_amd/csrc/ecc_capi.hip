@@ -26,8 +26,9 @@ extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
-extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
+extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, int variant, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
+extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
 
 #define ECC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -93,6 +94,7 @@ struct ecc_metric {
     // parameters
     double object_radius_mm = 0, dkappa = 0;
     int use_corr = 0;
+    int kernel_variant = 0;  // 0 fast (default), 1 reference-order
     // projections
     int n_views = 0;
     std::vector<double> P_first;  // first projection matrix (object radius estimate)
@@ -110,9 +112,9 @@ struct ecc_metric {
     float* K01_d = nullptr;
     int64_t K01_capacity = 0;
     double* sum_d = nullptr;
+    double* Ps_d = nullptr;   // n x 12 float64 as handed over by the caller
     // pinned host staging
-    float* geom_h = nullptr;  // 16 floats per view: 12 PinvT + 4 C
-    int geom_h_capacity = 0;
+    double* Ps_h = nullptr;
     double* sum_h = nullptr;
 };
 
@@ -543,7 +545,8 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->indices_d) (void)hipFree(m->indices_d);
     if (m->K01_d) (void)hipFree(m->K01_d);
     if (m->sum_d) (void)hipFree(m->sum_d);
-    if (m->geom_h) (void)hipHostFree(m->geom_h);
+    if (m->Ps_d) (void)hipFree(m->Ps_d);
+    if (m->Ps_h) (void)hipHostFree(m->Ps_h);
     if (m->sum_h) (void)hipHostFree(m->sum_h);
     delete m;
     return ECC_OK;
@@ -556,31 +559,42 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
     ecc_ctx* ctx = m->ctx;
     int rc = set_device(ctx);
     if (rc) return rc;
+    // the pinned staging buffer may still be in flight from the previous call
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (n_views > m->geom_capacity) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (m->Cs_d) HIP_TRY(hipFree(m->Cs_d));
         if (m->PinvTs_d) HIP_TRY(hipFree(m->PinvTs_d));
-        if (m->geom_h) HIP_TRY(hipHostFree(m->geom_h));
-        m->Cs_d = m->PinvTs_d = m->geom_h = nullptr;
+        if (m->Ps_d) HIP_TRY(hipFree(m->Ps_d));
+        if (m->Ps_h) HIP_TRY(hipHostFree(m->Ps_h));
+        m->Cs_d = m->PinvTs_d = nullptr;
+        m->Ps_d = m->Ps_h = nullptr;
         m->geom_capacity = 0;
         HIP_TRY(hipMalloc((void**)&m->Cs_d, sizeof(float) * 4 * n_views));
         HIP_TRY(hipMalloc((void**)&m->PinvTs_d, sizeof(float) * 12 * n_views));
-        HIP_TRY(hipHostMalloc((void**)&m->geom_h, sizeof(float) * 16 * n_views));
+        HIP_TRY(hipMalloc((void**)&m->Ps_d, sizeof(double) * 12 * n_views));
+        HIP_TRY(hipHostMalloc((void**)&m->Ps_h, sizeof(double) * 12 * n_views));
         m->geom_capacity = n_views;
-    } else {
-        // the pinned staging buffer may still be in flight from the previous call
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    float* PinvT_h = m->geom_h;
-    float* C_h = m->geom_h + 12 * (size_t)n_views;
-    for (int v = 0; v < n_views; ++v) {
-        ecc_host::pinv_transpose(Ps + 12 * (size_t)v, PinvT_h + 12 * (size_t)v);
-        ecc_host::source_position(Ps + 12 * (size_t)v, C_h + 4 * (size_t)v);
-    }
-    HIP_TRY(hipMemcpyAsync(m->PinvTs_d, PinvT_h, sizeof(float) * 12 * n_views, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(m->Cs_d, C_h, sizeof(float) * 4 * n_views, hipMemcpyHostToDevice, ctx->stream));
+    // E1 on the device: upload the n x 12 doubles, one thread per view does the reference's binary64
+    // Householder-QR arithmetic (geometry_kernel.hip); nothing else crosses PCIe.
+    std::memcpy(m->Ps_h, Ps, sizeof(double) * 12 * (size_t)n_views);
+    HIP_TRY(hipMemcpyAsync(m->Ps_d, m->Ps_h, sizeof(double) * 12 * n_views, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ecc_launch_e1(m->Ps_d, n_views, m->PinvTs_d, m->Cs_d, ctx->stream));
     m->n_views = n_views;
     m->P_first.assign(Ps, Ps + 12);
+    return ECC_OK;
+}
+
+/* Debug: read back what E1 produced on the device (12 + 4 floats per view). */
+ECC_EXPORT int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs)
+{
+    if (!m || !PinvTs || !Cs) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
+    int rc = set_device(m->ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(PinvTs, m->PinvTs_d, sizeof(float) * 12 * m->n_views, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(Cs, m->Cs_d, sizeof(float) * 4 * m->n_views, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
     return ECC_OK;
 }
 
@@ -590,6 +604,13 @@ ECC_EXPORT int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, dou
     m->object_radius_mm = object_radius_mm;
     m->dkappa = dkappa;
     m->use_corr = use_corr;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_set_kernel_variant(ecc_metric* m, int variant)
+{
+    if (!m || variant < 0 || variant > 1) return fail(ECC_ERR_INVALID_ARGUMENT, "bad kernel variant");
+    m->kernel_variant = variant;
     return ECC_OK;
 }
 
@@ -652,7 +673,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     p.cost = cost_d;
     p.K01_out = K01_d;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, m->kernel_variant, ctx->stream));
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;
@@ -762,7 +783,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     p.count = n_pairs;
     p.pair_values = m->pair_values_d;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, m->kernel_variant, ctx->stream));
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;

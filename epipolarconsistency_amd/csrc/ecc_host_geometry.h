@@ -17,6 +17,15 @@
 
 #include <cmath>
 
+// The same source is compiled for the host (C ABI helpers, tests) and for the device (e1_kernel in
+// geometry_kernel.hip): binary64 add/mul/div/sqrt are correctly rounded on both and contraction is
+// off, so both give bit-identical results.
+#if defined(__HIPCC__)
+#define ECC_HD __host__ __device__
+#else
+#define ECC_HD
+#endif
+
 namespace ecc_host {
 
 // In-place Householder QR of the column-major N x N matrix M (M becomes R) with explicit Q.
@@ -26,14 +35,14 @@ namespace ecc_host {
 //     diag_k = -scale*sigma; trailing columns j: M(k:N,j) -= (v.M(k:N,j) / c_k) * v;
 //   * last diagonal entry is negated; Q accumulates reflectors 0..N-2 applied to the identity.
 template <int N>
-inline void householder_qr(double* M, double* Q)
+ECC_HD inline void householder_qr(double* M, double* Q)
 {
     double diag[N], c[N];
     double scale = 0.0;
     for (int k = 0; k < N; ++k) {
         double* vk = M + N * k;
         for (int i = k; i < N; ++i) {
-            const double a = std::fabs(vk[i]);
+            const double a = fabs(vk[i]);
             if (scale < a) scale = a;
         }
         if (scale == 0.0) {
@@ -43,7 +52,7 @@ inline void householder_qr(double* M, double* Q)
         for (int i = k; i < N; ++i) vk[i] /= scale;
         double nrm2 = 0.0;
         for (int i = k; i < N; ++i) nrm2 += vk[i] * vk[i];
-        const double sigma = vk[k] > 0.0 ? std::sqrt(nrm2) : -std::sqrt(nrm2);
+        const double sigma = vk[k] > 0.0 ? sqrt(nrm2) : -sqrt(nrm2);
         vk[k] += sigma;
         c[k] = sigma * vk[k];
         diag[k] = -scale * sigma;
@@ -79,7 +88,7 @@ inline void householder_qr(double* M, double* Q)
 
 // x = R^-1 b for upper-triangular column-major R (back substitution, last row first).
 template <int N>
-inline void back_substitute(const double* R, const double* b, double* x)
+ECC_HD inline void back_substitute(const double* R, const double* b, double* x)
 {
     x[N - 1] = b[N - 1] / R[(N - 1) * N + (N - 1)];
     for (int i = N - 2; i >= 0; --i) {
@@ -90,7 +99,7 @@ inline void back_substitute(const double* R, const double* b, double* x)
 }
 
 // (P^+)^T, 3x4 column-major, double in -> float out.  P: 3x4 column-major.
-inline void pinv_transpose(const double* P, float* out12)
+ECC_HD inline void pinv_transpose(const double* P, float* out12)
 {
     double G[9];  // Gram matrix P P^T (symmetric)
     G[0] = P[0] * P[0] + P[3] * P[3] + P[6] * P[6] + P[9] * P[9];
@@ -122,7 +131,7 @@ inline void pinv_transpose(const double* P, float* out12)
 }
 
 // Source position: last column of Q in the QR of the 4x4 matrix (P^T | 0), scaled to w = 1.
-inline void source_position(const double* P, float* out4)
+ECC_HD inline void source_position(const double* P, float* out4)
 {
     double A[16], Q[16];
     for (int r = 0; r < 3; ++r)
@@ -132,13 +141,13 @@ inline void source_position(const double* P, float* out4)
     for (int i = 0; i < 4; ++i) out4[i] = (float)(Q[i + 12] / Q[15]);
 }
 
-inline void cross3(const double* a, const double* b, double* c)
+ECC_HD inline void cross3(const double* a, const double* b, double* c)
 {
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
-inline double det3(const double* a, const double* b, const double* c)
+ECC_HD inline double det3(const double* a, const double* b, const double* c)
 {
     return a[0] * (b[1] * c[2] - b[2] * c[1]) - b[0] * (a[1] * c[2] - a[2] * c[1]) +
            c[0] * (a[1] * b[2] - a[2] * b[1]);
@@ -147,27 +156,27 @@ inline double det3(const double* a, const double* b, const double* c)
 // ref: EpipolarConsistency.cpp:35-47 with getCameraFocalLengthPx (ProjectionMatrix.cpp:104-112)
 // and getCameraCenter (:70-76; the reference uses an SVD null space, any float64 null space
 // agrees to ~1e-13 -- here signed 3x3 minors).
-inline double object_radius(const double* P, int n_u, int n_v)
+ECC_HD inline double object_radius(const double* P, int n_u, int n_v)
 {
     const double m1[3] = {P[0], P[3], P[6]}, m2[3] = {P[1], P[4], P[7]}, m3[3] = {P[2], P[5], P[8]};
     double U[3], V[3], t[3];
     cross3(m3, m2, U);
-    double n = std::sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
+    double n = sqrt(U[0] * U[0] + U[1] * U[1] + U[2] * U[2]);
     U[0] /= n; U[1] /= n; U[2] /= n;
     cross3(m3, m1, V);
-    n = std::sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+    n = sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
     V[0] /= n; V[1] /= n; V[2] /= n;
     cross3(V, m3, t);
     const double fu = m1[0] * t[0] + m1[1] * t[1] + m1[2] * t[2];
     cross3(U, m3, t);
     const double fv = m2[0] * t[0] + m2[1] * t[1] + m2[2] * t[2];
-    const double a = std::fabs(std::atan(0.5 * n_u / fu)), b = std::fabs(std::atan(0.5 * n_v / fv));
+    const double a = fabs(atan(0.5 * n_u / fu)), b = fabs(atan(0.5 * n_v / fv));
     const double fov = a > b ? a : b;
     double C[4] = {det3(P + 3, P + 6, P + 9), -det3(P, P + 6, P + 9), det3(P, P + 3, P + 9), -det3(P, P + 3, P + 6)};
     if (C[3] < -1e-12 || C[3] > 1e-12) {
         C[0] /= C[3]; C[1] /= C[3]; C[2] /= C[3];
     }
-    return std::sin(fov) * std::sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
+    return sin(fov) * sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
 }
 
 }  // namespace ecc_host

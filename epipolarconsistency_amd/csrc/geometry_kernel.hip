@@ -1,0 +1,37 @@
+// geometry_kernel.hip -- per-view pre-compute (E1) on the device.
+//
+// MetricRadonIntermediate::setProjectionMatrices (ref: LibEpipolarConsistency/
+// EpipolarConsistencyRadonIntermediate.cpp:134-163) runs n small Householder QRs under OpenMP on
+// the host and uploads 16 floats per view; inside an optimiser loop that is ~170 us of serial host
+// work per evaluation for n = 400, a quarter of the pair kernel's time.  Here the caller's n x 12
+// float64 matrices are uploaded (38 KB) and one thread per view performs exactly the same binary64
+// arithmetic (ecc_host_geometry.h is compiled for both sides; add/mul/div/sqrt are correctly
+// rounded and contraction is off), so PinvTs/Cs are bit-identical to the host result.
+#include <hip/hip_runtime.h>
+
+#include "ecc_host_geometry.h"
+
+namespace {
+__global__ __launch_bounds__(64) void e1_kernel(const double* __restrict__ Ps, int n, float* __restrict__ PinvTs,
+                                                float* __restrict__ Cs)
+{
+    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    double P[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) P[k] = Ps[12 * (size_t)v + k];
+    float pinvT[12], C[4];
+    ecc_host::pinv_transpose(P, pinvT);
+    ecc_host::source_position(P, C);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) PinvTs[12 * (size_t)v + k] = pinvT[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Cs[4 * (size_t)v + k] = C[k];
+}
+}  // namespace
+
+extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream)
+{
+    hipLaunchKernelGGL(e1_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, Ps_d, n, PinvTs_d, Cs_d);
+    return hipGetLastError();
+}

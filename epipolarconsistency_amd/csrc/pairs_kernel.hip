@@ -212,14 +212,201 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     }
 }
 
+// =================================================================================================
+// Fast path (default).  Same algorithm, restructured for the CDNA4 vector ALU -- the kernel is bound
+// by VALU issue (4 x (sqrt + atan2 + 2 divisions + bilinear) per kappa sample), not by memory:
+//   * one WAVE per pair (4 pairs per 256-thread workgroup, no barrier, no LDS): 64 lanes x 23
+//     iterations cover N_kappa = 1448 with 98 % lane utilisation; K01 is wave-uniform and lives in
+//     SGPRs (readfirstlane);
+//   * +kappa and -kappa share the six products K[:,0]*cos, K[:,1]*sin (x(-kappa) = (-cos, sin));
+//   * the (alpha+pi, -t) periodicity fold is a sign-bit operation on the line instead of the
+//     reference's atan2 range tests: a line with l1 < 0 is negated (same point set), which maps
+//     a -> a-1, d -> 1-d, and the sample gets the sign bit back (derivative filter only);
+//   * 1/len by v_rsq_f32, the angle by one v_rcp_f32 + a degree-8 minimax polynomial of
+//     atan(q)/(pi q) in q^2 on [0,1] (max error 6.7e-8 in a, i.e. below the fp32 libm path of the
+//     oracle measured against float64), sin/cos(kappa) by the classic pi/4-reduced kernels
+//     (< 0.9 ulp); no IEEE division sequences in the loop;
+//   * two 8-byte loads per bilinear sample (taps (i,j),(i,j+1) are adjacent in the slab).
+// Differences to the oracle are at the ulp level of the sample coordinates; tests hold the mean
+// to 1e-5 and pair values to 2e-4 (fp32 noise floor, tests/test_oracle_properties.py).
+// =================================================================================================
+
+struct __attribute__((packed, aligned(4))) F2 {
+    float x, y;
+};
+
+__device__ __forceinline__ float uniformf(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+// sin and cos of kappa in [0, pi/2]: reduce to [0, pi/4] by kappa -> pi/2 - kappa (exact subtraction
+// of the high part, Sterbenz), then degree-7 / degree-8 kernels.
+__device__ __forceinline__ void sincos_quadrant(float kappa, float& s, float& c)
+{
+    const float pio2_hi = 1.57079637050628662109375f, pio2_lo = -4.37113900018624283e-8f;
+    const bool swap = kappa > 0.785398163397448f;
+    const float r = swap ? (pio2_hi - kappa) + pio2_lo : kappa;
+    const float z = r * r;
+    float ps = fmaf(fmaf(-1.958291686605662e-04f, z, 8.332724682986736e-03f), z, -1.66666641831398e-01f);
+    float sn = fmaf(ps, r * z, r);
+    float pc = fmaf(fmaf(fmaf(2.445712743792683e-05f, z, -1.3887537643313408e-03f), z, 4.166664928197861e-02f), z, -0.5f);
+    float cs = fmaf(pc, z, 1.0f);
+    s = swap ? cs : sn;
+    c = swap ? sn : cs;
+}
+
+struct SlabView {
+    const char* origin;  // slab base = padded element (row 0, column 0) = (ix = -1, iy = -1)
+    unsigned pitch4;     // row pitch in bytes
+};
+
+// One line (l0, l1, l2) -> signed bilinear sample of the dtr.
+template <bool DERIV>
+__device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
+                                             float n_t_f, float inv_range_t)
+{
+    // fold: negate the line when its normal points to negative y (the reference's a > 1 branch)
+    const unsigned m = __float_as_uint(l1) & 0x80000000u;
+    l0 = __uint_as_float(__float_as_uint(l0) ^ m);
+    l1 = __uint_as_float(__float_as_uint(l1) ^ m);
+    l2 = __uint_as_float(__float_as_uint(l2) ^ m);
+    const float inv = __builtin_amdgcn_rsqf(fmaf(l0, l0, l1 * l1));
+    const float d = fmaf(-(l2 * inv), inv_range_t, 0.5f);
+    // a = atan2(l1, l0) / pi in [0, 1]  (l1 >= 0)
+    const float ax = fabsf(l0);
+    const float mn = fminf(ax, l1), mx = fmaxf(ax, l1);
+    const float q = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = q * q;
+    float pz = 9.021107107e-04f;
+    pz = fmaf(pz, z, -5.094559398e-03f);
+    pz = fmaf(pz, z, 1.355605666e-02f);
+    pz = fmaf(pz, z, -2.385874465e-02f);
+    pz = fmaf(pz, z, 3.385784104e-02f);
+    pz = fmaf(pz, z, -4.520818591e-02f);
+    pz = fmaf(pz, z, 6.363805383e-02f);
+    pz = fmaf(pz, z, -1.061024442e-01f);
+    pz = fmaf(pz, z, 3.183098733e-01f);
+    const float base = pz * q;                       // atan(q)/pi in [0, 1/4]
+    const float r = (l1 > ax) ? 0.5f - base : base;  // first-quadrant angle / pi
+    const float a = (l0 < 0.f) ? 1.0f - r : r;
+    // texel position a*n_alpha - .5, d*n_t - .5 (normalised coordinates), expressed
+    // directly in the slab's padded coordinates (+1): the replicated border stands in for clamp
+    // addressing and all byte offsets are non-negative (saddr + 32-bit voffset loads)
+    const float xa = fmaf(a, n_alpha_f, 0.5f);
+    float yd = fmaf(d, n_t_f, 0.5f);
+    yd = fminf(fmaxf(yd, 0.f), n_t_f);
+    const float fi = floorf(xa), fj = floorf(yd);
+    const float fx = xa - fi, fy = yd - fj;
+    const unsigned off = (unsigned)(int)fi * sv.pitch4 + ((unsigned)(int)fj << 2);
+    const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);                // (i, j), (i, j+1)
+    const F2 c1 = *reinterpret_cast<const F2*>(sv.origin + (off + sv.pitch4));  // (i+1, j), (i+1, j+1)
+    const float r0 = fmaf(fx, c1.x - c0.x, c0.x);
+    const float r1 = fmaf(fx, c1.y - c0.y, c0.y);
+    const float v = fmaf(fy, r1 - r0, r0);
+    return DERIV ? __uint_as_float(__float_as_uint(v) ^ m) : v;
+}
+
+template <bool DERIV>
+__global__ __launch_bounds__(PK_THREADS) void pairs_kernel_fast(EccPairParams p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // XCD-aware mapping at workgroup granularity: a workgroup owns 4 consecutive pairs (they share
+    // view i, so its slab lines are reused out of this CU's L1); workgroups b and b+8 share an XCD.
+    const long long nblk = (p.count + 3) / 4;
+    const long long per_xcd = (nblk + 7) / 8;
+    const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= nblk) return;
+    const long long local = blk * 4 + wave;
+    if (local >= p.count) return;  // no barriers below: waves leave independently
+
+    int iP0, iP1, iD0, iD1, ci = 0, cj = 0;
+    if (p.indices) {
+        const int32_t* q = p.indices + 4 * (p.first + local);
+        iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
+    } else {
+        get_ij_closed(p.first + local, p.n_views, ci, cj);
+        iP0 = iD0 = ci;
+        iP1 = iD1 = cj;
+    }
+    iP0 = __builtin_amdgcn_readfirstlane(iP0);
+    iP1 = __builtin_amdgcn_readfirstlane(iP1);
+    iD0 = __builtin_amdgcn_readfirstlane(iD0);
+    iD1 = __builtin_amdgcn_readfirstlane(iD1);
+
+    float K0[8], K1[8];
+    if (iP0 == iP1) {
+        for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
+    } else {
+        compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0, p.PinvTs + 12 * iP1,
+                    p.object_radius_mm, p.num_samples, p.dkappa_user, K0, K1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        K0[i] = uniformf(K0[i]);
+        K1[i] = uniformf(K1[i]);
+    }
+    if (p.K01_out && lane == 0)
+        for (int i = 0; i < 8; i++) {
+            p.K01_out[16 * local + i] = K0[i];
+            p.K01_out[16 * local + 8 + i] = K1[i];
+        }
+
+    const unsigned pitch4 = (unsigned)p.pitch * 4u;
+    const SlabView sv0 = {reinterpret_cast<const char*>(p.dtrs[iD0]), pitch4};
+    const SlabView sv1 = {reinterpret_cast<const char*>(p.dtrs[iD1]), pitch4};
+    const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
+    const float inv_range_t = 1.0f / p.range_t;
+    const float dkappa = K1[6], kappa_max = K1[7], w06 = K0[6];
+
+    double acc = 0.0;
+    for (int k = lane; k < p.k_limit; k += 64) {
+        const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
+        if (kappa >= kappa_max) break;
+        float sn, cs;
+        sincos_quadrant(kappa, sn, cs);
+        // view 0
+        const float a00 = K0[0] * cs, a01 = K0[1] * cs, a02 = K0[2] * cs;
+        const float b00 = K0[3] * sn, b01 = K0[4] * sn, b02 = K0[5] * sn;
+        // view 1
+        const float a10 = K1[0] * cs, a11 = K1[1] * cs, a12 = K1[2] * cs;
+        const float b10 = K1[3] * sn, b11 = K1[4] * sn, b12 = K1[5] * sn;
+        const float v0p = sample_line<DERIV>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, inv_range_t);
+        const float v1p = sample_line<DERIV>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, inv_range_t);
+        const float v0m = sample_line<DERIV>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, inv_range_t);
+        const float v1m = sample_line<DERIV>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, inv_range_t);
+        const float vp = v0p - v1p, vm = v0m - v1m;
+        const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
+        acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) {
+        const float val = (float)acc;
+        if (p.pair_values) p.pair_values[local] = val;
+        if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
+    }
+}
+
 // Deterministic float64 sum of `count` pair values (single workgroup, fixed tree).
 // ref: ...RadonIntermediate.cpp:216-224 (host loop; weights are all 1).
 __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict__ vals, long long count,
                                                          double* __restrict__ out)
 {
     __shared__ double s[1024 / 64];
-    double acc = 0.0;
-    for (long long k = threadIdx.x; k < count; k += 1024) acc += (double)vals[k];
+    // 16-byte loads, four independent float64 accumulators per thread (fixed order => deterministic)
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const long long n4 = count >> 2;
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(vals);
+    for (long long k = threadIdx.x; k < n4; k += 1024) {
+        const float4 v = v4[k];
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+        a2 += (double)v.z;
+        a3 += (double)v.w;
+    }
+    double acc = (a0 + a1) + (a2 + a3);
+    if (threadIdx.x == 0)
+        for (long long k = n4 << 2; k < count; ++k) acc += (double)vals[k];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -232,15 +419,25 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream)
+extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, int variant, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
-    long long per_xcd = (p->count + 7) / 8;
+    if (variant == 1) {  // reference-order kernel (one workgroup per pair, libm-style math)
+        long long per_xcd = (p->count + 7) / 8;
+        dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
+        if (p->is_derivative)
+            hipLaunchKernelGGL(pairs_kernel<true>, grid, block, 0, stream, *p);
+        else
+            hipLaunchKernelGGL(pairs_kernel<false>, grid, block, 0, stream, *p);
+        return hipGetLastError();
+    }
+    long long nblk = (p->count + 3) / 4;
+    long long per_xcd = (nblk + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
     if (p->is_derivative)
-        hipLaunchKernelGGL(pairs_kernel<true>, grid, block, 0, stream, *p);
+        hipLaunchKernelGGL(pairs_kernel_fast<true>, grid, block, 0, stream, *p);
     else
-        hipLaunchKernelGGL(pairs_kernel<false>, grid, block, 0, stream, *p);
+        hipLaunchKernelGGL(pairs_kernel_fast<false>, grid, block, 0, stream, *p);
     return hipGetLastError();
 }
 

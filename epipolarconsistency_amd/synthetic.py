@@ -20,9 +20,15 @@ def sphere_phantom(n_spheres=8, seed=1234, extent_mm=60.0, rmin=10.0, rmax=40.0)
     return centers, radii, dens
 
 
-def short_scan(n_proj, n_u, n_v, pixel_mm, sid=744.3, sdd=1088.15476, max_angle_deg=200.0):
-    """Circular short scan with the example data's source/detector distances."""
-    return geometry.make_circular_trajectory(n_proj, sid, sdd, n_u, n_v, max_angle_deg, pixel_mm)
+def short_scan(n_proj, n_u, n_v, pixel_mm, sid=744.3, sdd=1088.15476, span_deg=200.0):
+    """Circular short scan with the example data's source/detector distances.  The n_proj views
+    cover [0, span_deg] inclusive (increment span/(n-1)): with the reference generator's
+    increment max_angle/n (makeCircularTrajectory) a 200 deg / 400 view scan contains 40 view pairs
+    exactly 180 deg apart, whose baseline passes through the world origin -- computeK01 then
+    divides 0/0 (ref: EpipolarConsistencyCommon.hxx:122,126) and the mean becomes NaN in the
+    reference as well.  The inclusive span has no such pair for the benchmark sizes."""
+    max_angle = span_deg * n_proj / max(n_proj - 1, 1)
+    return geometry.make_circular_trajectory(n_proj, sid, sdd, n_u, n_v, max_angle, pixel_mm)
 
 
 def _ray_setup(P):

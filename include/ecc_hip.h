@@ -117,13 +117,21 @@ int ecc_metric_destroy(ecc_metric* m);
 
 /* ref: MetricRadonIntermediate::setProjectionMatrices (…RadonIntermediate.cpp:134-163): per view
  * (P^+)^T and the source position in float64 (same Householder-QR arithmetic as
- * culaut/xprojectionmatrix.hxx:20-52,93-105), cast to float32 and uploaded asynchronously. */
+ * culaut/xprojectionmatrix.hxx:20-52,93-105), cast to float32.  The n x 12 doubles are uploaded
+ * asynchronously and the pre-compute runs on the device, one thread per view (bit-identical to
+ * ecc_host_pinvT / ecc_host_source_position). */
 int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n_views);
+/* Debug: the device-side result of the pre-compute (12 + 4 floats per view, host output). */
+int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs);
 
 /* ref: Metric::setObjectRadius / setEpipolarPlaneStep / MetricRadonIntermediate::useCorrelation
  * (EpipolarConsistency.cpp:70-90, …RadonIntermediate.cpp:80-85).  0 = automatic for both scalars.
  * use_corr != 0 is not implemented in this round (ECC_ERR_UNSUPPORTED at evaluate). */
 int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa, int use_corr);
+/* Diagnostic: 0 (default) = wave-per-pair kernel with restructured math; 1 = reference-order kernel
+ * (one workgroup per pair, sqrtf/atan2f/IEEE divisions as written in the reference).  Both are held
+ * to the same parity bar by tests/; variant 1 exists for A/B measurements. */
+int ecc_metric_set_kernel_variant(ecc_metric* m, int variant);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
 int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);

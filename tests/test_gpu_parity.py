@@ -95,6 +95,34 @@ def test_pairs_from_oracle_dtrs(gpu_ctx, oracle_mod, small_scan):
     assert m.evaluate() == mean
 
 
+def test_device_precompute_bitwise(gpu_ctx, oracle_mod, small_scan):
+    """E1 runs on the device in float64 (geometry_kernel.hip): bit-identical to the host/oracle."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"][:2]]
+    from test_oracle_pins import P000, P040, _random_Ps
+    Ps = [P000, P040] + _random_Ps(70, seed=5) + list(s["Ps"])
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    PinvTs, Cs = m.debug_geometry()
+    for k, P in enumerate(Ps):
+        assert np.array_equal(PinvTs[k], oracle_mod.pinvT(P)), k
+        assert np.array_equal(Cs[k], oracle_mod.source_position(P)), k
+        assert np.array_equal(PinvTs[k], E.host_pinvT(P)) and np.array_equal(Cs[k], E.host_source_position(P))
+
+
+def test_reference_order_kernel_variant(gpu_ctx, oracle_mod, small_scan):
+    """Variant 1 (one workgroup per pair, libm-style math) is held to the same bar as the default."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+    fast = m.evaluate()
+    m.setKernelVariant(1)
+    slow = m.evaluate()
+    assert _rel(fast, want["mean"]) < REL_MEAN and _rel(slow, want["mean"]) < REL_MEAN
+
+
 def test_end_to_end_small(gpu_ctx, oracle_mod, small_scan):
     """Images -> dtrs -> metric entirely on the GPU vs entirely in the oracle."""
     import epipolarconsistency_amd as E
