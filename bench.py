@@ -36,7 +36,6 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--bins", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="pair kernel: 0 fast (default), 1 reference-order")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
                     help="CPU baseline evaluates all pairs among every k-th view")
     return ap.parse_args()
@@ -103,7 +102,6 @@ def main():
         slabs_all = gathered
     dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
     metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
-    metric.setKernelVariant(args.variant)
 
     # ---- shard of the pair range --------------------------------------------------------------
     n_pairs = n * (n - 1) // 2

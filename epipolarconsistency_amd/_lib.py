@@ -47,7 +47,6 @@ SIGNATURES = {
     "ecc_metric_set_projections": (_i, [_vp, _vp, _i]),
     "ecc_metric_debug_geometry": (_i, [_vp, _vp, _vp]),
     "ecc_metric_set_params": (_i, [_vp, _d, _d, _i]),
-    "ecc_metric_set_kernel_variant": (_i, [_vp, _i]),
     "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
     "ecc_metric_evaluate_range": (_i, [_vp, _i64, _i64, _vp, _pd]),

@@ -206,7 +206,6 @@ class MetricRadonIntermediate:
         hs = (C.c_void_p * len(self._dtrs))(*[d._h for d in self._dtrs])
         check(_lib.lib().ecc_metric_create(self.ctx._h, len(self._dtrs), hs, C.byref(self._h)))
         check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
-        check(_lib.lib().ecc_metric_set_kernel_variant(self._h, getattr(self, '_variant', 0)))
         if self._Ps is not None:
             self.setProjectionMatrices(self._Ps)
         return self
@@ -252,13 +251,6 @@ class MetricRadonIntermediate:
         return self
 
     setdKappa = setEpipolarPlaneStep
-
-    def setKernelVariant(self, variant):
-        """0 = fast kernel (default), 1 = reference-order kernel (diagnostics / A-B runs)."""
-        self._variant = int(variant)
-        if self._h:
-            check(_lib.lib().ecc_metric_set_kernel_variant(self._h, self._variant))
-        return self
 
     def useCorrelation(self, corr=True):
         self._params[2] = 1 if corr else 0

@@ -26,7 +26,7 @@ extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
-extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, int variant, hipStream_t stream);
+extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
 
@@ -94,7 +94,6 @@ struct ecc_metric {
     // parameters
     double object_radius_mm = 0, dkappa = 0;
     int use_corr = 0;
-    int kernel_variant = 0;  // 0 fast (default), 1 reference-order
     // projections
     int n_views = 0;
     std::vector<double> P_first;  // first projection matrix (object radius estimate)
@@ -135,14 +134,15 @@ int ensure_trig(ecc_ctx* ctx, int n_alpha)
         ctx->trig_d = nullptr;
     }
     // alpha of angle bin ix, ref: RadonIntermediate.cu:46-50 (fp32, same expressions); the sine and
-    // cosine are taken once per angle on the host instead of once per thread on the device.
+    // cosine are taken once per angle on the host instead of once per thread on the device, correctly
+    // rounded (binary64 evaluation rounded once) so that the table does not depend on the libm.
     const float Pi = 3.14159265359f;
     std::vector<float> t(2 * (size_t)n_alpha);
     for (int ix = 0; ix < n_alpha; ++ix) {
         float x_rel = (ix / (float)n_alpha - 0.5f);
         float alpha = x_rel * Pi;
-        t[2 * ix] = sinf(alpha);
-        t[2 * ix + 1] = cosf(alpha);
+        t[2 * ix] = (float)std::sin((double)alpha);
+        t[2 * ix + 1] = (float)std::cos((double)alpha);
     }
     HIP_TRY(hipMalloc((void**)&ctx->trig_d, t.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(ctx->trig_d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -607,13 +607,6 @@ ECC_EXPORT int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, dou
     return ECC_OK;
 }
 
-ECC_EXPORT int ecc_metric_set_kernel_variant(ecc_metric* m, int variant)
-{
-    if (!m || variant < 0 || variant > 1) return fail(ECC_ERR_INVALID_ARGUMENT, "bad kernel variant");
-    m->kernel_variant = variant;
-    return ECC_OK;
-}
-
 ECC_EXPORT int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm)
 {
     if (!m || !radius_mm) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
@@ -673,7 +666,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     p.cost = cost_d;
     p.K01_out = K01_d;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(ecc_launch_pairs(&p, m->kernel_variant, ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;
@@ -783,7 +776,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     p.count = n_pairs;
     p.pair_values = m->pair_values_d;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(ecc_launch_pairs(&p, m->kernel_variant, ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;

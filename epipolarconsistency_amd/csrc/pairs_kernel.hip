@@ -2,11 +2,10 @@
 //
 // One launch does what the reference needs two kernels, two device-wide syncs and N_kappa float
 // atomics per pair for (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cu):
-//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> computed in-kernel by the workgroup that owns
-//                                                    the pair, kept in LDS, never written to HBM;
-//   kernelEpipolarCosistency<deriv,false> (:152-276) -> one 256-thread workgroup per pair, kappa
-//                                                    samples strided over the lanes, wave64
-//                                                    shuffle + LDS reduction, ONE plain store.
+//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> computed in-kernel by the wave that owns the
+//                                                    pair, kept in SGPRs, never written to HBM;
+//   kernelEpipolarCosistency<deriv,false> (:152-276) -> one wave64 per pair, kappa samples strided
+//                                                    over the lanes, shuffle reduction, ONE plain store.
 // Sampling replaces tex2D on a normalised, clamped, bilinear texture (ref: RadonIntermediate.cpp:192)
 // by the exact fp32 rule of SURVEY.md 8c on the padded, distance-fast slab of ecc_layout.h: two
 // 8-byte loads per sample (taps (i,j),(i,j+1) are adjacent), no index clamps.
@@ -47,7 +46,8 @@ __device__ __forceinline__ void shift_origin_and_normalize(float x, float y, flo
 // ref: EpipolarConsistencyCommon.hxx:93-149 (computeK01), same expressions in fp32.
 __device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0, const float* __restrict__ C1,
                             const float* __restrict__ P0invT, const float* __restrict__ P1invT,
-                            float object_radius_mm, float num_samples, float dkappa, float* K0, float* K1)
+                            float object_radius_mm, float num_samples, float dkappa, bool want_view_angle,
+                            float* K0, float* K1)
 {
     float B01 = C0[0] * C1[1] - C0[1] * C1[0];
     float B02 = C0[0] * C1[2] - C0[2] * C1[0];
@@ -76,145 +76,19 @@ __device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0
     shift_origin_and_normalize(n_x2, n_y2, K0);
     shift_origin_and_normalize(n_x2, n_y2, K1);
     K0[6] = s2 / s3;
-    K0[7] = -2.0f * atan2f(-0.5f * s3, s2 / s3);
+    // Elementary functions correctly rounded (binary64, rounded once), like the oracle; they run once
+    // per pair.  K0[7] (angle between the views) is not used by the metric: debug output only.
+    K0[7] = want_view_angle ? -2.0f * (float)atan2((double)(-0.5f * s3), (double)(s2 / s3)) : 0.f;
     const float Pi = 3.14159265359f;
     if (K0[6] <= object_radius_mm) K1[7] = 0.5f * Pi;
-    else K1[7] = asinf(object_radius_mm / K0[6]);
+    else K1[7] = (float)asin((double)(object_radius_mm / K0[6]));
     if (dkappa <= 0.f) K1[6] = 2.f * K1[7] / num_samples;
     else K1[6] = dkappa;
 }
 
-// Bilinear sample of a dtr slab at normalised texture coordinates (a, d) with clamp addressing
-// (SURVEY.md 8c): texel position a*n_alpha-.5, d*n_t-.5.  The replicated border of the slab stands
-// in for the per-tap index clamps.
-__device__ __forceinline__ float sample_dtr(const float* __restrict__ slab, int pitch, float n_alpha_f,
-                                            float n_t_f, float a, float d)
-{
-    float xa = a * n_alpha_f - 0.5f;
-    float yd = d * n_t_f - 0.5f;
-    xa = fminf(fmaxf(xa, -1.f), n_alpha_f - 1.f);
-    yd = fminf(fmaxf(yd, -1.f), n_t_f - 1.f);
-    float fi = floorf(xa), fj = floorf(yd);
-    float fx = xa - fi, fy = yd - fj;
-    int idx = ((int)fi + 1) * pitch + ((int)fj + 1);
-    float T00 = slab[idx], T01 = slab[idx + 1];                    // (i, j), (i, j+1)
-    float T10 = slab[idx + pitch], T11 = slab[idx + pitch + 1];    // (i+1, j), (i+1, j+1)
-    float r0 = (1.f - fx) * T00 + fx * T10;
-    float r1 = (1.f - fx) * T01 + fx * T11;
-    return (1.f - fy) * r0 + fy * r1;
-}
-
-// ref: ...RadonIntermediate.cu:71-84 (getRedundancy) + EpipolarConsistencyCommon.hxx:152-171
-// (lineToSampleDtr), same expressions.
-template <bool DERIV>
-__device__ __forceinline__ float redundancy(const float* K, const float* __restrict__ slab, int pitch,
-                                            float n_alpha_f, float n_t_f, float range_t, float x0, float x1)
-{
-    const float Pi = 3.14159265359f;
-    float l0 = K[0] * x0 + K[3] * x1;
-    float l1 = K[1] * x0 + K[4] * x1;
-    float l2 = K[2] * x0 + K[5] * x1;
-    float length = sqrtf(l0 * l0 + l1 * l1);
-    float a = atan2f(l1, l0) / Pi;
-    if (a < 0) a += 2;
-    float d = -(l2 / length) / range_t + 0.5f;
-    bool moved = false;
-    if (a > 1) {
-        a = a - 1.f;
-        d = 1.f - d;
-        moved = true;
-    }
-    float v = sample_dtr(slab, pitch, n_alpha_f, n_t_f, a, d);
-    return (DERIV && moved) ? -v : v;
-}
-
-template <bool DERIV>
-__global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
-{
-    __shared__ float sK[16];
-    __shared__ double s_part[PK_THREADS / 64];
-
-    // XCD-aware block -> pair mapping: blocks b and b+8 share an XCD (round-robin dispatch), so each
-    // XCD walks one contiguous eighth of the pair range and keeps view i's slab hot in its own L2.
-    const long long b = blockIdx.x;
-    const long long per_xcd = (p.count + 7) / 8;
-    const long long local = (b & 7) * per_xcd + (b >> 3);
-    if (local >= p.count) return;  // whole workgroup leaves together (before any barrier)
-
-    int iP0, iP1, iD0, iD1, ci = 0, cj = 0;
-    if (p.indices) {
-        const int32_t* q = p.indices + 4 * (p.first + local);
-        iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
-    } else {
-        get_ij_closed(p.first + local, p.n_views, ci, cj);
-        iP0 = iD0 = ci;
-        iP1 = iD1 = cj;
-    }
-
-    if (threadIdx.x == 0) {
-        float K0[8], K1[8];
-        if (iP0 == iP1) {  // same-pointer guard, ref: EpipolarConsistencyCommon.hxx:108-113
-            for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
-        } else {
-            compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0,
-                        p.PinvTs + 12 * iP1, p.object_radius_mm, p.num_samples, p.dkappa_user, K0, K1);
-        }
-        for (int i = 0; i < 8; i++) {
-            sK[i] = K0[i];
-            sK[8 + i] = K1[i];
-        }
-        if (p.K01_out)
-            for (int i = 0; i < 8; i++) {
-                p.K01_out[16 * local + i] = K0[i];
-                p.K01_out[16 * local + 8 + i] = K1[i];
-            }
-    }
-    __syncthreads();
-
-    float K0[8], K1[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        K0[i] = sK[i];
-        K1[i] = sK[8 + i];
-    }
-    const float* __restrict__ slab0 = p.dtrs[iD0];
-    const float* __restrict__ slab1 = p.dtrs[iD1];
-    const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
-    const float dkappa = K1[6], kappa_max = K1[7];
-
-    // ref: ...RadonIntermediate.cu:257-270 and :87-113
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < p.k_limit; k += PK_THREADS) {
-        float kappa = dkappa * 0.5f + dkappa * k;
-        if (kappa >= kappa_max) break;
-        float x0, x1;
-        sincosf(kappa, &x1, &x0);
-        float vp = redundancy<DERIV>(K0, slab0, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1) -
-                   redundancy<DERIV>(K1, slab1, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1);
-        x0 *= -1;
-        float vm = redundancy<DERIV>(K0, slab0, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1) -
-                   redundancy<DERIV>(K1, slab1, p.pitch, n_alpha_f, n_t_f, p.range_t, x0, x1);
-        float consistency = (vp * vp + vm * vm) * K0[6];
-        acc += (double)(consistency * dkappa);
-    }
-
-    // wave64 shuffle reduction, then one LDS hop across the 4 waves
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < PK_THREADS / 64; w++) tot += s_part[w];
-        float val = (float)tot;
-        if (p.pair_values) p.pair_values[local] = val;
-        if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
-    }
-}
-
 // =================================================================================================
-// Fast path (default).  Same algorithm, restructured for the CDNA4 vector ALU -- the kernel is bound
-// by VALU issue (4 x (sqrt + atan2 + 2 divisions + bilinear) per kappa sample), not by memory:
+// The pair kernel.  Same algorithm as the reference, restructured for the CDNA4 vector ALU -- it is
+// bound by VALU issue (4 x (sqrt + atan2 + 2 divisions + bilinear) per kappa sample), not by memory:
 //   * one WAVE per pair (4 pairs per 256-thread workgroup, no barrier, no LDS): 64 lanes x 23
 //     iterations cover N_kappa = 1448 with 98 % lane utilisation; K01 is wave-uniform and lives in
 //     SGPRs (readfirstlane);
@@ -287,9 +161,22 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     pz = fmaf(pz, z, 6.363805383e-02f);
     pz = fmaf(pz, z, -1.061024442e-01f);
     pz = fmaf(pz, z, 3.183098733e-01f);
-    const float base = pz * q;                       // atan(q)/pi in [0, 1/4]
-    const float r = (l1 > ax) ? 0.5f - base : base;  // first-quadrant angle / pi
-    const float a = (l0 < 0.f) ? 1.0f - r : r;
+    const float base = pz * q;  // atan(q)/pi in [0, 1/4]
+    // Octant assembly r = cq + u with cq in {0, 1/2, 1}, u = +-base: angle / pi of the folded line.
+    const bool steep = l1 > ax;
+    const unsigned sgn = (__float_as_uint(l0) & 0x80000000u) ^ (steep ? 0x80000000u : 0u);
+    const float u = __uint_as_float(__float_as_uint(base) ^ sgn);
+    const float cq = steep ? 0.5f : (l0 < 0.f ? 1.0f : 0.0f);
+    // The reference divides by the FLOAT constant Pi = 3.14159265359f = pi (1 + e), e = 2.78e-8
+    // (ref: EpipolarConsistencyCommon.hxx:155,159): a = r (1 - e) on the direct branch and
+    // a = r + e (1 - r) on the folded (+2, -1) branch.  That 1e-5-bin shift of the sampling angle moves
+    // the 400-view metric by 1.7e-5 (profiles/r01_parity_probes.txt), so it is reproduced here; the
+    // correction is added to the small term u BEFORE the one rounding against cq, otherwise it would
+    // vanish below half an ulp of a.
+    const float e = 2.7827534e-8f;
+    const float r = cq + u;
+    const float t = (m ? 1.0f - r : -r) * e;
+    const float a = cq + (u + t);
     // texel position a*n_alpha - .5, d*n_t - .5 (normalised coordinates), expressed
     // directly in the slab's padded coordinates (+1): the replicated border stands in for clamp
     // addressing and all byte offsets are non-negative (saddr + 32-bit voffset loads)
@@ -308,7 +195,7 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
 }
 
 template <bool DERIV>
-__global__ __launch_bounds__(PK_THREADS) void pairs_kernel_fast(EccPairParams p)
+__global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // XCD-aware mapping at workgroup granularity: a workgroup owns 4 consecutive pairs (they share
@@ -339,7 +226,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel_fast(EccPairParams p)
         for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
     } else {
         compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0, p.PinvTs + 12 * iP1,
-                    p.object_radius_mm, p.num_samples, p.dkappa_user, K0, K1);
+                    p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, K0, K1);
     }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -419,25 +306,16 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, int variant, hipStream_t stream)
+extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
-    if (variant == 1) {  // reference-order kernel (one workgroup per pair, libm-style math)
-        long long per_xcd = (p->count + 7) / 8;
-        dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
-        if (p->is_derivative)
-            hipLaunchKernelGGL(pairs_kernel<true>, grid, block, 0, stream, *p);
-        else
-            hipLaunchKernelGGL(pairs_kernel<false>, grid, block, 0, stream, *p);
-        return hipGetLastError();
-    }
     long long nblk = (p->count + 3) / 4;
     long long per_xcd = (nblk + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
     if (p->is_derivative)
-        hipLaunchKernelGGL(pairs_kernel_fast<true>, grid, block, 0, stream, *p);
+        hipLaunchKernelGGL(pairs_kernel<true>, grid, block, 0, stream, *p);
     else
-        hipLaunchKernelGGL(pairs_kernel_fast<false>, grid, block, 0, stream, *p);
+        hipLaunchKernelGGL(pairs_kernel<false>, grid, block, 0, stream, *p);
     return hipGetLastError();
 }
 

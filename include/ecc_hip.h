@@ -128,10 +128,6 @@ int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs);
  * (EpipolarConsistency.cpp:70-90, …RadonIntermediate.cpp:80-85).  0 = automatic for both scalars.
  * use_corr != 0 is not implemented in this round (ECC_ERR_UNSUPPORTED at evaluate). */
 int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa, int use_corr);
-/* Diagnostic: 0 (default) = wave-per-pair kernel with restructured math; 1 = reference-order kernel
- * (one workgroup per pair, sqrtf/atan2f/IEEE divisions as written in the reference).  Both are held
- * to the same parity bar by tests/; variant 1 exists for A/B measurements. */
-int ecc_metric_set_kernel_variant(ecc_metric* m, int variant);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
 int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);

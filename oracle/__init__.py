@@ -215,7 +215,8 @@ def evaluate_pairs(Ps, dtrs, n_u, n_v, idx4, object_radius_mm=0.0, dkappa=0.0, i
 
 
 def set_variant(v):
-    """0 = normative fp32 path; 1 = line->(angle,distance) mapping in binary64 (noise-floor probe)."""
+    """0 = normative fp32 path (correctly rounded elementary functions); 1 = line->(angle,distance)
+    mapping in binary64 (noise-floor probe); 2 = platform float libm (what oracle/_ref is built on)."""
     L = lib()
     L.eccor_set_variant.argtypes = [C.c_int]
     L.eccor_set_variant(int(v))

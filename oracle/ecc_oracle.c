@@ -18,7 +18,12 @@
  *
  * Arithmetic convention: every float expression is the reference's C++ source expression
  * evaluated in IEEE-754 binary32, left to right, WITHOUT fused contraction (build with
- * -ffp-contract=off; see oracle/Makefile).  CUDA's hardware bilinear filter (9-bit weights)
+ * -ffp-contract=off; see oracle/Makefile).  Elementary functions (sinf, cosf, atan2f, asinf) are
+ * taken CORRECTLY ROUNDED (evaluated in binary64 and rounded once) so that the oracle does not
+ * depend on one libm: glibc 2.35's atan2f is biased by 0.135 ulp towards zero, which alone moves
+ * the 400-view metric by 2e-5 (measured, DESIGN.md "Oracle"); CUDA's atan2f/__sincosf, which the
+ * reference actually runs, are different again.  eccor_set_variant(2) switches to the platform's
+ * float libm -- that is the variant pinned bit-for-bit against the reference headers.  CUDA's hardware bilinear filter (9-bit weights)
  * is replaced by the exact fp32 rule of SURVEY.md 8c ("normative sampling rule").
  * Per-pair sums (atomicAdd in arbitrary order in the reference) are accumulated in binary64
  * and rounded once to float.
@@ -34,6 +39,16 @@
 #endif
 
 #define ECCOR_API __attribute__((visibility("default")))
+
+/* 0 normative (correctly rounded elementary functions); 1 sensitivity probe: line -> (angle,
+ * distance) mapping in binary64; 2 platform float libm (pinned against oracle/_ref). */
+static int g_variant = 0;
+ECCOR_API void eccor_set_variant(int v) { g_variant = v; }
+
+static float or_sinf(float x) { return g_variant == 2 ? sinf(x) : (float)sin((double)x); }
+static float or_cosf(float x) { return g_variant == 2 ? cosf(x) : (float)cos((double)x); }
+static float or_atan2f(float y, float x) { return g_variant == 2 ? atan2f(y, x) : (float)atan2((double)y, (double)x); }
+static float or_asinf(float x) { return g_variant == 2 ? asinf(x) : (float)asin((double)x); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* E1: per-view pre-compute (double in, float out)                                             */
@@ -282,9 +297,9 @@ ECCOR_API void eccor_computeK01(float n_x2, float n_y2, const float *C0, const f
         or_shift_origin_and_normalize(n_x2, n_y2, K0);
         or_shift_origin_and_normalize(n_x2, n_y2, K1);
         K0[6] = s2 / s3;
-        K0[7] = -2.0f * atan2f(-0.5f * s3, s2 / s3);
+        K0[7] = -2.0f * or_atan2f(-0.5f * s3, s2 / s3);
         if (K0[6] <= object_radius_mm) K1[7] = 0.5f * Pi;
-        else K1[7] = asinf(object_radius_mm / K0[6]);
+        else K1[7] = or_asinf(object_radius_mm / K0[6]);
         if (dkappa <= 0.f) K1[6] = 2.f * K1[7] / num_samples;
         else K1[6] = dkappa;
     }
@@ -296,7 +311,7 @@ ECCOR_API int eccor_line_to_sample_dtr(float *line, float range_t)
 {
     const float Pi = 3.14159265359f;
     float length = sqrtf(line[0] * line[0] + line[1] * line[1]);
-    line[0] = atan2f(line[1], line[0]) / Pi;
+    line[0] = or_atan2f(line[1], line[0]) / Pi;
     if (line[0] < 0) line[0] += 2;
     line[1] = -(line[2] / length) / range_t + 0.5f;
     if (line[0] > 1) {
@@ -364,8 +379,8 @@ static float or_radon_bin(const float *img, int W, int H, int n_alpha, int n_t, 
     float diag = sqrtf(n_u * n_u + n_v * n_v);
     float alpha = x_rel * Pi;
     float tau = y_rel * diag;
-    l[0] = -sinf(alpha);
-    l[1] = cosf(alpha);
+    l[0] = -or_sinf(alpha);
+    l[1] = or_cosf(alpha);
     l[2] = -tau;
     l[2] += -0.5f * n_u * l[0] - 0.5f * n_v * l[1];
     o[0] = -l[2] * l[0];
@@ -449,19 +464,33 @@ ECCOR_API void eccor_radon_bins(const float *img, int n_u, int n_v, int n_alpha,
 /* Sensitivity probe (NOT the normative path): variant 1 evaluates the line -> (angle, distance)
  * mapping in binary64 and rounds the two texture coordinates to float.  Tests use the distance
  * between variant 0 and variant 1 as the fp32 "noise floor" of the pair values. */
-static int g_variant = 0;
-ECCOR_API void eccor_set_variant(int v) { g_variant = v; }
+/* probe bits for variant 1: re-introduce single fp32 roundings of the normative path one at a time
+ * (1 float constant Pi, 2 float sin/cos, 4 float line, 8 float length, 16 float atan2/Pi,
+ * 32 float angle after +2, 64 float distance); 127 ~ the normative path. */
+static int g_probe = 0;
+ECCOR_API void eccor_set_probe(int bits) { g_probe = bits; }
 
 static float or_redundancy_f64(const float *K, const float *dtr, int n_alpha, int n_t,
                                float range_t, double x0, double x1, int is_derivative)
 {
-    const double Pi = 3.14159265358979323846;
-    double l0 = K[0] * x0 + K[3] * x1, l1 = K[1] * x0 + K[4] * x1, l2 = K[2] * x0 + K[5] * x1;
-    double len = sqrt(l0 * l0 + l1 * l1);
-    double a = atan2(l1, l0) / Pi, d;
+    const double Pi = (g_probe & 1) ? (double)3.14159265359f : 3.14159265358979323846;
+    double l0, l1, l2, len, a, d;
     int moved = 0;
+    if (g_probe & 2) { x0 = (float)x0; x1 = (float)x1; }
+    l0 = K[0] * x0 + K[3] * x1; l1 = K[1] * x0 + K[4] * x1; l2 = K[2] * x0 + K[5] * x1;
+    if (g_probe & 4) {
+        l0 = (float)((float)(K[0] * (float)x0) + (float)(K[3] * (float)x1));
+        l1 = (float)((float)(K[1] * (float)x0) + (float)(K[4] * (float)x1));
+        l2 = (float)((float)(K[2] * (float)x0) + (float)(K[5] * (float)x1));
+    }
+    len = sqrt(l0 * l0 + l1 * l1);
+    if (g_probe & 8) len = (float)len;
+    a = atan2(l1, l0) / Pi;
+    if (g_probe & 16) a = (float)((float)atan2(l1, l0) / (float)Pi);
     if (a < 0) a += 2;
+    if (g_probe & 32) a = (float)a;
     d = -(l2 / len) / (double)range_t + 0.5;
+    if (g_probe & 64) d = (float)((float)(-(float)(l2 / len) / range_t) + 0.5f);
     if (a > 1) { a -= 1; d = 1 - d; moved = 1; }
     if (is_derivative && moved) return -eccor_tex2d_norm(dtr, n_alpha, n_t, (float)a, (float)d);
     return +eccor_tex2d_norm(dtr, n_alpha, n_t, (float)a, (float)d);
@@ -526,8 +555,8 @@ static float or_pair(const eccor_params *p, const float *C0, const float *C1, co
             acc += (double)(consistency * dkappa);
             continue;
         }
-        x0 = cosf(kappa);
-        x1 = sinf(kappa);
+        x0 = or_cosf(kappa);
+        x1 = or_sinf(kappa);
         vp = or_redundancy(K0, dtr0, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative) -
              or_redundancy(K1, dtr1, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
         x0 *= -1;

@@ -81,7 +81,7 @@ def test_pairs_from_oracle_dtrs(gpu_ctx, oracle_mod, small_scan):
     assert _rel(mean, want["mean"]) < REL_MEAN, (mean, want["mean"])
     # K01 as used by the kernel (fp32 device math vs glibc): tight
     K = m.debug_K01(0, n * (n - 1) // 2)
-    np.testing.assert_allclose(K, want["K01s"], rtol=3e-6, atol=1e-9)
+    np.testing.assert_allclose(K, want["K01s"], rtol=2e-7, atol=1e-12)  # same fp32 ops, CR asin/atan2 on both sides
     # cost image: i<j entries written at [j, i], everything else preserved (ref: ...cpp:183,214-221)
     for ij in range(n * (n - 1) // 2):
         i, j = E.get_ij(ij, n)
@@ -110,17 +110,29 @@ def test_device_precompute_bitwise(gpu_ctx, oracle_mod, small_scan):
         assert np.array_equal(PinvTs[k], E.host_pinvT(P)) and np.array_equal(Cs[k], E.host_source_position(P))
 
 
-def test_reference_order_kernel_variant(gpu_ctx, oracle_mod, small_scan):
-    """Variant 1 (one workgroup per pair, libm-style math) is held to the same bar as the default."""
+def test_subsampled_full_size_parity(gpu_ctx, oracle_mod):
+    """north_star's bar at BASELINE geometry: every 4th view of the 400-view 1024x1024 scan (100 views,
+    4950 pairs, N_kappa = 1448, 768x768 bins): mean within 1e-5 of the oracle.  Pair values are sums of
+    squared near-cancelling differences; at this size their fp32 noise floor (oracle with binary64
+    geometry vs the normative fp32 path, profiles/r01_parity_probes.txt) is ~2e-5 median / 5e-4 max, so
+    single pairs are held to 2e-3."""
+    import torch
     import epipolarconsistency_amd as E
-    s = small_scan
-    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
-    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
-    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
-    fast = m.evaluate()
-    m.setKernelVariant(1)
-    slow = m.evaluate()
-    assert _rel(fast, want["mean"]) < REL_MEAN and _rel(slow, want["mean"]) < REL_MEAN
+    from epipolarconsistency_amd import synthetic
+    S, B = 1024, 768
+    Ps = synthetic.short_scan(400, S, S, 0.308)[::4]
+    dev = torch.device("cuda", 0)
+    imgs = synthetic.projections_torch(Ps, S, S, synthetic.sphere_phantom(), dev)
+    torch.cuda.synchronize()
+    dtrs = E.RadonIntermediate.compute_batch(gpu_ctx, imgs, B, B)
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    n_pairs = len(Ps) * (len(Ps) - 1) // 2
+    total, vals = m.evaluate_range(0, n_pairs, want_pairs=True)
+    host = [d.readback() for d in dtrs]
+    want = oracle_mod.evaluate_all(Ps, host, S, S)
+    assert want["n_kappa"] == n_pairs * 1448
+    assert _rel(total / n_pairs, want["mean"]) < REL_MEAN, (total / n_pairs, want["mean"])
+    np.testing.assert_allclose(vals, want["pairs"], rtol=2e-3)
 
 
 def test_end_to_end_small(gpu_ctx, oracle_mod, small_scan):
