@@ -135,23 +135,11 @@ struct SlabView {
     unsigned pitch4;     // row pitch in bytes
 };
 
-// One line (l0, l1, l2) -> signed bilinear sample of the dtr.
-template <bool DERIV>
-__device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
-                                             float n_t_f, float inv_range_t)
+// atan(t)/pi for |t| <= 1 as t * P(t^2): degree-8 minimax fit of atan(q)/(pi q) on q^2 in [0,1]
+// (max error 6.7e-8 in the angle a, below the oracle's own fp32 rounding of a).
+__device__ __forceinline__ float atan_over_pi(float t)
 {
-    // fold: negate the line when its normal points to negative y (the reference's a > 1 branch)
-    const unsigned m = __float_as_uint(l1) & 0x80000000u;
-    l0 = __uint_as_float(__float_as_uint(l0) ^ m);
-    l1 = __uint_as_float(__float_as_uint(l1) ^ m);
-    l2 = __uint_as_float(__float_as_uint(l2) ^ m);
-    const float inv = __builtin_amdgcn_rsqf(fmaf(l0, l0, l1 * l1));
-    const float d = fmaf(-(l2 * inv), inv_range_t, 0.5f);
-    // a = atan2(l1, l0) / pi in [0, 1]  (l1 >= 0)
-    const float ax = fabsf(l0);
-    const float mn = fminf(ax, l1), mx = fmaxf(ax, l1);
-    const float q = mn * __builtin_amdgcn_rcpf(mx);
-    const float z = q * q;
+    const float z = t * t;
     float pz = 9.021107107e-04f;
     pz = fmaf(pz, z, -5.094559398e-03f);
     pz = fmaf(pz, z, 1.355605666e-02f);
@@ -161,12 +149,40 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     pz = fmaf(pz, z, 6.363805383e-02f);
     pz = fmaf(pz, z, -1.061024442e-01f);
     pz = fmaf(pz, z, 3.183098733e-01f);
-    const float base = pz * q;  // atan(q)/pi in [0, 1/4]
-    // Octant assembly r = cq + u with cq in {0, 1/2, 1}, u = +-base: angle / pi of the folded line.
-    const bool steep = l1 > ax;
-    const unsigned sgn = (__float_as_uint(l0) & 0x80000000u) ^ (steep ? 0x80000000u : 0u);
-    const float u = __uint_as_float(__float_as_uint(base) ^ sgn);
-    const float cq = steep ? 0.5f : (l0 < 0.f ? 1.0f : 0.0f);
+    return pz * t;
+}
+
+// One line (l0, l1, l2) -> signed bilinear sample of the dtr.
+// Instruction selection follows measured gfx950 issue costs (scripts/micro/valu_rate.hip):
+// v_fma/v_add/v_xor 2 cycles per wave64, v_floor/v_fract/v_cvt 4, v_cmp+v_cndmask 8 per pair,
+// v_rcp/v_rsq 8.6 -- so selects are replaced by sign-bit arithmetic and a wave-uniform branch.
+template <bool DERIV>
+__device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
+                                             float n_t_f, float inv_range_t, float pitch4_f)
+{
+    // fold: negate the line when its normal points to negative y (the reference's a > 1 branch)
+    const unsigned m = __float_as_uint(l1) & 0x80000000u;
+    l0 = __uint_as_float(__float_as_uint(l0) ^ m);
+    l1 = __uint_as_float(__float_as_uint(l1) ^ m);
+    l2 = __uint_as_float(__float_as_uint(l2) ^ m);
+    const float inv = __builtin_amdgcn_rsqf(fmaf(l0, l0, l1 * l1));
+    const float d = fmaf(-(l2 * inv), inv_range_t, 0.5f);
+
+    // r = angle(l0, l1) / pi in [0, 1] as cq + u, cq in {0, 1/2, 1}, |u| <= 1/4 (l1 >= 0 here).
+    float cq, u;
+    const float ax = fabsf(l0);
+    if (__builtin_amdgcn_ballot_w64(l1 < ax) == 0) {
+        // every lane of the wave has a line within 45 deg of the image x axis (normal closer to y):
+        // r = 1/2 - atan(l0 / l1) / pi.  This is the only case a circular C-arm scan produces.
+        cq = 0.5f;
+        u = -atan_over_pi(l0 * __builtin_amdgcn_rcpf(l1));
+    } else {
+        const bool steep = l1 >= ax;
+        const float num = steep ? l0 : l1, den = steep ? l1 : l0;  // signed quotient, |num/den| <= 1
+        const float p = atan_over_pi(num * __builtin_amdgcn_rcpf(den));
+        cq = steep ? 0.5f : (l0 < 0.f ? 1.0f : 0.0f);
+        u = steep ? -p : p;
+    }
     // The reference divides by the FLOAT constant Pi = 3.14159265359f = pi (1 + e), e = 2.78e-8
     // (ref: EpipolarConsistencyCommon.hxx:155,159): a = r (1 - e) on the direct branch and
     // a = r + e (1 - r) on the folded (+2, -1) branch.  That 1e-5-bin shift of the sampling angle moves
@@ -174,18 +190,18 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     // correction is added to the small term u BEFORE the one rounding against cq, otherwise it would
     // vanish below half an ulp of a.
     const float e = 2.7827534e-8f;
-    const float r = cq + u;
-    const float t = (m ? 1.0f - r : -r) * e;
-    const float a = cq + (u + t);
+    const float folded01 = __uint_as_float((unsigned)((int)m >> 31) & 0x3f800000u);  // 1.0f if folded else 0.0f
+    const float a = cq + fmaf(folded01 - (cq + u), e, u);
+
     // texel position a*n_alpha - .5, d*n_t - .5 (normalised coordinates), expressed
     // directly in the slab's padded coordinates (+1): the replicated border stands in for clamp
     // addressing and all byte offsets are non-negative (saddr + 32-bit voffset loads)
     const float xa = fmaf(a, n_alpha_f, 0.5f);
     float yd = fmaf(d, n_t_f, 0.5f);
-    yd = fminf(fmaxf(yd, 0.f), n_t_f);
-    const float fi = floorf(xa), fj = floorf(yd);
-    const float fx = xa - fi, fy = yd - fj;
-    const unsigned off = (unsigned)(int)fi * sv.pitch4 + ((unsigned)(int)fj << 2);
+    yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
+    const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
+    // byte offset floor(xa)*pitch4 + floor(yd)*4 formed exactly in fp32 (< 2^24), one conversion
+    const unsigned off = (unsigned)fmaf(xa - fx, pitch4_f, (yd - fy) * 4.0f);
     const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);                // (i, j), (i, j+1)
     const F2 c1 = *reinterpret_cast<const F2*>(sv.origin + (off + sv.pitch4));  // (i+1, j), (i+1, j+1)
     const float r0 = fmaf(fx, c1.x - c0.x, c0.x);
@@ -244,6 +260,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     const SlabView sv1 = {reinterpret_cast<const char*>(p.dtrs[iD1]), pitch4};
     const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
     const float inv_range_t = 1.0f / p.range_t;
+    const float pitch4_f = (float)pitch4;
     const float dkappa = K1[6], kappa_max = K1[7], w06 = K0[6];
 
     double acc = 0.0;
@@ -258,10 +275,10 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
         // view 1
         const float a10 = K1[0] * cs, a11 = K1[1] * cs, a12 = K1[2] * cs;
         const float b10 = K1[3] * sn, b11 = K1[4] * sn, b12 = K1[5] * sn;
-        const float v0p = sample_line<DERIV>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, inv_range_t);
-        const float v1p = sample_line<DERIV>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, inv_range_t);
-        const float v0m = sample_line<DERIV>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, inv_range_t);
-        const float v1m = sample_line<DERIV>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, inv_range_t);
+        const float v0p = sample_line<DERIV>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
+        const float v1p = sample_line<DERIV>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
+        const float v0m = sample_line<DERIV>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
+        const float v1m = sample_line<DERIV>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
         const float vp = v0p - v1p, vm = v0m - v1m;
         const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
         acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
