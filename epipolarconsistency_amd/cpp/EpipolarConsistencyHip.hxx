@@ -1,0 +1,289 @@
+// EpipolarConsistencyHip.hxx -- header-only C++ adapter: the reference's class names and method
+// signatures for the hot path, forwarding to the C ABI of libecc_hip.so (include/ecc_hip.h).
+//
+//   EpipolarConsistency::RadonIntermediate        ref: LibEpipolarConsistency/RadonIntermediate.h:18-128
+//   EpipolarConsistency::Metric                   ref: LibEpipolarConsistency/EpipolarConsistency.h:49-94
+//   EpipolarConsistency::MetricRadonIntermediate  ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.h:21-106
+//
+// A caller such as Gui/SingleImageMotion.h (:37,72,88), Gui/Registration.h (:34,67,80) or
+// tools/Registration/Registration3D3D.hxx (:66-67,95) compiles against this header instead of the
+// three reference headers above and links libecc_hip.so instead of LibEpipolarConsistency +
+// LibUtilsCuda; nothing else changes.  With Eigen on the include path Geometry::ProjectionMatrix is
+// the reference's Eigen::Matrix<double,3,4>; without it a 12-double column-major stand-in with the
+// same .data() contract is used (that is what this repository's tests compile, Eigen is not
+// installed here).  Images are taken as (pointer, width, height); an overload for the reference's
+// NRRD::ImageView<float> is enabled when <NRRD/nrrd_image_view.hxx> is on the include path.
+//
+// Error behaviour: the reference prints and exit()s on any CUDA error (LibUtilsCuda/UtilsCuda.hxx:14-28);
+// the adapter throws std::runtime_error with ecc_last_error() instead.
+// Not carried over: getTexture()/BindlessTexture2D (there are no textures),
+// setProjectionImages (a stub in the reference, ...RadonIntermediate.cpp:121-125), evaluateForImagePair.
+#ifndef ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
+#define ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
+
+#include <cmath>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ecc_hip.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define ECC_ADAPTER_HAVE_EIGEN 1
+#endif
+#if __has_include(<NRRD/nrrd_image_view.hxx>)
+#include <NRRD/nrrd_image_view.hxx>
+#define ECC_ADAPTER_HAVE_NRRD 1
+#endif
+#endif
+
+namespace Geometry {
+#ifdef ECC_ADAPTER_HAVE_EIGEN
+typedef Eigen::Matrix<double, 3, 4> ProjectionMatrix;  // ref: LibProjectiveGeometry/ProjectiveGeometry.hxx:22
+#else
+/// 3x4, column-major like Eigen's default: element (r, c) at data()[r + 3*c].
+struct ProjectionMatrix {
+    double v[12];
+    ProjectionMatrix() { for (double& x : v) x = 0; }
+    double& operator()(int r, int c) { return v[r + 3 * c]; }
+    double operator()(int r, int c) const { return v[r + 3 * c]; }
+    const double* data() const { return v; }
+    double* data() { return v; }
+};
+#endif
+}  // namespace Geometry
+
+namespace EpipolarConsistency {
+
+using Geometry::ProjectionMatrix;
+
+namespace detail {
+inline void check(int rc)
+{
+    if (rc != ECC_OK) throw std::runtime_error(std::string("libecc_hip: ") + ecc_last_error());
+}
+/// One context per (device, stream); the reference uses the current device's default stream.
+inline ecc_ctx* default_context()
+{
+    static ecc_ctx* ctx = nullptr;
+    if (!ctx) check(ecc_ctx_create(0, nullptr, &ctx));
+    return ctx;
+}
+}  // namespace detail
+
+/// ref: class RadonIntermediate
+class RadonIntermediate {
+public:
+    enum Filter { Derivative = 0, Ramp = 1, None = 2 };
+    enum PostProcess { Identity = 0, SquareRoot = 1, Logarithm = 2 };
+
+    /// ref: RadonIntermediate(const NRRD::ImageView<float>&, size_alpha, size_t, filter, post_process)
+    RadonIntermediate(const float* projectionData, int n_u, int n_v, int size_alpha, int size_t, Filter filter,
+                      PostProcess post_process, ecc_ctx* ctx = nullptr)
+        : m_h(nullptr)
+    {
+        detail::check(ecc_radon_compute(ctx ? ctx : detail::default_context(), projectionData, 0, n_u, n_v, size_alpha,
+                                        size_t, (int)filter, (int)post_process, &m_h));
+    }
+#ifdef ECC_ADAPTER_HAVE_NRRD
+    RadonIntermediate(const NRRD::ImageView<float>& projectionData, int size_alpha, int size_t, Filter filter,
+                      PostProcess post_process)
+        : RadonIntermediate((const float*)projectionData, projectionData.size(0), projectionData.size(1), size_alpha,
+                            size_t, filter, post_process)
+    {
+    }
+#endif
+    /// ref: RadonIntermediate(const NRRD::ImageView<float>& radon_intermediate_image): existing dtr data,
+    /// n_t rows x n_alpha columns (alpha fastest); the original image size comes from the meta info there.
+    RadonIntermediate(const float* radon_intermediate_image, int n_alpha, int n_t, int original_n_u, int original_n_v,
+                      Filter filter, ecc_ctx* ctx = nullptr)
+        : m_h(nullptr)
+    {
+        detail::check(ecc_dtr_from_host(ctx ? ctx : detail::default_context(), radon_intermediate_image, n_alpha, n_t,
+                                        original_n_u, original_n_v, (int)filter, &m_h));
+    }
+    /// Adopts a handle produced by ecc_radon_compute_batch.
+    explicit RadonIntermediate(ecc_dtr* handle) : m_h(handle) {}
+    ~RadonIntermediate() { ecc_dtr_destroy(m_h); }
+
+    Filter getFilter() const { return (Filter)info().filter; }
+    bool isDerivative() const { return getFilter() == Derivative; }
+    /// 0: angle bins, 1: distance bins (ref: RadonIntermediate.cpp:165-168)
+    int getRadonBinNumber(int dim) const { return dim ? info().n_t : info().n_alpha; }
+    int getOriginalImageSize(int dim) const { return dim ? info().n_v : info().n_u; }
+    /// 0: angle, 1: distance (ref: RadonIntermediate.cpp:175-178)
+    double getRadonBinSize(int dim = 1) const { return dim ? info().bin_distance : info().bin_angle; }
+
+    /// ref: readback() + data(): host copy, n_t rows x n_alpha columns, alpha fastest.
+    void readback(bool /*gpu_memory_only*/ = false)
+    {
+        Info i = info();
+        m_raw_cpu.resize((size_t)i.n_alpha * i.n_t);
+        detail::check(ecc_dtr_readback(m_h, m_raw_cpu.data()));
+    }
+    const std::vector<float>& data() const { return m_raw_cpu; }
+    void clearRawData() { std::vector<float>().swap(m_raw_cpu); }
+
+    /// ref: writePropertiesToMeta (RadonIntermediate.cpp:95-103)
+    void writePropertiesToMeta(std::map<std::string, std::string>& dict) const
+    {
+        Info i = info();
+        dict["Bin Size/Angle"] = std::to_string(i.bin_angle);
+        dict["Bin Size/Distance"] = std::to_string(i.bin_distance);
+        dict["Original Image/Width"] = std::to_string(i.n_u);
+        dict["Original Image/Height"] = std::to_string(i.n_v);
+        dict["Filter"] = i.filter == Derivative ? "Derivative" : (i.filter == Ramp ? "Ramp" : "None");
+    }
+
+    ecc_dtr* handle() const { return m_h; }
+
+private:
+    RadonIntermediate(const RadonIntermediate&);
+    RadonIntermediate& operator=(const RadonIntermediate&);
+    struct Info {
+        int n_alpha, n_t, n_u, n_v, filter;
+        double bin_angle, bin_distance;
+    };
+    Info info() const
+    {
+        Info i;
+        detail::check(ecc_dtr_info(m_h, &i.n_alpha, &i.n_t, &i.n_u, &i.n_v, &i.filter, &i.bin_angle, &i.bin_distance));
+        return i;
+    }
+    ecc_dtr* m_h;
+    std::vector<float> m_raw_cpu;
+};
+
+/// ref: class Metric (interface)
+class Metric {
+protected:
+    double object_radius_mm;
+    double dkappa;
+    std::vector<ProjectionMatrix> Ps;
+
+public:
+    Metric() : object_radius_mm(0), dkappa(0) {}
+    virtual ~Metric() {}
+    virtual Metric& setObjectRadius(double radius_mm = 0) { object_radius_mm = radius_mm; return *this; }
+    virtual double getObjectRadius() const = 0;
+    virtual Metric& setEpipolarPlaneStep(double dkappa_rad = 0) { dkappa = dkappa_rad; return *this; }
+    virtual Metric& setProjectionMatrices(const std::vector<ProjectionMatrix>& _Ps) { Ps = _Ps; return *this; }
+    const std::vector<ProjectionMatrix>& getProjectionMatrices() const { return Ps; }
+    virtual int getNumberOfProjetions() = 0;
+    virtual double evaluate(float* cost_image = 0x0) = 0;
+};
+
+/// ref: class MetricRadonIntermediate : public Metric
+class MetricRadonIntermediate : public Metric {
+    std::vector<RadonIntermediate*> dtrs;
+    bool use_corr;
+    ecc_metric* m_h;
+    ecc_ctx* m_ctx;
+
+    void push_params() { if (m_h) detail::check(ecc_metric_set_params(m_h, object_radius_mm, dkappa, use_corr ? 1 : 0)); }
+    void push_projections()
+    {
+        if (!m_h || Ps.empty()) return;
+        std::vector<double> flat(12 * Ps.size());
+        for (size_t i = 0; i < Ps.size(); ++i)
+            for (int k = 0; k < 12; ++k) flat[12 * i + k] = Ps[i].data()[k];
+        detail::check(ecc_metric_set_projections(m_h, flat.data(), (int)Ps.size()));
+    }
+
+public:
+    explicit MetricRadonIntermediate(ecc_ctx* ctx = nullptr) : use_corr(false), m_h(nullptr), m_ctx(ctx) {}
+    MetricRadonIntermediate(const std::vector<ProjectionMatrix>& _Ps, const std::vector<RadonIntermediate*>& _dtrs,
+                            ecc_ctx* ctx = nullptr)
+        : use_corr(false), m_h(nullptr), m_ctx(ctx)
+    {
+        setProjectionMatrices(_Ps);
+        setRadonIntermediates(_dtrs);
+    }
+    ~MetricRadonIntermediate() { ecc_metric_destroy(m_h); }
+
+    MetricRadonIntermediate& setdKappa(float _dkappa) { dkappa = _dkappa; push_params(); return *this; }
+    MetricRadonIntermediate& useCorrelation(bool corr = true) { use_corr = corr; push_params(); return *this; }
+
+    /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
+    MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)
+    {
+        dtrs = _dtrs;
+        ecc_metric_destroy(m_h);
+        m_h = nullptr;
+        std::vector<ecc_dtr*> hs(dtrs.size());
+        for (size_t i = 0; i < dtrs.size(); ++i) hs[i] = dtrs[i]->handle();
+        detail::check(ecc_metric_create(m_ctx ? m_ctx : detail::default_context(), (int)hs.size(), hs.data(), &m_h));
+        push_params();
+        push_projections();
+        return *this;
+    }
+    const std::vector<RadonIntermediate*>& getRadonIntermediates() const { return dtrs; }
+
+    virtual Metric& setObjectRadius(double radius_mm = 0) { Metric::setObjectRadius(radius_mm); push_params(); return *this; }
+    virtual Metric& setEpipolarPlaneStep(double dkappa_rad = 0) { Metric::setEpipolarPlaneStep(dkappa_rad); push_params(); return *this; }
+    virtual double getObjectRadius() const
+    {
+        double r = 0;
+        if (m_h) detail::check(ecc_metric_get_object_radius(m_h, &r));
+        return r;
+    }
+
+    virtual Metric& setProjectionMatrices(const std::vector<ProjectionMatrix>& _Ps)
+    {
+        Metric::setProjectionMatrices(_Ps);
+        push_projections();
+        return *this;
+    }
+
+    virtual int getNumberOfProjetions() { return (int)Ps.size(); }
+
+    /// Out is n*n (index i + j*n, i<j written, the rest preserved) and the mean is returned.
+    virtual double evaluate(float* out = 0x0)
+    {
+        double mean = 0;
+        detail::check(ecc_metric_evaluate_all(m_h, out, &mean));
+        return mean;
+    }
+
+    /// ref: evaluate(const std::set<int>& views, float* out): all pairs inside the subset.
+    double evaluate(const std::set<int>& views, float* _out = 0x0)
+    {
+        std::vector<int32_t> idx;
+        for (std::set<int>::const_iterator i = views.begin(); i != views.end(); ++i)
+            for (std::set<int>::const_iterator j = i; j != views.end(); ++j) {
+                if (i == j) continue;
+                const int32_t t[4] = {*i, *j, *i, *j};
+                idx.insert(idx.end(), t, t + 4);
+            }
+        return evaluate_indices(idx.data(), (int)(idx.size() / 4), _out);
+    }
+
+#ifdef ECC_ADAPTER_HAVE_EIGEN
+    /// ref: evaluate(const std::vector<Eigen::Vector4i>& indices, float* out): (P0, P1, dtr0, dtr1) tuples.
+    double evaluate(const std::vector<Eigen::Vector4i>& _indices, float* _out)
+    {
+        std::vector<int32_t> idx(4 * _indices.size());
+        for (size_t i = 0; i < _indices.size(); ++i)
+            for (int k = 0; k < 4; ++k) idx[4 * i + k] = _indices[i][k];
+        return evaluate_indices(idx.data(), (int)_indices.size(), _out);
+    }
+#endif
+    /// Same with a flat int32 array of 4-tuples (what the Eigen overload forwards to).
+    double evaluate_indices(const int32_t* idx4, int n_pairs, float* _out)
+    {
+        double mean = 0;
+        detail::check(ecc_metric_evaluate_pairs(m_h, idx4, n_pairs, _out, &mean));
+        return mean;
+    }
+
+private:
+    MetricRadonIntermediate(const MetricRadonIntermediate&);
+};
+
+}  // namespace EpipolarConsistency
+
+#endif

@@ -1,0 +1,55 @@
+// Exercises the C++ adapter the way the reference's callers use the classes
+// (ref: Gui/SingleImageMotion.h:84-90 -- overwrite one projection matrix, setProjectionMatrices, evaluate).
+// Reads a raw float32 image stack + matrices written by the pytest driver, prints results as text.
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <vector>
+
+#include "EpipolarConsistencyHip.hxx"
+
+using namespace EpipolarConsistency;
+
+int main(int argc, char** argv)
+{
+    if (argc < 8) return 2;
+    const char* path = argv[1];
+    const int n = atoi(argv[2]), n_u = atoi(argv[3]), n_v = atoi(argv[4]), n_alpha = atoi(argv[5]), n_t = atoi(argv[6]);
+    const char* ppath = argv[7];
+    std::vector<float> imgs((size_t)n * n_u * n_v);
+    std::vector<double> Pflat(12 * (size_t)n);
+    FILE* f = fopen(path, "rb");
+    if (!f || fread(imgs.data(), sizeof(float), imgs.size(), f) != imgs.size()) return 3;
+    fclose(f);
+    f = fopen(ppath, "rb");
+    if (!f || fread(Pflat.data(), sizeof(double), Pflat.size(), f) != Pflat.size()) return 3;
+    fclose(f);
+    try {
+        std::vector<RadonIntermediate*> dtrs;
+        std::vector<ProjectionMatrix> Ps(n);
+        for (int k = 0; k < n; ++k) {
+            dtrs.push_back(new RadonIntermediate(imgs.data() + (size_t)k * n_u * n_v, n_u, n_v, n_alpha, n_t,
+                                                 RadonIntermediate::Derivative, RadonIntermediate::Identity));
+            for (int e = 0; e < 12; ++e) Ps[k].data()[e] = Pflat[12 * k + e];
+        }
+        MetricRadonIntermediate ecc(Ps, dtrs);
+        std::vector<float> cost((size_t)n * n, -1.f);
+        printf("radius %.17g\n", ecc.getObjectRadius());
+        printf("mean %.17g\n", ecc.evaluate(cost.data()));
+        printf("cost10 %.9g cost01 %.9g\n", cost[0 + 1 * n], cost[1 + 0 * n]);
+        std::set<int> views;
+        views.insert(0); views.insert(2); views.insert(3);
+        printf("subset %.17g\n", ecc.evaluate(views));
+        dtrs[1]->readback();
+        printf("dtr1 %zu %.9g bins %d %d size %d %d step %.17g\n", dtrs[1]->data().size(), dtrs[1]->data()[1234 % dtrs[1]->data().size()],
+               dtrs[1]->getRadonBinNumber(0), dtrs[1]->getRadonBinNumber(1), dtrs[1]->getOriginalImageSize(0),
+               dtrs[1]->getOriginalImageSize(1), dtrs[1]->getRadonBinSize(1));
+        ecc.setObjectRadius(50.0);
+        printf("mean_r50 %.17g\n", ecc.evaluate());
+        for (size_t k = 0; k < dtrs.size(); ++k) delete dtrs[k];
+    } catch (const std::exception& e) {
+        fprintf(stderr, "exception: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
