@@ -25,13 +25,21 @@
 
 #include "ecc_layout.h"
 
+#ifdef ECC_RADON_STATS
+__device__ unsigned long long g_radon_stats[8];
+#define RSTAT(i, v) atomicAdd(&g_radon_stats[i], (unsigned long long)(v))
+#else
+#define RSTAT(i, v)
+#endif
+
 namespace {
 
 constexpr int RT_T = 32;                   // distance bins per workgroup (lane & 31)
 constexpr int RT_A = 8;                    // angle bins per workgroup    (tid >> 5)
 constexpr int RT_THREADS = RT_T * RT_A;    // 256
-constexpr int TILE_S = 96;                 // LDS tile row stride (floats)
+constexpr int TILE_W = 96;                 // usable LDS tile width (texels)
 constexpr int TILE_H = 96;                 // LDS tile rows
+constexpr int TILE_S_MAX = 97;             // row stride is 97 or 95 floats (odd, see radon_kernel)
 constexpr float RADON_STEP = .66f;         // ref: RadonIntermediate.cu:102
 constexpr int MAX_CHUNKS = 8192;           // bound on the chunk loop (every spin is bounded)
 
@@ -54,6 +62,7 @@ __device__ __forceinline__ float tex_global(const float* __restrict__ img, int W
 
 // Same rule on the staged tile.  tile_off = by0*TILE_S + bx0 (tile origin in image texels); the
 // tile already holds clamped (replicated) texels, so taps need no index clamps.
+template <int TILE_S>
 __device__ __forceinline__ float tex_lds(const float* tile, int tile_off, float x, float y)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
@@ -89,14 +98,27 @@ __device__ __forceinline__ float wave_max_f(float v)
     return v;
 }
 
-template <bool DERIV>
-__global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
+struct RadonShared {
+    float tile[TILE_S_MAX * TILE_H];
+    int box[4][4];    // per wave: min x, min y, max x, max y
+    float u[4][2];    // per wave: min/max of the along-line coordinate
+    float geo[6];
+    int pend[4];
+};
+
+// TILE_S is the LDS row stride.  The 32 lanes of a half-wave are 32 adjacent distance bins of one
+// angle, i.e. sample points spaced 1.9 px along the line NORMAL (nx, ny).  ds_read_b32 banks are
+// (j*TILE_S + i) mod 32: with stride 97 the bank advances by 1.9 (nx + ny) per lane, with 95 by
+// 1.9 (nx - ny); the launcher of the body picks the one with the larger advance, so a half-wave never
+// walks along an iso-bank direction (a 96-float stride made 64 % of all LDS cycles bank conflicts
+// for near-horizontal lines, profiles/r01_pmc_lds.txt).
+template <bool DERIV, int TILE_S>
+__device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared& sh)
 {
-    __shared__ float tile[TILE_S * TILE_H];
-    __shared__ int s_box[4][4];      // per wave: min x, min y, max x, max y
-    __shared__ float s_u[4][2];      // per wave: min/max of the along-line coordinate
-    __shared__ float s_L;
-    __shared__ int s_pend[4];
+    float* tile = sh.tile;
+    auto& s_box = sh.box;
+    auto& s_u = sh.u;
+    auto& s_pend = sh.pend;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -163,22 +185,36 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
     const float U0 = fminf(fminf(s_u[0][0], s_u[1][0]), fminf(s_u[2][0], s_u[3][0]));
     const float U1 = fmaxf(fmaxf(s_u[0][1], s_u[1][1]), fmaxf(s_u[2][1], s_u[3][1]));
     if (tid == 0) {
-        // Chunk length so that the bounding box of a (L x band) rectangle at this angle fits the tile.
+        // Geometry of this workgroup's band for the chunk-length rule below (uniform via LDS).
         const float Pi = 3.14159265359f;
-        float dtau = diag / (float)p.n_t;
-        float far = fmaxf(fabsf(U0), fabsf(U1));
-        float band = (RT_T - 1) * dtau + 2.f + (RT_A - 1) * (Pi / (float)p.n_alpha) * far;
-        float cs = fabsf(d0), sn = fabsf(d1);
-        float Lw = cs > 1e-3f ? ((float)(TILE_S - 4) - band * sn) / cs : 1e9f;
-        float Lh = sn > 1e-3f ? ((float)(TILE_H - 4) - band * cs) / sn : 1e9f;
-        s_L = fminf(fmaxf(fminf(Lw, Lh), 4.f), 4096.f);
+        const float dtau = diag / (float)p.n_t;
+        const int iy0 = blockIdx.y * RT_T;
+        const float tau_a = fabsf(((float)iy0 / (float)p.n_t - 0.5f) * diag);
+        const float tau_b = fabsf(((float)(iy0 + RT_T - 1) / (float)p.n_t - 0.5f) * diag);
+        sh.geo[0] = fabsf(d0);                                    // |cos| of the line direction
+        sh.geo[1] = fabsf(d1);                                    // |sin|
+        sh.geo[2] = (RT_T - 1) * dtau + 2.f;                      // band across the lines (+ derivative pair)
+        sh.geo[3] = (RT_A - 1) * (Pi / (float)p.n_alpha);         // angular spread of the workgroup
+        sh.geo[4] = fmaxf(tau_a, tau_b);                          // largest |distance to centre|
+        sh.geo[5] = fmaxf(fabsf(U0), fabsf(U1));                  // largest |along-line coordinate|
     }
     __syncthreads();
-    const float L = s_L;
+    const float g_cs = sh.geo[0], g_sn = sh.geo[1], g_band = sh.geo[2], g_spread = sh.geo[3];
+    const float g_tau = sh.geo[4], g_far = sh.geo[5];
 
     float sum = 0.f, sumo = 0.f;
     float U = U0;
-    for (int it = 0; it < MAX_CHUNKS; ++it, U += L) {
+    for (int it = 0; it < MAX_CHUNKS; ++it) {
+        // Chunk length L: the chunk covers along-line coordinates [U, U+L) of every line of the workgroup.
+        // Seen from the image centre the 8 angles rotate the (L x band) rectangle by up to `spread`, which
+        // widens it by spread*|u| across the lines and lengthens it by spread*|tau| along them; L is the
+        // largest length whose axis-aligned bounding box still fits the LDS tile (identical in all threads).
+        const float reach = fminf(g_far, fabsf(U) + (float)TILE_W);
+        const float band = g_band + g_spread * reach;
+        const float slack = g_spread * g_tau;
+        const float Lw = g_cs > 1e-3f ? ((float)(TILE_W - 4) - band * g_sn) / g_cs : 1e9f;
+        const float Lh = g_sn > 1e-3f ? ((float)(TILE_H - 4) - band * g_cs) / g_sn : 1e9f;
+        const float L = fminf(fmaxf(fminf(Lw, Lh) - slack, 4.f), 4096.f);
         const float lim = (U + L) + tc;
         const bool pending = active && (t <= t_max);  // samples left at all
         const bool has = pending && (t < lim);        // samples inside this chunk
@@ -220,15 +256,33 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
         by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
         const bool any = bx1 >= bx0;
         const int w = bx1 - bx0 + 1, h = by1 - by0 + 1;
-        const bool fits = any && w <= TILE_S && h <= TILE_H;
+        const bool fits = any && w <= TILE_W && h <= TILE_H;
+        if (tid == 0) { RSTAT(0, 1); RSTAT(1, fits ? 1 : 0); RSTAT(2, any ? 1 : 0); RSTAT(5, w > 0 ? w : 0); RSTAT(6, h > 0 ? h : 0); }
         if (fits) {
+            // Stage the footprint: all of a thread's (up to 36) global loads are issued before the first
+            // LDS store so their latencies overlap (a load -> store loop serialises one L2 round trip per
+            // element).  Rows by wave-quarter, 32 consecutive texels per half-wave = one 128-B segment.
             const int cx = tid & 31, ry = tid >> 5;
-            for (int r = ry; r < h; r += RT_THREADS / 32) {
-                int gy = min(max(by0 + r, 0), H - 1);
+            float stage[(TILE_H / 8) * (TILE_W / 32)];
+#pragma unroll
+            for (int q = 0; q < TILE_H / 8; ++q) {
+                const int r = ry + 8 * q;
+                const int gy = min(max(by0 + r, 0), H - 1);
                 const float* __restrict__ row = img + (size_t)gy * W;
-                for (int c = cx; c < w; c += 32) {
-                    int gx = min(max(bx0 + c, 0), W - 1);
-                    tile[r * TILE_S + c] = row[gx];
+#pragma unroll
+                for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
+                    const int c = cx + 32 * c3;
+                    const int gx = min(max(bx0 + c, 0), W - 1);
+                    stage[q * (TILE_W / 32) + c3] = (r < h && c < w) ? row[gx] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TILE_H / 8; ++q) {
+                const int r = ry + 8 * q;
+#pragma unroll
+                for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
+                    const int c = cx + 32 * c3;
+                    if (r < h && c < w) tile[r * TILE_S + c] = stage[q * (TILE_W / 32) + c3];
                 }
             }
         }
@@ -238,18 +292,21 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
                 const int tile_off = by0 * TILE_S + bx0;
                 // ref: RadonIntermediate.cu:105-123 (t += step accumulates in fp32)
                 for (; t <= t_max && t < lim; t += RADON_STEP) {
+                    RSTAT(4, 1);
                     float x = o0 + t * d0, y = o1 + t * d1;
-                    sum += tex_lds(tile, tile_off, x, y);
-                    if (DERIV) sumo += tex_lds(tile, tile_off, x + d1, y - d0);
+                    sum += tex_lds<TILE_S>(tile, tile_off, x, y);
+                    if (DERIV) sumo += tex_lds<TILE_S>(tile, tile_off, x + d1, y - d0);
                 }
             } else {
                 for (; t <= t_max && t < lim; t += RADON_STEP) {
+                    RSTAT(3, 1);
                     float x = o0 + t * d0, y = o1 + t * d1;
                     sum += tex_global(img, W, H, x, y);
                     if (DERIV) sumo += tex_global(img, W, H, x + d1, y - d0);
                 }
             }
         }
+        U += L;
     }
     // Safety net (never taken for sane sizes): finish whatever MAX_CHUNKS did not cover.
     if (active)
@@ -271,6 +328,19 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
         float* out = p.out + (int64_t)blockIdx.z * p.out_stride;
         out[(size_t)(ix + 1) * p.pitch + (iy + 1)] = result;
     }
+}
+
+template <bool DERIV>
+__global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
+{
+    __shared__ RadonShared sh;
+    // line normal of this workgroup's first angle: (nx, ny) = (-sin a, cos a)
+    const int ix0 = min((int)blockIdx.x * RT_A, p.n_alpha - 1);
+    const float nx = -p.trig[2 * ix0], ny = p.trig[2 * ix0 + 1];
+    if (fabsf(nx + ny) >= fabsf(nx - ny))
+        radon_body<DERIV, 97>(p, sh);
+    else
+        radon_body<DERIV, 95>(p, sh);
 }
 
 // Replicate the border rows/columns of the private layout (clamp addressing, ecc_layout.h).
@@ -361,3 +431,14 @@ extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst_alpha_
     hipLaunchKernelGGL(dtr_export_kernel, grid, block, 0, stream, slab, dst_alpha_fast, n_alpha, n_t, pitch);
     return hipGetLastError();
 }
+
+#ifdef ECC_RADON_STATS
+extern "C" __attribute__((visibility("default"))) void ecc_debug_radon_stats(unsigned long long* out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_radon_stats), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_radon_stats), z, sizeof(z));
+    }
+}
+#endif
