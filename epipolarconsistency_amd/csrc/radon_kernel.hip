@@ -10,7 +10,7 @@
 // What is different from the reference is the machine mapping:
 //   * no texture unit: the bilinear filter is the exact fp32 rule of SURVEY.md 8c, evaluated from
 //     an LDS tile (4 taps = 2 x ds_read2_b32) instead of 4 scattered global loads;
-//   * a workgroup owns RT_A adjacent angles x RT_T adjacent distances (256 threads).  Its lines are
+//   * a workgroup owns RT_A = 16 adjacent angles x RT_T = 16 adjacent distances (256 threads).  Its lines are
 //     (nearly) parallel, so they sweep a narrow band of the image.  The band is walked in chunks
 //     along the line direction; for every chunk the axis-aligned bounding box of all sample
 //     footprints is staged into LDS with coalesced row reads (border replicated = clamp addressing),
@@ -34,8 +34,8 @@ __device__ unsigned long long g_radon_stats[8];
 
 namespace {
 
-constexpr int RT_T = 32;                   // distance bins per workgroup (lane & 31)
-constexpr int RT_A = 8;                    // angle bins per workgroup    (tid >> 5)
+constexpr int RT_T = 16;                   // distance bins per workgroup (tid & 15)
+constexpr int RT_A = 16;                   // angle bins per workgroup    (tid >> 4)
 constexpr int RT_THREADS = RT_T * RT_A;    // 256
 constexpr int TILE_W = 96;                 // usable LDS tile width (texels)
 constexpr int TILE_H = 96;                 // LDS tile rows
@@ -106,12 +106,13 @@ struct RadonShared {
     int pend[4];
 };
 
-// TILE_S is the LDS row stride.  The 32 lanes of a half-wave are 32 adjacent distance bins of one
-// angle, i.e. sample points spaced 1.9 px along the line NORMAL (nx, ny).  ds_read_b32 banks are
+// TILE_S is the LDS row stride.  A half-wave is 16 adjacent distance bins x 2 adjacent angles, i.e.
+// sample points spaced 1.9 px along the line NORMAL (nx, ny).  ds_read_b32 banks are
 // (j*TILE_S + i) mod 32: with stride 97 the bank advances by 1.9 (nx + ny) per lane, with 95 by
-// 1.9 (nx - ny); the launcher of the body picks the one with the larger advance, so a half-wave never
-// walks along an iso-bank direction (a 96-float stride made 64 % of all LDS cycles bank conflicts
-// for near-horizontal lines, profiles/r01_pmc_lds.txt).
+// 1.9 (nx - ny); the kernel picks the one with the larger advance, so a half-wave never walks along an
+// iso-bank direction.  (Measured: bank conflicts are still ~55 % of LDS-active cycles -- 32 lanes
+// spread over ~60 texel rows/columns cannot all land on distinct banks of a linear layout; see
+// DESIGN.md 8.)
 template <bool DERIV, int TILE_S>
 __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared& sh)
 {
@@ -122,8 +123,8 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int ix = blockIdx.x * RT_A + (tid >> 5);
-    const int iy = blockIdx.y * RT_T + (tid & 31);
+    const int ix = blockIdx.x * RT_A + (tid / RT_T);
+    const int iy = blockIdx.y * RT_T + (tid % RT_T);
     const float* __restrict__ img = p.images + (int64_t)blockIdx.z * p.image_stride;
     const int W = p.n_u, H = p.n_v;
     const float n_u = (float)W, n_v = (float)H;
