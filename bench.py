@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--bins", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
                     help="CPU baseline evaluates all pairs among every k-th view")
     return ap.parse_args()
@@ -66,10 +70,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     n, S, B = args.views, args.size, args.bins
     pixel_mm = 0.308 * 1024.0 / S
@@ -97,8 +106,13 @@ def main():
         del keep, imgs
     ms_per_radon = radon_ms / max(hi - lo, 1)
     if world > 1:
-        gathered = torch.empty_like(slabs_all)
-        dist.all_gather_into_tensor(gathered, local.contiguous())
+        if args.backend == "nccl":
+            gathered = torch.empty_like(slabs_all)
+            dist.all_gather_into_tensor(gathered, local.contiguous())
+        else:  # gloo rehearsal: through host memory
+            parts = [torch.empty(local.shape, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, local.cpu())
+            gathered = torch.cat(parts).to(dev)
         slabs_all = gathered
     dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
     metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
@@ -138,7 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        e = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        e = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = e.item()
     pair_ms /= max(args.steps, 1)

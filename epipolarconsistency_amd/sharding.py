@@ -26,6 +26,10 @@ def allreduce_mean(partial_sum_tensor, n_pairs, group=None):
     returns the mean over all pairs as a Python float."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if partial_sum_tensor.is_cuda and dist.get_backend(group) == "gloo":
+            host = partial_sum_tensor.cpu()  # gloo rehearsal of the GPU path: reduce through host memory
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            return float(host.item()) / n_pairs
         dist.all_reduce(partial_sum_tensor, op=dist.ReduceOp.SUM, group=group)
     return float(partial_sum_tensor.item()) / n_pairs
 
