@@ -152,6 +152,17 @@ __device__ __forceinline__ float atan_over_pi(float t)
     return pz * t;
 }
 
+// Same for |t| <= 0.3 (lines within 16.7 deg of the image x axis): degree 3 is enough (max error 1.3e-8).
+__device__ __forceinline__ float atan_over_pi_small(float t)
+{
+    const float z = t * t;
+    float pz = -3.970951959e-02f;
+    pz = fmaf(pz, z, 6.334859133e-02f);
+    pz = fmaf(pz, z, -1.060977504e-01f);
+    pz = fmaf(pz, z, 3.183098733e-01f);
+    return pz * t;
+}
+
 // One line (l0, l1, l2) -> signed bilinear sample of the dtr.
 // Instruction selection follows measured gfx950 issue costs (scripts/micro/valu_rate.hip):
 // v_fma/v_add/v_xor 2 cycles per wave64, v_floor/v_fract/v_cvt 4, v_cmp+v_cndmask 8 per pair,
@@ -171,10 +182,14 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     // r = angle(l0, l1) / pi in [0, 1] as cq + u, cq in {0, 1/2, 1}, |u| <= 1/4 (l1 >= 0 here).
     float cq, u;
     const float ax = fabsf(l0);
-    if (__builtin_amdgcn_ballot_w64(l1 < ax) == 0) {
-        // every lane of the wave has a line within 45 deg of the image x axis (normal closer to y):
-        // r = 1/2 - atan(l0 / l1) / pi.  This is the only case a circular C-arm scan produces.
+    if (__builtin_amdgcn_ballot_w64(ax > 0.3f * l1) == 0) {
+        // every lane of the wave has a line within 16.7 deg of the image x axis (normal close to y):
+        // r = 1/2 - atan(l0 / l1) / pi with the short polynomial.  This is the case almost all pairs of a
+        // circular C-arm scan are in.
         cq = 0.5f;
+        u = -atan_over_pi_small(l0 * __builtin_amdgcn_rcpf(l1));
+    } else if (__builtin_amdgcn_ballot_w64(l1 < ax) == 0) {
+        cq = 0.5f;  // within 45 deg
         u = -atan_over_pi(l0 * __builtin_amdgcn_rcpf(l1));
     } else {
         const bool steep = l1 >= ax;
