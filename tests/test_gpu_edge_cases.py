@@ -1,0 +1,169 @@
+"""Edge cases of the hot path on the GPU (through the C ABI) against the oracle: smallest problems,
+degenerate inputs, the non-derivative variant, error behaviour."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+def test_two_and_three_views(gpu_ctx, oracle_mod, small_scan):
+    import epipolarconsistency_amd as E
+    s = small_scan
+    for views in ([0, 5], [1, 4, 7]):
+        Ps = [s["Ps"][v] for v in views]
+        host = [s["dtrs"][v] for v in views]
+        dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in host]
+        m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+        want = oracle_mod.evaluate_all(Ps, host, s["n_u"], s["n_v"])
+        assert _rel(m.evaluate(), want["mean"]) < 1e-5
+
+
+def test_single_view_is_rejected(gpu_ctx, small_scan):
+    """The reference divides 0/0 for n < 2 (...RadonIntermediate.cpp:224); the ABI reports an error."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    d = E.RadonIntermediate.from_host(gpu_ctx, s["dtrs"][0], s["n_u"], s["n_v"])
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"][:1], [d])
+    with pytest.raises(E.EccError):
+        m.evaluate()
+
+
+@pytest.mark.parametrize("shape,bins", [((8, 8), (5, 7)), ((3, 200), (64, 9)), ((130, 2), (7, 65))])
+def test_tiny_and_ragged_radon(gpu_ctx, oracle_mod, shape, bins):
+    import epipolarconsistency_amd as E
+    rng = np.random.default_rng(2)
+    img = rng.uniform(0, 9, size=shape).astype(np.float32)
+    for filt in (0, 2):
+        want = oracle_mod.radon(img, bins[0], bins[1], filter=filt)
+        got = E.RadonIntermediate.compute(gpu_ctx, img, bins[0], bins[1], filter=filt).readback()
+        assert np.array_equal(got, want)
+
+
+def test_zero_image_and_constant_image(gpu_ctx, oracle_mod):
+    import epipolarconsistency_amd as E
+    z = np.zeros((40, 56), np.float32)
+    assert np.all(E.RadonIntermediate.compute(gpu_ctx, z, 32, 24).readback() == 0)
+    c = np.full((40, 56), 2.5, np.float32)
+    assert np.array_equal(E.RadonIntermediate.compute(gpu_ctx, c, 32, 24).readback(), oracle_mod.radon(c, 32, 24))
+
+
+def test_batch_equals_single(gpu_ctx, small_scan):
+    import epipolarconsistency_amd as E
+    s = small_scan
+    batch = E.RadonIntermediate.compute_batch(gpu_ctx, s["imgs"][:3], 48, 40)
+    for k in range(3):
+        single = E.RadonIntermediate.compute(gpu_ctx, s["imgs"][k], 48, 40)
+        assert np.array_equal(batch[k].readback(), single.readback())
+
+
+def test_non_derivative_pairs(gpu_ctx, oracle_mod, small_scan):
+    """Filter::None dtrs: the (alpha + pi, -t) fold keeps the sign (ref: ...RadonIntermediate.cu:80-83)."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    host = [oracle_mod.radon(im, 64, 64, filter=2) for im in s["imgs"][:5]]
+    dtrs = E.RadonIntermediate.compute_batch(gpu_ctx, s["imgs"][:5], 64, 64, filter=E.FILTER_NONE)
+    assert not dtrs[0].isDerivative()
+    for d, h in zip(dtrs, host):
+        assert np.array_equal(d.readback(), h)
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"][:5], dtrs)
+    want = oracle_mod.evaluate_all(s["Ps"][:5], host, s["n_u"], s["n_v"], is_derivative=False)
+    assert _rel(m.evaluate(), want["mean"]) < 1e-5
+
+
+def test_identical_views_in_index_list(gpu_ctx, oracle_mod, small_scan):
+    """(P, P) tuples hit the reference's same-pointer guard (EpipolarConsistencyCommon.hxx:108-113): value 0."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    idx = np.array([[3, 3, 3, 3], [0, 1, 0, 1], [0, 1, 0, 1]], np.int32)
+    out = np.full(3, -1, np.float32)
+    m.evaluate(idx, out)
+    want = oracle_mod.evaluate_pairs(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], idx)
+    assert out[0] == 0.0 and want["pairs"][0] == 0.0
+    assert out[1] == out[2] and _rel(out[1], want["pairs"][1]) < 2e-4
+
+
+def test_wide_kappa_range_general_branch(gpu_ctx, oracle_mod, small_scan):
+    """A huge object radius makes kappa_max = pi/2: epipolar lines of every orientation, so the general
+    (non-steep) branches of the angle computation and the texture clamp are exercised."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    m.setObjectRadius(5000.0)
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], object_radius_mm=5000.0)
+    total, vals = m.evaluate_range(0, 28, want_pairs=True)
+    assert _rel(total / 28, want["mean"]) < 1e-5
+    np.testing.assert_allclose(vals, want["pairs"], rtol=2e-4)
+
+
+def test_rotated_detector_geometry(gpu_ctx, oracle_mod, small_scan):
+    """In-plane detector rotations of 30..150 deg: epipolar lines far from horizontal."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    Ps = []
+    for k, P in enumerate(s["Ps"]):
+        a = np.deg2rad(30.0 + 17.0 * k)
+        c, sn = np.cos(a), np.sin(a)
+        T = np.array([[1, 0, 64.0], [0, 1, 64.0], [0, 0, 1]]) @ np.array([[c, -sn, 0], [sn, c, 0], [0, 0, 1]]) @ \
+            np.array([[1, 0, -64.0], [0, 1, -64.0], [0, 0, 1]])
+        Ps.append(T @ P)
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    want = oracle_mod.evaluate_all(Ps, s["dtrs"], s["n_u"], s["n_v"])
+    total, vals = m.evaluate_range(0, 28, want_pairs=True)
+    assert _rel(total / 28, want["mean"]) < 1e-5
+    np.testing.assert_allclose(vals, want["pairs"], rtol=2e-4)
+
+
+def test_error_behaviour(gpu_ctx, small_scan):
+    import epipolarconsistency_amd as E
+    s = small_scan
+    img = s["imgs"][0]
+    with pytest.raises(E.EccError) as ei:
+        E.RadonIntermediate.compute(gpu_ctx, img, 32, 32, filter=E.FILTER_RAMP)
+    assert ei.value.code == 5
+    with pytest.raises(E.EccError):
+        E.RadonIntermediate.compute(gpu_ctx, img, 0, 32)
+    a = E.RadonIntermediate.compute(gpu_ctx, img, 32, 32)
+    b = E.RadonIntermediate.compute(gpu_ctx, img, 40, 32)
+    with pytest.raises(E.EccError):
+        E.MetricRadonIntermediate(gpu_ctx, s["Ps"][:2], [a, b])  # mixed bin counts are rejected
+    m = E.MetricRadonIntermediate(gpu_ctx, None, [a, a])
+    with pytest.raises(E.EccError):
+        m.evaluate()  # projection matrices not set
+    m.setProjectionMatrices(s["Ps"][:2])
+    m.useCorrelation(True)
+    with pytest.raises(E.EccError) as ei:
+        m.evaluate()
+    assert ei.value.code == 5
+    m.useCorrelation(False)
+    assert np.isfinite(m.evaluate())
+    with pytest.raises(E.EccError):
+        m.evaluate_range(0, 2)  # only one pair exists
+    m3 = E.MetricRadonIntermediate(gpu_ctx, s["Ps"][:3], [a, a])
+    with pytest.raises(E.EccError):
+        m3.evaluate()  # fewer dtrs than projection matrices
+
+
+def test_reevaluate_after_changing_one_view(gpu_ctx, oracle_mod, small_scan):
+    """The optimiser loop (ref: Gui/SingleImageMotion.h:84-90): overwrite one matrix, set all, evaluate."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import geometry
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    packed = E.pack_projection_matrices(s["Ps"])
+    for step in range(3):
+        T = geometry.rigid_transform(tx=0.7 * step, ry=0.01 * step)
+        Ps = list(s["Ps"])
+        Ps[3] = s["Ps"][3] @ T
+        packed[3] = Ps[3].T.reshape(12)
+        m.setProjectionMatrices(packed)
+        want = oracle_mod.evaluate_all(Ps, s["dtrs"], s["n_u"], s["n_v"])
+        assert _rel(m.evaluate(), want["mean"]) < 1e-5
