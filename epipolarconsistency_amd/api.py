@@ -125,6 +125,21 @@ class RadonIntermediate:
         return cls(ctx, h)
 
     @classmethod
+    def load(cls, ctx, path):
+        """ref: RadonIntermediate(const std::string path): a dtr NRRD written by the reference's tools
+        (or by save()); returns (RadonIntermediate, info) where info carries the optional
+        "Original Image/Projection Matrix"."""
+        from . import nrrd
+        data, info = nrrd.read_dtr(path)
+        return cls.from_host(ctx, data, info["n_u"], info["n_v"], info["filter"]), info
+
+    def save(self, path, projection_matrix=None):
+        """ref: readback() + NRRD save with writePropertiesToMeta (RadonIntermediate.cpp:95-103,148-163)."""
+        from . import nrrd
+        nrrd.write_dtr(path, self.readback(), self.getOriginalImageSize(0), self.getOriginalImageSize(1),
+                       self.getFilter(), projection_matrix)
+
+    @classmethod
     def wrap_device(cls, ctx, slab, n_alpha, n_t, n_u, n_v, filter=FILTER_DERIVATIVE):
         """Adopt a torch tensor that already holds a dtr in the private layout (e.g. after an all-gather)."""
         h = C.c_void_p()

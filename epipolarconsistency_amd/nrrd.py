@@ -84,3 +84,77 @@ def parse_matrix(text):
 def format_matrix(M):
     M = np.asarray(M, dtype=np.float64)
     return "[" + "; ".join(" ".join("%.12g" % x for x in row) for row in M) + "]"
+
+
+# ---------------------------------------------------------------------------------------------------
+# Radon-intermediate files and projection tables exchanged with the reference's tools
+# ---------------------------------------------------------------------------------------------------
+
+FILTER_NAMES = {0: "Derivative", 1: "Ramp", 2: "None"}
+
+
+def write_dtr(path, data, n_u, n_v, filter=0, projection_matrix=None):
+    """dtr as the reference stores it: n_t x n_alpha float32 (alpha fastest) with the meta keys of
+    RadonIntermediate::writePropertiesToMeta (ref: code/LibEpipolarConsistency/RadonIntermediate.cpp:95-103)
+    and, optionally, "Original Image/Projection Matrix" (ref: Gui/ComputeRadonIntermediate.hxx:79)."""
+    data = np.ascontiguousarray(data, np.float32)
+    n_t, n_alpha = data.shape
+    meta = {
+        "Bin Size/Angle": repr(float(np.pi / n_alpha)),
+        "Bin Size/Distance": repr(float(np.sqrt(float(n_u) ** 2 + float(n_v) ** 2) / n_t)),
+        "Original Image/Width": str(int(n_u)),
+        "Original Image/Height": str(int(n_v)),
+        "Filter": FILTER_NAMES[int(filter)],
+    }
+    if projection_matrix is not None:
+        meta["Original Image/Projection Matrix"] = format_matrix(projection_matrix)
+    write(path, data, meta=meta)
+
+
+def read_dtr(path):
+    """Inverse of write_dtr, ref: RadonIntermediate(const std::string path) + readPropertiesFromMeta
+    (RadonIntermediate.cpp:47-67,82-93): unknown/missing "Filter" means None, like the reference."""
+    data, _, meta = read(path)
+    if data.ndim != 2:
+        raise ValueError("%s: a Radon intermediate is a 2-D image" % path)
+    flt = {"Derivative": 0, "Ramp": 1}.get(meta.get("Filter", ""), 2)
+    info = dict(n_u=int(meta.get("Original Image/Width", 0)), n_v=int(meta.get("Original Image/Height", 0)),
+                filter=flt, bin_size_angle=float(meta.get("Bin Size/Angle", 0) or 0),
+                bin_size_distance=float(meta.get("Bin Size/Distance", 0) or 0))
+    if "Original Image/Projection Matrix" in meta:
+        info["projection_matrix"] = parse_matrix(meta["Original Image/Projection Matrix"])
+    return np.ascontiguousarray(data, np.float32), info
+
+
+def write_ompl(path, Ps, comment="", spacing=0.0, detector_size_px=None):
+    """One projection matrix per line ("[a b c d; e f g h; i j k l]"), '#' comments, optional "#> key="value""
+    attributes (ref: code/HeaderOnly/Utils/Projtable.hxx:168-220, saveProjectionsOneMatrixPerLine)."""
+    with open(path, "w") as f:
+        if comment:
+            f.write("#%s\n" % comment)
+        if spacing:
+            line = '#> spacing="%s"' % repr(float(spacing))
+            if detector_size_px is not None:
+                line += ' detector_size_px="[%d %d]"' % tuple(detector_size_px)
+            f.write(line + "\n")
+        for P in Ps:
+            f.write(format_matrix(np.asarray(P, np.float64).reshape(3, 4)) + "\n")
+
+
+def read_ompl(path):
+    """Returns (list of 3x4 arrays, meta dict), ref: loadProjectionsOneMatrixPerLine (Projtable.hxx:168-190)."""
+    Ps, meta = [], {}
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            if line[0] == "#":
+                if len(line) > 1 and line[1] == ">":
+                    for k, v in re.findall(r'(\S+?)="([^"]*)"', line[2:]):
+                        meta[k] = v
+                elif "comment" not in meta:
+                    meta["comment"] = line[1:]
+                continue
+            Ps.append(parse_matrix(line))
+    return Ps, meta

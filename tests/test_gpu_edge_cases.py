@@ -167,3 +167,16 @@ def test_reevaluate_after_changing_one_view(gpu_ctx, oracle_mod, small_scan):
         m.setProjectionMatrices(packed)
         want = oracle_mod.evaluate_all(Ps, s["dtrs"], s["n_u"], s["n_v"])
         assert _rel(m.evaluate(), want["mean"]) < 1e-5
+
+
+def test_dtr_save_load(gpu_ctx, small_scan, tmp_path):
+    import os
+    import epipolarconsistency_amd as E
+    s = small_scan
+    d = E.RadonIntermediate.compute(gpu_ctx, s["imgs"][2], 48, 40)
+    p = os.path.join(tmp_path, "d.nrrd")
+    d.save(p, projection_matrix=s["Ps"][2])
+    d2, info = E.RadonIntermediate.load(gpu_ctx, p)
+    assert np.array_equal(d2.readback(), d.readback()) and d2.isDerivative()
+    assert d2.getOriginalImageSize(0) == s["n_u"] and d2.getRadonBinNumber(1) == 40
+    assert np.allclose(info["projection_matrix"], s["Ps"][2], rtol=1e-11)

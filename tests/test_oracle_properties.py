@@ -114,3 +114,26 @@ def test_reads_reference_example_data():
     assert abs(float(img.max()) - 233.07385) < 1e-3 and float(img.min()) == 0.0
     P = nrrd.parse_matrix(meta["Projection Matrix"])
     assert P.shape == (3, 4) and P[2, 3] == 744.3
+
+
+def test_dtr_file_and_projection_table_roundtrip(tmp_path):
+    """dtr NRRD with the reference's meta keys and the one-matrix-per-line .ompl table."""
+    from epipolarconsistency_amd import nrrd, synthetic
+    rng = np.random.default_rng(4)
+    d = rng.normal(size=(40, 56)).astype(np.float32)
+    Ps = synthetic.short_scan(5, 320, 240, 1.0)
+    p = os.path.join(tmp_path, "dtr000.nrrd")
+    nrrd.write_dtr(p, d, 320, 240, filter=0, projection_matrix=Ps[2])
+    raw = open(p, "rb").read()
+    for key in (b"Bin Size/Angle:=", b"Bin Size/Distance:=", b"Original Image/Width:=320", b"Original Image/Height:=240",
+                b"Filter:=Derivative", b"Original Image/Projection Matrix:=["):
+        assert key in raw
+    d2, info = nrrd.read_dtr(p)
+    assert np.array_equal(d, d2) and info["n_u"] == 320 and info["n_v"] == 240 and info["filter"] == 0
+    assert abs(info["bin_size_angle"] - np.pi / 56) < 1e-15 and abs(info["bin_size_distance"] - 400.0 / 40) < 1e-12
+    assert np.allclose(info["projection_matrix"], Ps[2], rtol=1e-11)
+    q = os.path.join(tmp_path, "scan.ompl")
+    nrrd.write_ompl(q, Ps, comment=" synthetic short scan", spacing=0.308, detector_size_px=(320, 240))
+    Ps2, meta = nrrd.read_ompl(q)
+    assert len(Ps2) == 5 and all(np.allclose(a, b, rtol=1e-11) for a, b in zip(Ps, Ps2))
+    assert meta["spacing"] == "0.308" and meta["comment"].strip() == "synthetic short scan"
