@@ -620,7 +620,6 @@ namespace {
 
 int fill_pair_params(ecc_metric* m, EccPairParams* p)
 {
-    if (m->use_corr) return fail(ECC_ERR_UNSUPPORTED, "useCorrelation(true) is not implemented");
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     double radius = 0;
     ecc_metric_get_object_radius(m, &radius);
@@ -644,6 +643,7 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p)
     int max_num_samples = p->dkappa_user <= 0.0f ? (int)image_diagonal : (int)(Pi * 0.5f / p->dkappa_user);
     p->k_limit = (max_num_samples + 255) / 256 * 256;
     p->is_derivative = m->is_derivative ? 1 : 0;
+    p->use_corr = m->use_corr ? 1 : 0;
     return ECC_OK;
 }
 

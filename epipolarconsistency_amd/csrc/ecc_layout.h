@@ -60,6 +60,7 @@ struct EccPairParams {
     float dkappa_user;         // <=0: automatic
     int k_limit;               // launch bound on the kappa index (ref: ...RadonIntermediate.cu:348-358)
     int is_derivative;
+    int use_corr;              // MetricRadonIntermediate::useCorrelation (ref: ...RadonIntermediate.cu:116-149)
 };
 
 #endif

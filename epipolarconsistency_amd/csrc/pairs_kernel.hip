@@ -225,7 +225,7 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ m) : v;
 }
 
-template <bool DERIV>
+template <bool DERIV, bool CORR>
 __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     const float dkappa = K1[6], kappa_max = K1[7], w06 = K0[6];
 
     double acc = 0.0;
+    double mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;  // CORR: sums of x*x, y*y, x*y (x, y alone are not used by cc())
     for (int k = lane; k < p.k_limit; k += 64) {
         const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
         if (kappa >= kappa_max) break;
@@ -294,13 +295,35 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
         const float v1p = sample_line<DERIV>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
         const float v0m = sample_line<DERIV>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
         const float v1m = sample_line<DERIV>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
-        const float vp = v0p - v1p, vm = v0m - v1m;
-        const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
-        acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
+        if (!CORR) {
+            const float vp = v0p - v1p, vm = v0m - v1m;
+            const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
+            acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
+        } else {
+            // ref: ...RadonIntermediate.cu:116-149; the launcher passes kappa_max/kappa as "1/n" (:211,274)
+            const float one_over_n = kappa_max / kappa;
+            mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
+            mom3 += (double)(one_over_n * (v1p * v1p + v1m * v1m));
+            mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    float val;
+    if (!CORR) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        val = (float)acc;
+    } else {
+        for (int off = 32; off > 0; off >>= 1) {
+            mom2 += __shfl_down(mom2, off);
+            mom3 += __shfl_down(mom3, off);
+            mom4 += __shfl_down(mom4, off);
+        }
+        // host epilogue of the reference: cc = xy / (sqrt(xx) sqrt(yy)), cost = (1 - cc) * weight(= 1)
+        // (ref: ...RadonIntermediate.cpp:127-131,199-210)
+        const float xx = (float)mom2, yy = (float)mom3, xy = (float)mom4;
+        const float corr = (float)((double)xy / (sqrt((double)xx) * sqrt((double)yy)));
+        val = (1.0f - corr) * 1.0f;
+    }
     if (lane == 0) {
-        const float val = (float)acc;
         if (p.pair_values) p.pair_values[local] = val;
         if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
     }
@@ -344,10 +367,17 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
     long long nblk = (p->count + 3) / 4;
     long long per_xcd = (nblk + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
-    if (p->is_derivative)
-        hipLaunchKernelGGL(pairs_kernel<true>, grid, block, 0, stream, *p);
-    else
-        hipLaunchKernelGGL(pairs_kernel<false>, grid, block, 0, stream, *p);
+    if (p->use_corr) {
+        if (p->is_derivative)
+            hipLaunchKernelGGL((pairs_kernel<true, true>), grid, block, 0, stream, *p);
+        else
+            hipLaunchKernelGGL((pairs_kernel<false, true>), grid, block, 0, stream, *p);
+    } else {
+        if (p->is_derivative)
+            hipLaunchKernelGGL((pairs_kernel<true, false>), grid, block, 0, stream, *p);
+        else
+            hipLaunchKernelGGL((pairs_kernel<false, false>), grid, block, 0, stream, *p);
+    }
     return hipGetLastError();
 }
 

@@ -126,7 +126,9 @@ int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs);
 
 /* ref: Metric::setObjectRadius / setEpipolarPlaneStep / MetricRadonIntermediate::useCorrelation
  * (EpipolarConsistency.cpp:70-90, …RadonIntermediate.cpp:80-85).  0 = automatic for both scalars.
- * use_corr != 0 is not implemented in this round (ECC_ERR_UNSUPPORTED at evaluate). */
+ * use_corr != 0: pair value = 1 - un-centred correlation of the two redundant signals, with the
+ * reference's provisional per-sample weight kappa_max/kappa (ref: ...RadonIntermediate.cu:116-149,274;
+ * .cpp:127-131); the reference has no test for it (parity unpinned). */
 int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa, int use_corr);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */

@@ -220,3 +220,11 @@ def set_variant(v):
     L = lib()
     L.eccor_set_variant.argtypes = [C.c_int]
     L.eccor_set_variant(int(v))
+
+
+def set_use_corr(v):
+    """MetricRadonIntermediate::useCorrelation: pair value = 1 - un-centred correlation of the two
+    redundant signals (ref: ...RadonIntermediate.cu:116-149, .cpp:127-131,199-210).  Parity unpinned."""
+    L = lib()
+    L.eccor_set_use_corr.argtypes = [C.c_int]
+    L.eccor_set_use_corr(1 if v else 0)

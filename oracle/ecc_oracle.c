@@ -45,6 +45,9 @@
 static int g_variant = 0;
 ECCOR_API void eccor_set_variant(int v) { g_variant = v; }
 
+static int g_use_corr = 0;
+ECCOR_API void eccor_set_use_corr(int v) { g_use_corr = v; }
+
 static float or_sinf(float x) { return g_variant == 2 ? sinf(x) : (float)sin((double)x); }
 static float or_cosf(float x) { return g_variant == 2 ? cosf(x) : (float)cos((double)x); }
 static float or_atan2f(float y, float x) { return g_variant == 2 ? atan2f(y, x) : (float)atan2((double)y, (double)x); }
@@ -515,6 +518,7 @@ typedef struct {
     float step_alpha, step_t;
     float object_radius_mm, dkappa;
     int is_derivative;
+    int use_corr;
 } eccor_params;
 
 /* One pair: K01 (launcher arguments of ref: ...RadonIntermediate.cu:320-338) then the kappa loop
@@ -529,6 +533,7 @@ static float or_pair(const eccor_params *p, const float *C0, const float *C1, co
     float range_t = p->n_t * p->step_t;
     float dkappa, kappa_max;
     double acc = 0.0;
+    double mom[5] = {0, 0, 0, 0, 0}; /* x, y, xx, yy, xy (use_corr) */
     int k, k_limit;
     const float Pi = 3.14159265359f;
     eccor_computeK01(p->n_u * 0.5f, p->n_v * 0.5f, C0, C1, P0invT, P1invT, p->object_radius_mm,
@@ -557,6 +562,23 @@ static float or_pair(const eccor_params *p, const float *C0, const float *C1, co
         }
         x0 = or_cosf(kappa);
         x1 = or_sinf(kappa);
+        if (p->use_corr) {
+            /* ref: ...RadonIntermediate.cu:116-149 (consistencyForPlusMinusKappa_XCORR); the "1/n" the
+             * launcher passes is kappa_max/kappa (:211,274) -- kept as written. */
+            float one_over_n = kappa_max / kappa;
+            float xp = or_redundancy(K0, dtr0, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
+            float yp = or_redundancy(K1, dtr1, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
+            float xm, ym;
+            x0 *= -1;
+            xm = or_redundancy(K0, dtr0, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
+            ym = or_redundancy(K1, dtr1, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
+            mom[0] += (double)(one_over_n * (xp + xm));
+            mom[1] += (double)(one_over_n * (yp + ym));
+            mom[2] += (double)(one_over_n * (xp * xp + xm * xm));
+            mom[3] += (double)(one_over_n * (yp * yp + ym * ym));
+            mom[4] += (double)(one_over_n * (xp * yp + xm * ym));
+            continue;
+        }
         vp = or_redundancy(K0, dtr0, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative) -
              or_redundancy(K1, dtr1, p->n_alpha, p->n_t, range_t, x0, x1, p->is_derivative);
         x0 *= -1;
@@ -566,6 +588,12 @@ static float or_pair(const eccor_params *p, const float *C0, const float *C1, co
         acc += (double)(consistency * dkappa);
     }
     if (n_kappa) *n_kappa += k;
+    if (p->use_corr) {
+        /* host epilogue, ref: ...RadonIntermediate.cpp:127-131 (cc, un-centred) and :199-210: cost = (1 - cc) * 1 */
+        float xx = (float)mom[2], yy = (float)mom[3], xy = (float)mom[4];
+        float corr = (float)((double)xy / (sqrt((double)xx) * sqrt((double)yy)));
+        return (1.0f - corr) * 1.0f;
+    }
     return (float)acc;
 }
 
@@ -594,6 +622,7 @@ ECCOR_API double eccor_evaluate_all(int n, const double *Ps, const float *const 
                                                        : eccor_object_radius(Ps, n_u, n_v));
     p.dkappa = (float)dkappa;
     p.is_derivative = is_derivative;
+    p.use_corr = g_use_corr;
     for (v = 0; v < n; v++) {
         eccor_pinvT(Ps + 12 * v, PinvTs + 12 * v);
         eccor_source_position(Ps + 12 * v, Cs + 4 * v);
@@ -641,6 +670,7 @@ ECCOR_API double eccor_evaluate_pairs(int n_P, const double *Ps, int n_dtr, cons
                                                        : eccor_object_radius(Ps, n_u, n_v));
     p.dkappa = (float)dkappa;
     p.is_derivative = is_derivative;
+    p.use_corr = g_use_corr;
     for (v = 0; v < n_P; v++) {
         eccor_pinvT(Ps + 12 * v, PinvTs + 12 * v);
         eccor_source_position(Ps + 12 * v, Cs + 4 * v);

@@ -138,11 +138,6 @@ def test_error_behaviour(gpu_ctx, small_scan):
     with pytest.raises(E.EccError):
         m.evaluate()  # projection matrices not set
     m.setProjectionMatrices(s["Ps"][:2])
-    m.useCorrelation(True)
-    with pytest.raises(E.EccError) as ei:
-        m.evaluate()
-    assert ei.value.code == 5
-    m.useCorrelation(False)
     assert np.isfinite(m.evaluate())
     with pytest.raises(E.EccError):
         m.evaluate_range(0, 2)  # only one pair exists
@@ -180,3 +175,31 @@ def test_dtr_save_load(gpu_ctx, small_scan, tmp_path):
     assert np.array_equal(d2.readback(), d.readback()) and d2.isDerivative()
     assert d2.getOriginalImageSize(0) == s["n_u"] and d2.getRadonBinNumber(1) == 40
     assert np.allclose(info["projection_matrix"], s["Ps"][2], rtol=1e-11)
+
+
+def test_use_correlation(gpu_ctx, oracle_mod, small_scan):
+    """useCorrelation(true): 1 - cc per pair (provisional formula, parity unpinned).  1 - cc is
+    a cancellation of two numbers near 1, so it is compared absolutely."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    m.useCorrelation(True)
+    oracle_mod.set_use_corr(1)
+    try:
+        want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+        idx = np.array([[0, 4, 0, 4], [6, 2, 6, 2]], np.int32)
+        want_idx = oracle_mod.evaluate_pairs(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], idx)
+    finally:
+        oracle_mod.set_use_corr(0)
+    cost = np.zeros((8, 8), np.float32)
+    mean = m.evaluate(cost)
+    assert abs(mean - want["mean"]) < 2e-6 and 0 < mean < 0.1
+    for ij in range(28):
+        i, j = E.get_ij(ij, 8)
+        assert abs(cost[j, i] - want["pairs"][ij]) < 2e-6
+    out = np.zeros(2, np.float32)
+    assert abs(m.evaluate(idx, out) - want_idx["mean"]) < 2e-6
+    m.useCorrelation(False)
+    ssd = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+    assert abs(m.evaluate() - ssd["mean"]) < 1e-5 * ssd["mean"]
