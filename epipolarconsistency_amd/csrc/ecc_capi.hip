@@ -22,6 +22,10 @@
 #include "ecc_layout.h"
 
 extern "C" hipError_t ecc_launch_radon(const EccRadonParams* p, int derivative, hipStream_t stream);
+extern "C" hipError_t ecc_launch_dtr_border(float* slabs, int64_t slab_stride, int n_img, int n_alpha, int n_t,
+                                            int pitch, hipStream_t stream);
+extern "C" hipError_t ecc_launch_ramp(float* slabs, int64_t slab_stride, int n_img, int n_alpha, int n_t, int pitch,
+                                      const double* h2_d, hipStream_t stream);
 extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
@@ -76,6 +80,9 @@ struct ecc_ctx {
     // trig table cache for the Radon kernel
     float* trig_d = nullptr;
     int trig_n_alpha = 0;
+    // circular-convolution kernel of Filter::Ramp (2*n_t doubles), cached per n_t
+    double* ramp_d = nullptr;
+    int ramp_n_t = 0;
 };
 
 struct ecc_dtr {
@@ -151,6 +158,37 @@ int ensure_trig(ecc_ctx* ctx, int n_alpha)
     return ECC_OK;
 }
 
+// Filter::Ramp as a circular convolution: h2[m] = h[m mod n_t], h[m] = sum_k w_k cos(2 pi k m / n_t),
+// w_k = (float)min(k, n_t-k) * scale with the reference's float scale -0.5f/(n_t*n_theta)
+// (ref: RadonIntermediate.cu:173-183,219); binary64, same expressions as oracle/ecc_oracle.c.
+int ensure_ramp(ecc_ctx* ctx, int n_t)
+{
+    if (ctx->ramp_d && ctx->ramp_n_t == n_t) return ECC_OK;
+    if (ctx->ramp_d) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipFree(ctx->ramp_d));
+        ctx->ramp_d = nullptr;
+    }
+    const int n_theta = n_t / 2 + 1;
+    const float scale = -0.5f / (n_t * n_theta);
+    std::vector<double> c((size_t)n_t), h2(2 * (size_t)n_t);
+    for (int r = 0; r < n_t; ++r) c[r] = std::cos(6.283185307179586476925286766559 * (double)r / (double)n_t);
+    for (int m = 0; m < n_t; ++m) {
+        double acc = 0.0;
+        for (int k = 0; k < n_t; ++k) {
+            const int kk = k <= n_t - k ? k : n_t - k;
+            const float w = kk * scale;
+            acc += (double)w * c[((long long)k * m) % n_t];
+        }
+        h2[m] = h2[(size_t)m + n_t] = acc;
+    }
+    HIP_TRY(hipMalloc((void**)&ctx->ramp_d, h2.size() * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(ctx->ramp_d, h2.data(), h2.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // h2 goes out of scope
+    ctx->ramp_n_t = n_t;
+    return ECC_OK;
+}
+
 template <class T>
 int ensure_capacity(T** ptr, int64_t* cap, int64_t need, hipStream_t stream)
 {
@@ -171,6 +209,10 @@ int radon_launch(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, i
 {
     int rc = ensure_trig(ctx, n_alpha);
     if (rc) return rc;
+    if (filter == ECC_FILTER_RAMP) {
+        rc = ensure_ramp(ctx, n_t);
+        if (rc) return rc;
+    }
     EccRadonParams p;
     p.images = images_d;
     p.out = slabs;
@@ -187,6 +229,11 @@ int radon_launch(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, i
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     // gridDim.z is limited to 65535; batches are far below that.
     HIP_TRY(ecc_launch_radon(&p, filter == ECC_FILTER_DERIVATIVE ? 1 : 0, ctx->stream));
+    if (filter == ECC_FILTER_RAMP) {
+        // ref: RadonIntermediate.cu:166-167 (apply1DRampFilter after the plain line integrals)
+        HIP_TRY(ecc_launch_ramp(slabs, slab_stride, n, n_alpha, n_t, p.pitch, ctx->ramp_d, ctx->stream));
+        HIP_TRY(ecc_launch_dtr_border(slabs, slab_stride, n, n_alpha, n_t, p.pitch, ctx->stream));
+    }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
         ctx->ev_valid[1] = true;
@@ -203,8 +250,7 @@ int check_radon_args(ecc_ctx* ctx, const float* image, int n, int n_u, int n_v, 
         return fail(ECC_ERR_INVALID_ARGUMENT, "image size must be in [2, 16384]");
     if (n_alpha < 1 || n_t < 1 || n_alpha > 16384 || n_t > 16384)
         return fail(ECC_ERR_INVALID_ARGUMENT, "Radon bin counts must be in [1, 16384]");
-    if (filter == ECC_FILTER_RAMP) return fail(ECC_ERR_UNSUPPORTED, "Filter::Ramp is not implemented");
-    if (filter != ECC_FILTER_DERIVATIVE && filter != ECC_FILTER_NONE)
+    if (filter != ECC_FILTER_DERIVATIVE && filter != ECC_FILTER_RAMP && filter != ECC_FILTER_NONE)
         return fail(ECC_ERR_INVALID_ARGUMENT, "unknown filter");
     if (post < 0 || post > 2) return fail(ECC_ERR_INVALID_ARGUMENT, "unknown post-process");
     return ECC_OK;
@@ -266,6 +312,7 @@ ECC_EXPORT int ecc_ctx_destroy(ecc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->trig_d) (void)hipFree(ctx->trig_d);
+    if (ctx->ramp_d) (void)hipFree(ctx->ramp_d);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;

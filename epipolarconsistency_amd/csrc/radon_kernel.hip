@@ -412,6 +412,15 @@ extern "C" hipError_t ecc_launch_radon(const EccRadonParams* p, int derivative, 
     return hipGetLastError();
 }
 
+extern "C" hipError_t ecc_launch_dtr_border(float* slabs, int64_t slab_stride, int n_img, int n_alpha, int n_t,
+                                            int pitch, hipStream_t stream)
+{
+    int border = 2 * (n_t + 2) + 2 * (n_alpha + 2);
+    hipLaunchKernelGGL(dtr_border_kernel, dim3((border + 255) / 256, 1, n_img), dim3(256), 0, stream, slabs,
+                       slab_stride, n_alpha, n_t, pitch);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t ecc_launch_dtr_import(const float* src_alpha_fast, float* slab, int n_alpha, int n_t,
                                             int pitch, hipStream_t stream)
 {

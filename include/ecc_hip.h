@@ -69,7 +69,9 @@ int ecc_ctx_synchronize(ecc_ctx* ctx);
  * (ref: LibEpipolarConsistency/RadonIntermediate.cu:149-170) and the ctor
  * RadonIntermediate(ImageView<float>, size_alpha, size_t, filter, post) (ref: RadonIntermediate.cpp:17-31).
  * `image` is n_u*n_v floats on the host (image_on_device = 0) or on ctx's device (= 1).
- * ECC_FILTER_RAMP is not implemented in this round (returns ECC_ERR_UNSUPPORTED). */
+ * ECC_FILTER_RAMP: plain line integrals followed by the ramp filter along t of apply1DRampFilter
+ * (ref: RadonIntermediate.cu:173-237), evaluated as the exact circular convolution the two cuFFT
+ * calls amount to (binary64 accumulation, no FFT library). */
 int ecc_radon_compute(ecc_ctx* ctx, const float* image, int image_on_device, int n_u, int n_v,
                       int n_alpha, int n_t, int filter, int post_process, ecc_dtr** out);
 

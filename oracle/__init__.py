@@ -61,6 +61,8 @@ def _bind(L):
     L.eccor_tex2d_norm.restype = C.c_float
     L.eccor_radon.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p,
                               C.POINTER(C.c_longlong)]
+    L.eccor_ramp_kernel.argtypes = [C.c_int, _f64p]
+    L.eccor_ramp_filter.argtypes = [_f32p, C.c_int, C.c_int]
     L.eccor_radon_bins.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    _i32p, C.c_int, _f32p]
     L.eccor_evaluate_all.argtypes = [C.c_int, _f64p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -164,6 +166,21 @@ def radon(img, n_alpha, n_t, filter=0, post=0, count_fetches=False):
     nf = C.c_longlong(0)
     lib().eccor_radon(img, n_u, n_v, n_alpha, n_t, filter, post, out, C.byref(nf))
     return (out, nf.value) if count_fetches else out
+
+
+def ramp_kernel(n_t):
+    """h2 (2*n_t doubles) of the circular convolution Filter::Ramp amounts to."""
+    h2 = np.zeros(2 * n_t, np.float64)
+    lib().eccor_ramp_kernel(int(n_t), h2)
+    return h2
+
+
+def ramp_filter(dtr):
+    """dtr: (n_t, n_alpha) float32 -> ramp filtered copy (ref: RadonIntermediate.cu:186-237)."""
+    out = np.ascontiguousarray(dtr, np.float32).copy()
+    n_t, n_alpha = out.shape
+    lib().eccor_ramp_filter(out, n_alpha, n_t)
+    return out
 
 
 def radon_bins(img, n_alpha, n_t, bins, filter=0, post=0, native=False):

@@ -367,7 +367,7 @@ static void or_sort4(float *v)
             if (v[i] > v[i + 1]) { float tmp = v[i]; v[i] = v[i + 1]; v[i + 1] = tmp; }
 }
 
-/* One Radon bin.  filter: 0 Derivative, 1 Ramp (unfiltered here), 2 None; post: 0/1/2.
+/* One Radon bin.  filter: 0 Derivative, 1 Ramp (line integral; the filter follows in eccor_radon), 2 None; post: 0/1/2.
  * ref: RadonIntermediate.cu:32-143 (radonDerivative<derivative>); *fetches += #bilinear fetches. */
 static float or_radon_bin(const float *img, int W, int H, int n_alpha, int n_t, int ix, int iy,
                           int filter, int post, long long *fetches)
@@ -430,8 +430,61 @@ static float or_radon_bin(const float *img, int W, int H, int n_alpha, int n_t, 
     }
 }
 
+/* Ramp filter along t (Filter::Ramp), ref: RadonIntermediate.cu:173-237 (apply1DRampFilter).
+ * The reference runs, per angle column, an unnormalised real-to-complex FFT of the n_t values, multiplies
+ * bin k = 0..n_t/2 by the FLOAT factor k*scale, scale = -0.5f/(n_t*n_theta), n_theta = n_t/2+1
+ * (ramp_filter1D, :173-183, :219), and transforms back with an unnormalised complex-to-real FFT whose
+ * input is Hermitian-extended (bins k > n_t/2 carry the weight of n_t-k).  cuFFT's float round-off is
+ * not reproducible on a CPU; the oracle evaluates the SAME linear map exactly: a circular convolution
+ *   y[t] = sum_s x[s] * h[(t-s) mod n_t],   h[m] = sum_{k=0}^{n_t-1} w_k cos(2 pi k m / n_t),
+ *   w_k = (float)min(k, n_t-k) * scale  (the float factor of ramp_filter1D),
+ * with h and the sum over s = 0..n_t-1 (in this order, unfused) in binary64, rounded once to float.
+ * h2 receives 2*n_t doubles, h2[m] = h[m mod n_t] (so that h2[t - s + n_t] needs no modulo). */
+ECCOR_API void eccor_ramp_kernel(int n_t, double *h2)
+{
+    const int n_theta = n_t / 2 + 1;
+    const float scale = -0.5f / (n_t * n_theta);
+    double *c = (double *)malloc(sizeof(double) * (size_t)n_t);
+    int m, r;
+    for (r = 0; r < n_t; r++) c[r] = cos(6.283185307179586476925286766559 * (double)r / (double)n_t);
+#pragma omp parallel for schedule(static)
+    for (m = 0; m < n_t; m++) {
+        double acc = 0.0;
+        int k;
+        for (k = 0; k < n_t; k++) {
+            int kk = k <= n_t - k ? k : n_t - k;
+            float w = kk * scale;
+            acc += (double)w * c[((long long)k * m) % n_t]; /* argument reduced exactly */
+        }
+        h2[m] = acc;
+        h2[m + n_t] = acc;
+    }
+    free(c);
+}
+
+/* In place on an n_t x n_alpha, alpha-fast array. */
+ECCOR_API void eccor_ramp_filter(float *dtr, int n_alpha, int n_t)
+{
+    double *h2 = (double *)malloc(sizeof(double) * 2 * (size_t)n_t);
+    int ix;
+    eccor_ramp_kernel(n_t, h2);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (ix = 0; ix < n_alpha; ix++) {
+        float *x = (float *)malloc(sizeof(float) * (size_t)n_t);
+        int t, s;
+        for (t = 0; t < n_t; t++) x[t] = dtr[(size_t)t * n_alpha + ix];
+        for (t = 0; t < n_t; t++) {
+            double acc = 0.0;
+            for (s = 0; s < n_t; s++) acc += (double)x[s] * h2[t - s + n_t];
+            dtr[(size_t)t * n_alpha + ix] = (float)acc;
+        }
+        free(x);
+    }
+    free(h2);
+}
+
 /* Full Radon intermediate, output n_t rows x n_alpha columns, alpha fastest (idx = iy*n_alpha+ix).
- * ref: RadonIntermediate.cu:149-170 (computeDerivLineIntegrals), without the ramp filter. */
+ * ref: RadonIntermediate.cu:149-170 (computeDerivLineIntegrals); filter == 1 appends the ramp filter. */
 ECCOR_API void eccor_radon(const float *img, int n_u, int n_v, int n_alpha, int n_t, int filter,
                            int post, float *out, long long *fetches)
 {
@@ -447,6 +500,7 @@ ECCOR_API void eccor_radon(const float *img, int n_u, int n_v, int n_alpha, int 
         total += f;
     }
     if (fetches) *fetches = total;
+    if (filter == 1) eccor_ramp_filter(out, n_alpha, n_t);
 }
 
 /* Selected bins only (bins[k] = iy*n_alpha+ix): spot checks at full problem sizes. */

@@ -126,8 +126,8 @@ def test_error_behaviour(gpu_ctx, small_scan):
     s = small_scan
     img = s["imgs"][0]
     with pytest.raises(E.EccError) as ei:
-        E.RadonIntermediate.compute(gpu_ctx, img, 32, 32, filter=E.FILTER_RAMP)
-    assert ei.value.code == 5
+        E.RadonIntermediate.compute(gpu_ctx, img, 32, 32, filter=7)  # unknown filter
+    assert ei.value.code == 1
     with pytest.raises(E.EccError):
         E.RadonIntermediate.compute(gpu_ctx, img, 0, 32)
     a = E.RadonIntermediate.compute(gpu_ctx, img, 32, 32)
@@ -203,3 +203,32 @@ def test_use_correlation(gpu_ctx, oracle_mod, small_scan):
     m.useCorrelation(False)
     ssd = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
     assert abs(m.evaluate() - ssd["mean"]) < 1e-5 * ssd["mean"]
+
+
+@pytest.mark.parametrize("shape,bins", [((96, 128), (96, 80)), ((61, 47), (33, 29)), ((40, 40), (8, 300))])
+def test_ramp_filtered_radon(gpu_ctx, oracle_mod, shape, bins):
+    """Filter::Ramp: line integrals + ramp filter along t (ref: RadonIntermediate.cu:166-167,173-237) --
+    same binary64 circular convolution as the oracle, rounded once."""
+    import epipolarconsistency_amd as E
+    rng = np.random.default_rng(11)
+    img = rng.uniform(0, 4, size=shape).astype(np.float32)
+    want = oracle_mod.radon(img, bins[0], bins[1], filter=1)
+    d = E.RadonIntermediate.compute(gpu_ctx, img, bins[0], bins[1], filter=E.FILTER_RAMP)
+    assert d.getFilter() == E.FILTER_RAMP and not d.isDerivative()
+    got = d.readback()
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    # the filter removes the mean of every angle column
+    assert np.abs(got.astype(np.float64).sum(axis=0)).max() <= 1e-4 * np.abs(got).sum(axis=0).max()
+
+
+def test_ramp_filtered_pairs(gpu_ctx, oracle_mod, small_scan):
+    """Ramp-filtered dtrs go through the non-derivative pair kernel (no sign flip on the fold)."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    host = [oracle_mod.radon(im, 64, 64, filter=1) for im in s["imgs"][:4]]
+    dtrs = E.RadonIntermediate.compute_batch(gpu_ctx, s["imgs"][:4], 64, 64, filter=E.FILTER_RAMP)
+    for d, h in zip(dtrs, host):
+        assert np.abs(d.readback() - h).max() <= 1e-6 * np.abs(h).max()
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"][:4], dtrs)
+    want = oracle_mod.evaluate_all(s["Ps"][:4], host, s["n_u"], s["n_v"], is_derivative=False)
+    assert _rel(m.evaluate(), want["mean"]) < 1e-5

@@ -137,3 +137,22 @@ def test_dtr_file_and_projection_table_roundtrip(tmp_path):
     Ps2, meta = nrrd.read_ompl(q)
     assert len(Ps2) == 5 and all(np.allclose(a, b, rtol=1e-11) for a, b in zip(Ps, Ps2))
     assert meta["spacing"] == "0.308" and meta["comment"].strip() == "synthetic short scan"
+
+
+@pytest.mark.parametrize("n_t,n_alpha", [(96, 40), (97, 33), (2, 3), (1, 4)])
+def test_ramp_filter_is_the_fft_filter_of_the_reference(oracle_mod, n_t, n_alpha):
+    """Filter::Ramp (ref: RadonIntermediate.cu:173-237): unnormalised R2C FFT along t, bin k times the float
+    k*scale, unnormalised C2R FFT.  The oracle's circular convolution is that linear map evaluated exactly."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n_t, n_alpha)).astype(np.float32)
+    y = oracle_mod.ramp_filter(x)
+    n_theta = n_t // 2 + 1
+    scale = np.float32(-0.5) / np.float32(n_t * n_theta)
+    w = (np.arange(n_theta, dtype=np.float32) * scale).astype(np.float64)
+    Y = np.fft.rfft(x.astype(np.float64), axis=0) * w[:, None]
+    want = np.fft.irfft(Y, n=n_t, axis=0) * n_t
+    assert np.abs(y - want).max() <= 2e-7 * max(np.abs(want).max(), 1e-30)
+    # the kernel is real and even, and sums to w_0 * n_t = 0 (no DC)
+    h2 = oracle_mod.ramp_kernel(n_t)
+    assert np.allclose(h2[1:n_t], h2[1:n_t][::-1], rtol=0, atol=1e-18 + 1e-12 * np.abs(h2).max())
+    assert abs(h2[:n_t].sum()) <= 1e-12 * max(np.abs(h2).sum(), 1e-30)
