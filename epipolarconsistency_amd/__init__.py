@@ -8,6 +8,7 @@ loudly if it has not been built.
 """
 from ._lib import (EccError, FILTER_DERIVATIVE, FILTER_NONE, FILTER_RAMP, POST_IDENTITY, POST_LOGARITHM,
                    POST_SQUARE_ROOT)
+from . import geometry
 from .api import (Context, MetricRadonIntermediate, RadonIntermediate, get_ij, host_object_radius, host_pinvT,
                   host_source_position, pack_projection_matrices, slab_floats)
 

@@ -302,6 +302,27 @@ class MetricRadonIntermediate:
                                           C.c_void_p(out.ctypes.data), C.byref(mean)))
         return mean.value
 
+    def evaluateForImagePair(self, i, j):
+        """ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas, radon_samples0,
+        radon_samples1) (...RadonIntermediate.cpp:324-393, visualisation).  Returns (ecc, dict) with the
+        reference's five output vectors (radon_samples as (n, 2) arrays of (angle, distance) texture
+        coordinates) and K01."""
+        L = _lib.lib()
+        cap = C.c_int()
+        check(L.ecc_metric_pair_samples_bound(self._h, C.byref(cap)))
+        cap = cap.value
+        s0, s1, kap = (np.empty(cap, np.float32) for _ in range(3))
+        r0, r1 = np.empty((cap, 2), np.float32), np.empty((cap, 2), np.float32)
+        K01 = np.empty(16, np.float32)
+        n, ecc = C.c_int(), C.c_double()
+        check(L.ecc_metric_evaluate_for_image_pair(
+            self._h, int(i), int(j), cap, C.byref(n), C.c_void_p(s0.ctypes.data), C.c_void_p(s1.ctypes.data),
+            C.c_void_p(kap.ctypes.data), C.c_void_p(r0.ctypes.data), C.c_void_p(r1.ctypes.data),
+            C.c_void_p(K01.ctypes.data), C.byref(ecc)))
+        n = n.value
+        return ecc.value, dict(redundant_samples0=s0[:n], redundant_samples1=s1[:n], kappas=kap[:n],
+                               radon_samples0=r0[:n], radon_samples1=r1[:n], K01=K01)
+
     def evaluate_range(self, first, count, want_pairs=False):
         """Partial sum over pairs [first, first+count) of the get_ij order (multi-GPU shard)."""
         s = C.c_double()

@@ -17,7 +17,7 @@
 // Error behaviour: the reference prints and exit()s on any CUDA error (LibUtilsCuda/UtilsCuda.hxx:14-28);
 // the adapter throws std::runtime_error with ecc_last_error() instead.
 // Not carried over: getTexture()/BindlessTexture2D (there are no textures),
-// setProjectionImages (a stub in the reference, ...RadonIntermediate.cpp:121-125), evaluateForImagePair.
+// setProjectionImages (a stub in the reference, ...RadonIntermediate.cpp:121-125).
 #ifndef ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
 #define ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
 
@@ -26,6 +26,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ecc_hip.h"
@@ -278,6 +279,35 @@ public:
         double mean = 0;
         detail::check(ecc_metric_evaluate_pairs(m_h, idx4, n_pairs, _out, &mean));
         return mean;
+    }
+
+    /// ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas) -- visualisation.
+    virtual double evaluateForImagePair(int i, int j, std::vector<float>* redundant_samples0 = 0x0,
+                                        std::vector<float>* redundant_samples1 = 0x0, std::vector<float>* kappas = 0x0)
+    {
+        return evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas, 0x0, 0x0);
+    }
+
+    /// ref: ... and the sample locations in the two Radon transforms (angle, distance in [0,1]).
+    double evaluateForImagePair(int i, int j, std::vector<float>* redundant_samples0,
+                                std::vector<float>* redundant_samples1, std::vector<float>* kappas,
+                                std::vector<std::pair<float, float> >* radon_samples0,
+                                std::vector<std::pair<float, float> >* radon_samples1)
+    {
+        int cap = 0, n = 0;
+        detail::check(ecc_metric_pair_samples_bound(m_h, &cap));
+        std::vector<float> s0(cap), s1(cap), kp(cap), r0(2 * (size_t)cap), r1(2 * (size_t)cap);
+        double ecc = 0;
+        detail::check(ecc_metric_evaluate_for_image_pair(m_h, i, j, cap, &n, s0.data(), s1.data(), kp.data(), r0.data(),
+                                                         r1.data(), 0x0, &ecc));
+        if (redundant_samples0) redundant_samples0->insert(redundant_samples0->end(), s0.begin(), s0.begin() + n);
+        if (redundant_samples1) redundant_samples1->insert(redundant_samples1->end(), s1.begin(), s1.begin() + n);
+        if (kappas) kappas->insert(kappas->end(), kp.begin(), kp.begin() + n);
+        for (int k = 0; k < n; ++k) {
+            if (radon_samples0) radon_samples0->push_back(std::make_pair(r0[2 * k], r0[2 * k + 1]));
+            if (radon_samples1) radon_samples1->push_back(std::make_pair(r1[2 * k], r1[2 * k + 1]));
+        }
+        return ecc;
     }
 
 private:

@@ -31,6 +31,7 @@ extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
+extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
 
@@ -851,5 +852,99 @@ ECC_EXPORT int ecc_metric_debug_K01(ecc_metric* m, int64_t first, int64_t count,
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(K01s, m->K01_d, sizeof(float) * 16 * count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ECC_OK;
+}
+
+// ---- evaluateForImagePair (E7) ------------------------------------------------------------------
+ECC_EXPORT int ecc_metric_pair_samples_bound(const ecc_metric* m, int* capacity)
+{
+    if (!m || !capacity) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    // kappa runs over (-kappa_max, kappa_max) in steps of dkappa: automatic dkappa = 2 kappa_max / num_samples
+    // gives num_samples steps; a user dkappa gives at most Pi / dkappa (kappa_max <= Pi/2).
+    const float num_samples = sqrtf((float)(m->n_u * m->n_u + m->n_v * m->n_v));
+    const double n = m->dkappa > 0 ? 3.14159265358979323846 / (double)(float)m->dkappa : (double)num_samples;
+    if (!(n < 65536.0)) return fail(ECC_ERR_INVALID_ARGUMENT, "more than 65536 kappa samples (visualisation path)");
+    *capacity = (int)n + 16;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, int capacity, int* n_samples,
+                                                  float* rs0, float* rs1, float* kappas, float* radon0, float* radon1,
+                                                  float* K01, double* ecc)
+{
+    if (!m || !n_samples) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
+    const int nD = (int)m->dtrs.size();
+    if (i < 0 || j < 0 || i >= m->n_views || j >= m->n_views || i >= nD || j >= nD)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "view index out of range");
+    int bound = 0;
+    int rc = ecc_metric_pair_samples_bound(m, &bound);
+    if (rc) return rc;
+    ecc_ctx* ctx = m->ctx;
+    rc = set_device(ctx);
+    if (rc) return rc;
+    double radius = 0;
+    ecc_metric_get_object_radius(m, &radius);
+
+    float* out_d = nullptr;
+    HIP_TRY(hipMalloc((void**)&out_d, sizeof(float) * (7 * (size_t)bound + 16) + sizeof(int)));
+    float* K01_d = out_d + 7 * (size_t)bound;
+    int* n_d = reinterpret_cast<int*>(K01_d + 16);
+    EccPairSamplesParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.dtr0 = m->dtrs[i]->base;
+    p.dtr1 = m->dtrs[j]->base;
+    p.Cs = m->Cs_d;
+    p.PinvTs = m->PinvTs_d;
+    p.out = out_d;
+    p.K01_out = K01_d;
+    p.n_out = n_d;
+    p.iP0 = i;
+    p.iP1 = j;
+    p.capacity = bound;
+    p.n_alpha = m->n_alpha;
+    p.n_t = m->n_t;
+    p.pitch = m->pitch;
+    p.n_x2 = m->n_u * 0.5f;
+    p.n_y2 = m->n_v * 0.5f;
+    p.object_radius_mm = (float)radius;
+    p.num_samples = sqrtf((float)(m->n_u * m->n_u + m->n_v * m->n_v));  // ref: ...RadonIntermediate.cpp:349
+    p.range_t = m->step_t * m->n_t;                                      // ref: RadonIntermediate.h:90
+    p.dkappa_user = (float)m->dkappa;
+    p.derivative0 = m->dtrs[i]->filter == ECC_FILTER_DERIVATIVE;
+    p.derivative1 = m->dtrs[j]->filter == ECC_FILTER_DERIVATIVE;
+    std::vector<float> host(7 * (size_t)bound + 16 + 1);
+    hipError_t e = hipMemsetAsync(out_d, 0, sizeof(float) * (7 * (size_t)bound + 16) + sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = ecc_launch_pair_samples(&p, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host.data(), out_d, sizeof(float) * host.size(), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(out_d);
+    HIP_TRY(e);
+    int n = 0;
+    std::memcpy(&n, &host[7 * (size_t)bound + 16], sizeof(int));
+    *n_samples = n;
+    if (n >= bound) return fail(ECC_ERR_HIP, "internal: kappa sample bound exceeded");
+    if (n > capacity) return fail(ECC_ERR_INVALID_ARGUMENT, "capacity is smaller than the number of kappa samples");
+    const float* v0 = host.data();
+    const float* v1 = v0 + bound;
+    const float* kp = v1 + bound;
+    const float* a0 = kp + bound;
+    const float* d0 = a0 + bound;
+    const float* a1 = d0 + bound;
+    const float* d1 = a1 + bound;
+    const float* K = d1 + bound;
+    const float dkappa = K[8 + 6];
+    double acc = 0;
+    for (int k = 0; k < n; ++k) {
+        if (rs0) rs0[k] = v0[k];
+        if (rs1) rs1[k] = v1[k];
+        if (kappas) kappas[k] = kp[k];
+        if (radon0) { radon0[2 * k] = a0[k]; radon0[2 * k + 1] = d0[k]; }
+        if (radon1) { radon1[2 * k] = a1[k]; radon1[2 * k + 1] = d1[k]; }
+        acc += (double)((v0[k] - v1[k]) * (v0[k] - v1[k]) * dkappa);  // ref: ...RadonIntermediate.cpp:389, accumulated
+    }
+    if (K01) std::memcpy(K01, K, sizeof(float) * 16);
+    if (ecc) *ecc = acc;
     return ECC_OK;
 }

@@ -63,4 +63,24 @@ struct EccPairParams {
     int use_corr;              // MetricRadonIntermediate::useCorrelation (ref: ...RadonIntermediate.cu:116-149)
 };
 
+// ---- evaluateForImagePair (E7, visualisation) -------------------------------------------------
+struct EccPairSamplesParams {
+    const float* dtr0;       // slab of view i
+    const float* dtr1;       // slab of view j
+    const float* Cs;
+    const float* PinvTs;
+    float* out;              // 7 x capacity floats: v0, v1, kappa, a0, d0, a1, d1
+    float* K01_out;          // 16 floats
+    int* n_out;              // number of samples produced (zeroed by the caller)
+    int iP0, iP1;
+    int capacity;
+    int n_alpha, n_t, pitch;
+    float n_x2, n_y2;
+    float object_radius_mm;
+    float num_samples;       // sqrtf(n_u*n_u + n_v*n_v)  (ref: ...RadonIntermediate.cpp:349)
+    float range_t;
+    float dkappa_user;
+    int derivative0, derivative1;
+};
+
 #endif

@@ -359,7 +359,108 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// E7: evaluateForImagePair -- the two redundant signals of ONE pair over kappa in (-kappa_max, kappa_max),
+// for plotting (ref: EpipolarConsistencyRadonIntermediate.cpp:324-393, "visualization only").  One thread
+// per kappa sample; this is the oracle's plain arithmetic (or_pair_samples in oracle/ecc_oracle.c): the
+// reference's float expressions in source order, elementary functions correctly rounded, bilinear rule of
+// SURVEY.md 8c with explicit index clamps -- not the fast path of pairs_kernel.
+// Deviations from the reference's host code, which is visibly unfinished: the fold's sign is
+// applied (its sample() can never reach the flip after lineToSampleDtr folded the angle,
+// RadonIntermediate.h:91-100), and sampling uses the texel rule of the metric itself (a*n_alpha - .5) instead
+// of the host image's (n-1)*s scaling (RadonIntermediate.h:108), so the curves are what evaluate() compares.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float slab_texel(const float* slab, int pitch, int n_alpha, int n_t, int i, int j)
+{
+    i = min(max(i, 0), n_alpha - 1);
+    j = min(max(j, 0), n_t - 1);
+    return slab[(size_t)(i + 1) * pitch + (j + 1)];
+}
+
+// (a, d) in normalised texture coordinates -> value; W = n_alpha (x), H = n_t (y).
+__device__ float slab_tex2d_norm(const float* slab, int pitch, int n_alpha, int n_t, float s, float t)
+{
+    const float x = s * (float)n_alpha, y = t * (float)n_t;
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fi = floorf(xb), fj = floorf(yb);
+    const float fx = xb - fi, fy = yb - fj;
+    // float -> int saturates on the device; the clamps below do the rest (d may be far outside [0, 1])
+    const int i = (int)fmaxf(fminf(fi, 1e9f), -1e9f), j = (int)fmaxf(fminf(fj, 1e9f), -1e9f);
+    const float T00 = slab_texel(slab, pitch, n_alpha, n_t, i, j), T10 = slab_texel(slab, pitch, n_alpha, n_t, i + 1, j);
+    const float T01 = slab_texel(slab, pitch, n_alpha, n_t, i, j + 1),
+                T11 = slab_texel(slab, pitch, n_alpha, n_t, i + 1, j + 1);
+    const float r0 = (1.f - fx) * T00 + fx * T10;
+    const float r1 = (1.f - fx) * T01 + fx * T11;
+    return (1.f - fy) * r0 + fy * r1;
+}
+
+// ref: EpipolarConsistencyCommon.hxx:152-171 (lineToSampleDtr) + RadonIntermediate.h:86-105 (sample)
+__device__ float sample_line_plain(const float* K, float x0, float x1, const float* slab, int pitch, int n_alpha,
+                                   int n_t, float range_t, bool derivative, float* a_out, float* d_out)
+{
+    const float Pi = 3.14159265359f;
+    float l0 = K[0] * x0 + K[3] * x1;
+    float l1 = K[1] * x0 + K[4] * x1;
+    float l2 = K[2] * x0 + K[5] * x1;
+    const float length = sqrtf(l0 * l0 + l1 * l1);
+    float a = (float)atan2((double)l1, (double)l0) / Pi;
+    if (a < 0) a += 2;
+    float d = -(l2 / length) / range_t + 0.5f;
+    bool moved = false;
+    if (a > 1) {
+        a = a - 1.f;
+        d = 1.f - d;
+        moved = true;
+    }
+    *a_out = a;
+    *d_out = d;
+    const float v = slab_tex2d_norm(slab, pitch, n_alpha, n_t, a, d);
+    return (derivative && moved) ? -v : v;
+}
+
+__global__ __launch_bounds__(256) void pair_samples_kernel(EccPairSamplesParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    float K0[8], K1[8];
+    if (p.iP0 == p.iP1) {
+        for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
+    } else {
+        compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * p.iP0, p.Cs + 4 * p.iP1, p.PinvTs + 12 * p.iP0, p.PinvTs + 12 * p.iP1,
+                    p.object_radius_mm, p.num_samples, p.dkappa_user, true, K0, K1);
+    }
+    if (k == 0)
+        for (int i = 0; i < 8; i++) {
+            p.K01_out[i] = K0[i];
+            p.K01_out[8 + i] = K1[i];
+        }
+    const float dkappa = K1[6], kappa_max = K1[7];
+    // ref: ...RadonIntermediate.cpp:367: for (float kappa=-kappa_max+0.5f*dkappa; kappa<kappa_max; kappa+=dkappa)
+    // -- kappa accumulates in fp32; thread k replays the first k additions.
+    float kappa = -kappa_max + 0.5f * dkappa;
+    if (!(dkappa > 0.f)) return;  // degenerate pair: the reference's loop would not terminate / not start
+    for (int q = 0; q < k && kappa < kappa_max; ++q) kappa += dkappa;
+    if (!(kappa < kappa_max) || k >= p.capacity) return;
+    if (!(kappa + dkappa < kappa_max) || k + 1 == p.capacity) *p.n_out = k + 1;  // exactly one thread: the last sample
+    const float x0 = (float)cos((double)kappa), x1 = (float)sin((double)kappa);
+    float a0, d0, a1, d1;
+    const float v0 = sample_line_plain(K0, x0, x1, p.dtr0, p.pitch, p.n_alpha, p.n_t, p.range_t, p.derivative0 != 0, &a0, &d0);
+    const float v1 = sample_line_plain(K1, x0, x1, p.dtr1, p.pitch, p.n_alpha, p.n_t, p.range_t, p.derivative1 != 0, &a1, &d1);
+    p.out[0 * (size_t)p.capacity + k] = v0;
+    p.out[1 * (size_t)p.capacity + k] = v1;
+    p.out[2 * (size_t)p.capacity + k] = kappa;
+    p.out[3 * (size_t)p.capacity + k] = a0;
+    p.out[4 * (size_t)p.capacity + k] = d0;
+    p.out[5 * (size_t)p.capacity + k] = a1;
+    p.out[6 * (size_t)p.capacity + k] = d1;
+}
+
 }  // namespace
+
+extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pair_samples_kernel, dim3((p->capacity + 255) / 256), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream)
 {

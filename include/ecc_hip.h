@@ -159,6 +159,23 @@ int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int64_t count,
 int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int n_pairs, float* out,
                               double* mean);
 
+/* ref: MetricRadonIntermediate::evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas,
+ * radon_samples0, radon_samples1) (...RadonIntermediate.cpp:324-393, "visualization only"): the two
+ * redundant signals of ONE pair over kappa in (-kappa_max, kappa_max) with num_samples = image diagonal
+ * (:349) and the fp32-accumulated kappa loop (:367).  The reference does this on the host from read-back
+ * dtrs; here one small kernel samples the device-resident dtrs.  The evident intent is implemented where
+ * the reference code is unfinished: the (alpha+pi, -t) fold flips the sign of derivative
+ * dtrs, sampling uses the metric's own texel rule, and *ecc = SUM (v0-v1)^2 dkappa (the reference assigns).
+ * All output arrays are on the host and nullable; each holds `capacity` entries (radon_samples: 2 floats
+ * per sample = texture coordinates (angle, distance) in [0,1]).  *n_samples receives the number of samples;
+ * fails with ECC_ERR_INVALID_ARGUMENT (and *n_samples set) when capacity is too small --
+ * ecc_metric_pair_samples_bound gives a sufficient capacity.  K01 (nullable) receives 16 floats. */
+int ecc_metric_pair_samples_bound(const ecc_metric* m, int* capacity);
+int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, int capacity, int* n_samples,
+                                       float* redundant_samples0, float* redundant_samples1, float* kappas,
+                                       float* radon_samples0, float* radon_samples1, float* K01,
+                                       double* ecc);
+
 /* Debug: the 16 K01 floats per pair the kernel used (ref: kernelEpipolarConsistencyComputeK01,
  * …RadonIntermediate.cu:13-67), for ij in [first, first+count).  Host output. */
 int ecc_metric_debug_K01(ecc_metric* m, int64_t first, int64_t count, float* K01s);

@@ -74,6 +74,10 @@ def _bind(L):
                                        C.c_int, _f32p, C.c_void_p]
     L.eccor_evaluate_pairs.restype = C.c_double
     L.eccor_num_threads.restype = C.c_int
+    L.eccor_evaluate_for_image_pair.argtypes = [_f64p, _f64p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _f32p, _f32p,
+                                                _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_double)]
+    L.eccor_evaluate_for_image_pair.restype = C.c_int
     return L
 
 
@@ -229,6 +233,26 @@ def evaluate_pairs(Ps, dtrs, n_u, n_v, idx4, object_radius_mm=0.0, dkappa=0.0, i
         len(Ps), pack_Ps(Ps), len(dtrs), arr, n_u, n_v, n_alpha, n_t, float(object_radius_mm),
         float(dkappa), 1 if is_derivative else 0, idx4.reshape(-1), len(idx4), out, None)
     return dict(mean=mean, pairs=out)
+
+
+def evaluate_for_image_pair(Ps, dtrs, i, j, n_u, n_v, object_radius_mm=0.0, dkappa=0.0, derivative=True):
+    """E7 (ref: ...RadonIntermediate.cpp:324-393, evident intent -- see ecc_oracle.c).  Returns dict(ecc, samples0,
+    samples1, kappas, radon0 (n,2), radon1 (n,2), K01)."""
+    n_t, n_alpha = dtrs[i].shape
+    radius = float(object_radius_mm) if object_radius_mm > 0 else object_radius(Ps[0], n_u, n_v)
+    cap = int(np.sqrt(float(n_u * n_u + n_v * n_v))) + 16 if dkappa <= 0 else int(np.pi / dkappa) + 16
+    rs0, rs1, kap = (np.zeros(cap, np.float32) for _ in range(3))
+    r0, r1 = np.zeros(2 * cap, np.float32), np.zeros(2 * cap, np.float32)
+    K01 = np.zeros(16, np.float32)
+    ecc = C.c_double()
+    d0 = np.ascontiguousarray(dtrs[i], np.float32)
+    d1 = np.ascontiguousarray(dtrs[j], np.float32)
+    n = lib().eccor_evaluate_for_image_pair(_P(Ps[i]), _P(Ps[j]), d0, d1, n_u, n_v, n_alpha, n_t, radius, float(dkappa),
+                                            1 if derivative else 0, 1 if derivative else 0, cap, rs0, rs1, kap, r0, r1,
+                                            K01, C.byref(ecc))
+    assert n <= cap
+    return dict(ecc=ecc.value, samples0=rs0[:n], samples1=rs1[:n], kappas=kap[:n], radon0=r0[:2 * n].reshape(n, 2),
+                radon1=r1[:2 * n].reshape(n, 2), K01=K01)
 
 
 def set_variant(v):

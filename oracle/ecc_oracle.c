@@ -740,6 +740,66 @@ ECCOR_API double eccor_evaluate_pairs(int n_P, const double *Ps, int n_dtr, cons
     return sum / n_pairs;
 }
 
+/* E7: evaluateForImagePair -- the redundant signals of one pair over kappa in (-kappa_max, kappa_max).
+ * ref: EpipolarConsistencyRadonIntermediate.cpp:324-393 and RadonIntermediate.h:86-108 (sample, tex2D).
+ * The reference's host code is "visualization only" and visibly unfinished; NOT a parity
+ * target against the reference.  Kept as written: K01 with num_samples = sqrtf(n_u*n_u+n_v*n_v) (:349), the
+ * fp32-accumulated kappa loop (:367), cosf/sinf and the line products (:370-375).  Evident intent
+ * implemented instead of the code as written: (1) the fold's sign for derivative dtrs is applied (sample()'s
+ * flip branch is unreachable after lineToSampleDtr has folded the angle); (2) sampling uses the metric's own
+ * texel rule (normalised coordinates) rather than the host image's (n-1)*s scaling;
+ * (3) ecc ACCUMULATES (v0-v1)^2*dkappa (the reference assigns, :389).  P^+T and C come from E1 (QR), the
+ * reference takes them from Eigen's SVD here -- same quantities to ~1e-13.
+ * out arrays hold `capacity` entries each (radon0/radon1: 2 per sample = (a, d)); returns the number of
+ * samples (which may exceed capacity: then only the first `capacity` are stored). */
+ECCOR_API int eccor_evaluate_for_image_pair(const double *P0, const double *P1, const float *dtr0,
+                                            const float *dtr1, int n_u, int n_v, int n_alpha, int n_t,
+                                            double object_radius_mm, double dkappa_user,
+                                            int derivative0, int derivative1, int capacity, float *rs0,
+                                            float *rs1, float *kappas, float *radon0, float *radon1,
+                                            float *K01, double *ecc_out)
+{
+    float C0[4], C1[4], P0invT[12], P1invT[12], K0[8], K1[8];
+    double diagonal = sqrt((double)n_v * n_v + (double)n_u * n_u);
+    float step_t = (float)(diagonal / n_t);
+    float range_t = step_t * n_t; /* ref: RadonIntermediate.h:90 */
+    float dkappa, kappa_max, kappa;
+    double ecc = 0;
+    int n = 0;
+    eccor_pinvT(P0, P0invT);
+    eccor_pinvT(P1, P1invT);
+    eccor_source_position(P0, C0);
+    eccor_source_position(P1, C1);
+    eccor_computeK01(n_u * 0.5f, n_v * 0.5f, C0, C1, P0invT, P1invT, (float)object_radius_mm,
+                     sqrtf((float)(n_u * n_u + n_v * n_v)), (float)dkappa_user, K0, K1);
+    if (K01) { memcpy(K01, K0, 32); memcpy(K01 + 8, K1, 32); }
+    dkappa = K1[6];
+    kappa_max = K1[7];
+    if (!(dkappa > 0.f)) { if (ecc_out) *ecc_out = 0; return 0; }
+    for (kappa = -kappa_max + 0.5f * dkappa; kappa < kappa_max; kappa += dkappa) {
+        float x0 = or_cosf(kappa), x1 = or_sinf(kappa);
+        float line0[3] = {K0[0] * x0 + K0[3] * x1, K0[1] * x0 + K0[4] * x1, K0[2] * x0 + K0[5] * x1};
+        float line1[3] = {K1[0] * x0 + K1[3] * x1, K1[1] * x0 + K1[4] * x1, K1[2] * x0 + K1[5] * x1};
+        int m0 = eccor_line_to_sample_dtr(line0, range_t);
+        int m1 = eccor_line_to_sample_dtr(line1, range_t);
+        float v0 = eccor_tex2d_norm(dtr0, n_alpha, n_t, line0[0], line0[1]);
+        float v1 = eccor_tex2d_norm(dtr1, n_alpha, n_t, line1[0], line1[1]);
+        if (derivative0 && m0) v0 = -v0;
+        if (derivative1 && m1) v1 = -v1;
+        if (n < capacity) {
+            if (rs0) rs0[n] = v0;
+            if (rs1) rs1[n] = v1;
+            if (kappas) kappas[n] = kappa;
+            if (radon0) { radon0[2 * n] = line0[0]; radon0[2 * n + 1] = line0[1]; }
+            if (radon1) { radon1[2 * n] = line1[0]; radon1[2 * n + 1] = line1[1]; }
+        }
+        ecc += (double)((v0 - v1) * (v0 - v1) * dkappa);
+        n++;
+    }
+    if (ecc_out) *ecc_out = ecc;
+    return n;
+}
+
 ECCOR_API int eccor_num_threads(void)
 {
 #ifdef _OPENMP

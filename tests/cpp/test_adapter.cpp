@@ -44,6 +44,10 @@ int main(int argc, char** argv)
         printf("dtr1 %zu %.9g bins %d %d size %d %d step %.17g\n", dtrs[1]->data().size(), dtrs[1]->data()[1234 % dtrs[1]->data().size()],
                dtrs[1]->getRadonBinNumber(0), dtrs[1]->getRadonBinNumber(1), dtrs[1]->getOriginalImageSize(0),
                dtrs[1]->getOriginalImageSize(1), dtrs[1]->getRadonBinSize(1));
+        std::vector<float> rs0, rs1, kappas;
+        std::vector<std::pair<float, float> > loc0, loc1;
+        const double pair_ecc = ecc.evaluateForImagePair(0, 2, &rs0, &rs1, &kappas, &loc0, &loc1);
+        printf("pair02 %.17g %zu %zu %zu %.9g %.9g\n", pair_ecc, rs0.size(), kappas.size(), loc1.size(), kappas[0], loc0[0].first);
         ecc.setObjectRadius(50.0);
         printf("mean_r50 %.17g\n", ecc.evaluate());
         for (size_t k = 0; k < dtrs.size(); ++k) delete dtrs[k];

@@ -52,5 +52,10 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     f = val["dtr1"].split()
     assert int(f[0]) == s["n_alpha"] * s["n_t"] and float(f[1]) == float(dtrs[1].reshape(-1)[1234])
     assert f[3:5] == [str(s["n_alpha"]), str(s["n_t"])] and f[6:8] == [str(s["n_u"]), str(s["n_v"])]
+    e7 = oracle_mod.evaluate_for_image_pair(Ps, dtrs, 0, 2, s["n_u"], s["n_v"])
+    f = val["pair02"].split()
+    assert abs(float(f[0]) - e7["ecc"]) < 1e-4 * e7["ecc"]
+    assert [int(x) for x in f[1:4]] == [len(e7["kappas"])] * 3
+    assert float(f[4]) == float(e7["kappas"][0]) and abs(float(f[5]) - e7["radon0"][0, 0]) < 2e-6
     r50 = oracle_mod.evaluate_all(Ps, dtrs, s["n_u"], s["n_v"], object_radius_mm=50.0)
     assert abs(float(val["mean_r50"]) - r50["mean"]) < 1e-5 * r50["mean"]

@@ -232,3 +232,35 @@ def test_ramp_filtered_pairs(gpu_ctx, oracle_mod, small_scan):
     m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"][:4], dtrs)
     want = oracle_mod.evaluate_all(s["Ps"][:4], host, s["n_u"], s["n_v"], is_derivative=False)
     assert _rel(m.evaluate(), want["mean"]) < 1e-5
+
+
+@pytest.mark.parametrize("dkappa", [0.0, 0.004])
+def test_evaluate_for_image_pair(gpu_ctx, oracle_mod, small_scan, dkappa):
+    """E7 (ref: ...RadonIntermediate.cpp:324-393): redundant signals of one pair, GPU vs the oracle's restatement
+    of the evident intent."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs).setEpipolarPlaneStep(dkappa)
+    for (i, j) in ((1, 5), (6, 2)):
+        ecc, got = m.evaluateForImagePair(i, j)
+        want = oracle_mod.evaluate_for_image_pair(s["Ps"], s["dtrs"], i, j, s["n_u"], s["n_v"], dkappa=dkappa)
+        n = len(want["kappas"])
+        assert len(got["kappas"]) == n and n > 50
+        assert np.array_equal(got["kappas"], want["kappas"])
+        assert np.allclose(got["K01"], want["K01"], rtol=3e-7, atol=1e-7 * np.abs(want["K01"]).max())
+        assert np.abs(got["radon_samples0"] - want["radon0"]).max() < 2e-6
+        assert np.abs(got["radon_samples1"] - want["radon1"]).max() < 2e-6
+        scale = max(np.abs(want["samples0"]).max(), np.abs(want["samples1"]).max())
+        assert np.abs(got["redundant_samples0"] - want["samples0"]).max() < 1e-3 * scale
+        assert np.abs(got["redundant_samples1"] - want["samples1"]).max() < 1e-3 * scale
+        assert _rel(ecc, want["ecc"]) < 1e-4
+    # the two signals agree much better for the consistent geometry than for a perturbed one
+    ecc_ok, _ = m.evaluateForImagePair(1, 5)
+    Ps_bad = [p.copy() for p in s["Ps"]]
+    Ps_bad[5] = Ps_bad[5] @ E.geometry.rigid_transform(tx=3.0, ry=0.02)
+    m.setProjectionMatrices(Ps_bad)
+    ecc_bad, _ = m.evaluateForImagePair(1, 5)
+    assert ecc_bad > 2 * ecc_ok
+    with pytest.raises(E.EccError):
+        m.evaluateForImagePair(0, 99)
