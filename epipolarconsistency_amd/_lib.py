@@ -20,6 +20,14 @@ class EccError(RuntimeError):
         self.code = code
 
 
+class PreprocessConfig(C.Structure):
+    """struct ecc_preprocess_config (include/ecc_hip.h)."""
+    _fields_ = [("process", C.c_int32), ("normalize", C.c_int32), ("bias", C.c_double), ("scale", C.c_double),
+                ("apply_log", C.c_int32), ("gaussian_sigma", C.c_double), ("half_kernel_width", C.c_int32),
+                ("flip_u", C.c_int32), ("flip_v", C.c_int32), ("zero", C.c_int32 * 4), ("feather", C.c_int32 * 4),
+                ("n_blanks", C.c_int32), ("blanks", C.c_void_p)]
+
+
 _lib = None
 
 # name -> (restype, argtypes); every symbol declared in include/ecc_hip.h
@@ -59,6 +67,9 @@ SIGNATURES = {
     "ecc_host_pinvT": (None, [_vp, _vp]),
     "ecc_host_source_position": (None, [_vp, _vp]),
     "ecc_host_object_radius": (_d, [_vp, _i, _i]),
+    "ecc_preprocess_defaults": (None, [_vp]),
+    "ecc_preprocess": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "ecc_host_intrinsics": (None, [_vp, _pf, _pf, _pf]),
     "ecc_ctx_enable_timing": (_i, [_vp, _i]),
     "ecc_ctx_last_kernel_ms": (_i, [_vp, _i, _pf]),
 }

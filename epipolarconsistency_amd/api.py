@@ -48,9 +48,9 @@ class Context:
         check(_lib.lib().ecc_ctx_enable_timing(self._h, 1 if on else 0))
 
     def last_kernel_ms(self, which):
-        """which: 'pairs' or 'radon' -- HIP-event time of the last such kernel on this stream."""
+        """which: 'pairs', 'radon' or 'preprocess' -- HIP-event time of the last such kernel on this stream."""
         ms = C.c_float()
-        check(_lib.lib().ecc_ctx_last_kernel_ms(self._h, {"pairs": 0, "radon": 1}[which], C.byref(ms)))
+        check(_lib.lib().ecc_ctx_last_kernel_ms(self._h, {"pairs": 0, "radon": 1, "preprocess": 2}[which], C.byref(ms)))
         return ms.value
 
     def close(self):
@@ -63,6 +63,69 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class PreProccess:  # sic, ref: struct EpipolarConsistency::PreProccess (Gui/PreProccess.h:14-50)
+    """Pre-processing of X-ray projection images, same fields and defaults as the reference's struct
+    (intensity.*, lowpass.*, image_geometry.*, border.*).  process() = PreProccess::process followed by
+    apply_weight_cos_principal_ray when projection matrices are given (call order of
+    Gui/InputDataDirect.cpp:85-86), fused into one device kernel for a whole stack."""
+
+    class _NS:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    def __init__(self):
+        self.intensity = self._NS(normalize=False, bias=0.0, scale=1.0, apply_log=False)
+        self.lowpass = self._NS(gaussian_sigma=1.84, half_kernel_width=5)
+        self.image_geometry = self._NS(flip_u=False, flip_v=False)
+        self.border = self._NS(zero=[1, 1, 1, 1], feather=[16, 16, 16, 16], blanks=[])
+
+    def _config(self, process=True):
+        cfg = _lib.PreprocessConfig()
+        _lib.lib().ecc_preprocess_defaults(C.byref(cfg))
+        cfg.process = 1 if process else 0
+        cfg.normalize, cfg.bias, cfg.scale = int(self.intensity.normalize), self.intensity.bias, self.intensity.scale
+        cfg.apply_log = int(self.intensity.apply_log)
+        cfg.gaussian_sigma, cfg.half_kernel_width = self.lowpass.gaussian_sigma, int(self.lowpass.half_kernel_width)
+        cfg.flip_u, cfg.flip_v = int(self.image_geometry.flip_u), int(self.image_geometry.flip_v)
+        cfg.zero = (C.c_int32 * 4)(*[int(v) for v in self.border.zero])
+        cfg.feather = (C.c_int32 * 4)(*[int(v) for v in self.border.feather])
+        bl = np.ascontiguousarray(np.asarray(self.border.blanks, np.int32).reshape(-1, 4))
+        cfg.n_blanks = len(bl)
+        cfg.blanks = bl.ctypes.data if len(bl) else None
+        return cfg, bl
+
+    def _run(self, ctx, images, Ps, out, process):
+        cfg, keep = self._config(process)
+        Pp = None if Ps is None else _Ps_colmajor(Ps)
+        if _is_torch(images):
+            import torch
+            assert images.dtype == torch.float32 and images.is_contiguous() and images.is_cuda and images.dim() == 3
+            out = images if out is None else out
+            assert out.shape == images.shape and out.is_contiguous() and out.is_cuda
+            n, n_v, n_u = images.shape
+            a, b, on_dev = images.data_ptr(), out.data_ptr(), 1
+        else:
+            images = np.ascontiguousarray(images, np.float32)
+            assert images.ndim == 3
+            out = np.empty_like(images) if out is None else out
+            n, n_v, n_u = images.shape
+            a, b, on_dev = images.ctypes.data, out.ctypes.data, 0
+        assert Pp is None or len(Pp) == n
+        check(_lib.lib().ecc_preprocess(ctx._h, C.c_void_p(a), on_dev, C.c_void_p(b), n, n_u, n_v, C.byref(cfg),
+                                        C.c_void_p(Pp.ctypes.data) if Pp is not None else None))
+        del keep
+        return out
+
+    def process(self, ctx, images, Ps=None, out=None):
+        """images: (n, n_v, n_u) float32, numpy (host; returns a new array) or torch on ctx's device (in place
+        unless `out` is given).  Ps: n projection matrices -> cosine weighting is applied as well."""
+        return self._run(ctx, images, Ps, out, True)
+
+    def apply_weight_cos_principal_ray(self, ctx, images, Ps, out=None):
+        """ref: PreProccess::apply_weight_cos_principal_ray alone (Gui/PreProccess.cpp:146-166)."""
+        return self._run(ctx, images, Ps, out, False)
 
 
 class RadonIntermediate:
@@ -388,3 +451,11 @@ def host_source_position(P):
 def host_object_radius(P, n_u, n_v):
     P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, 4).T).reshape(12)
     return _lib.lib().ecc_host_object_radius(C.c_void_p(P.ctypes.data), int(n_u), int(n_v))
+
+
+def host_intrinsics(P):
+    """(sdd_px, ppu, ppv) = K(0,0), K(0,2), K(1,2) of P = K[R|t] (ref: getCameraIntrinsics)."""
+    P = np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, 4).T).reshape(12)
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    _lib.lib().ecc_host_intrinsics(C.c_void_p(P.ctypes.data), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libecc_hip.so")
-SOURCES = ["radon_kernel.hip", "ramp_kernel.hip", "pairs_kernel.hip", "geometry_kernel.hip", "ecc_capi.hip"]
+SOURCES = ["radon_kernel.hip", "ramp_kernel.hip", "preprocess_kernel.hip", "pairs_kernel.hip", "geometry_kernel.hip", "ecc_capi.hip"]
 HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", os.path.join("..", "..", "include", "ecc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]

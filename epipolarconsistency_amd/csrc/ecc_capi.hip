@@ -31,6 +31,8 @@ extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
+extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream);
+extern "C" size_t ecc_preprocess_lds_bytes(int k);
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
@@ -76,8 +78,8 @@ struct ecc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // pair start/stop, radon start/stop
-    bool ev_valid[2] = {false, false};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pair, radon, preprocess start/stop
+    bool ev_valid[3] = {false, false, false};
     // trig table cache for the Radon kernel
     float* trig_d = nullptr;
     int trig_n_alpha = 0;
@@ -338,13 +340,13 @@ ECC_EXPORT int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable)
         for (auto& e : ctx->ev)
             if (!e) HIP_TRY(hipEventCreate(&e));
     ctx->timing = enable != 0;
-    ctx->ev_valid[0] = ctx->ev_valid[1] = false;
+    ctx->ev_valid[0] = ctx->ev_valid[1] = ctx->ev_valid[2] = false;
     return ECC_OK;
 }
 
 ECC_EXPORT int ecc_ctx_last_kernel_ms(ecc_ctx* ctx, int which, float* ms)
 {
-    if (!ctx || !ms || which < 0 || which > 1) return fail(ECC_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!ctx || !ms || which < 0 || which > 2) return fail(ECC_ERR_INVALID_ARGUMENT, "bad argument");
     if (!ctx->timing || !ctx->ev_valid[which]) return fail(ECC_ERR_INVALID_ARGUMENT, "no timed launch recorded");
     int rc = set_device(ctx);
     if (rc) return rc;
@@ -946,5 +948,148 @@ ECC_EXPORT int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, i
     }
     if (K01) std::memcpy(K01, K, sizeof(float) * 16);
     if (ecc) *ecc = acc;
+    return ECC_OK;
+}
+
+// ---- projection pre-processing --------------------------------------------------------------------
+ECC_EXPORT void ecc_host_intrinsics(const double* P, float* sdd_px, float* ppu, float* ppv)
+{
+    ecc_host::intrinsics(P, sdd_px, ppu, ppv);
+}
+
+ECC_EXPORT void ecc_preprocess_defaults(ecc_preprocess_config* cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    // ref: Gui/PreProccess.h:19-45
+    cfg->process = 1;
+    cfg->scale = 1.0;
+    cfg->gaussian_sigma = 1.84;
+    cfg->half_kernel_width = 5;
+    for (int s = 0; s < 4; ++s) {
+        cfg->zero[s] = 1;
+        cfg->feather[s] = 16;
+    }
+}
+
+ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, float* out, int n, int n_u, int n_v,
+                              const ecc_preprocess_config* cfg, const double* Ps)
+{
+    if (!ctx || !images || !out || !cfg) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n <= 0 || n > 65535) return fail(ECC_ERR_INVALID_ARGUMENT, "batch size must be in [1, 65535]");
+    if (n_u < 1 || n_v < 1 || n_u > 16384 || n_v > 16384)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "image size must be in [1, 16384]");
+    if (cfg->n_blanks < 0 || (cfg->n_blanks > 0 && !cfg->blanks))
+        return fail(ECC_ERR_INVALID_ARGUMENT, "bad blanks");
+    for (int s = 0; s < 4; ++s)
+        if (cfg->zero[s] < 0 || cfg->feather[s] < 0) return fail(ECC_ERR_INVALID_ARGUMENT, "negative border width");
+    // ref: Gui/PreProccess.cpp:142: low-pass only if sigma > 0 and half width > 1
+    const bool lowpass = cfg->process && cfg->gaussian_sigma > 0 && cfg->half_kernel_width > 1;
+    const int k = lowpass ? cfg->half_kernel_width : 0;
+    if (k > 16) return fail(ECC_ERR_UNSUPPORTED, "half kernel width above 16 is not supported");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+
+    const size_t img_floats = (size_t)n_u * n_v;
+    // device-side tables: kernel (2k+1 doubles), blanks, per-image cosine-weight intrinsics, per-image maxima
+    std::vector<double> kernel(2 * (size_t)k + 1, 0.0);
+    if (k > 0) {  // ref: HeaderOnly/NRRD/nrrd_lowpass.hxx:19-33 (gaussianKernel)
+        double sum = 0;
+        for (int x = -k; x <= k; ++x) {
+            const double v = std::exp(-0.5 * std::pow(x / cfg->gaussian_sigma, 2));
+            sum += v;
+            kernel[x + k] = v;
+        }
+        for (double& v : kernel) v /= sum;
+    }
+    std::vector<float> cosw;
+    std::vector<int> valid;
+    if (Ps) {
+        cosw.resize(3 * (size_t)n);
+        valid.resize(n);
+        for (int v = 0; v < n; ++v) {
+            const double* P = Ps + 12 * (size_t)v;
+            bool zero = true;
+            for (int e = 0; e < 12; ++e) zero = zero && P[e] == 0;
+            valid[v] = zero ? 0 : 1;
+            if (zero) cosw[3 * v] = cosw[3 * v + 1] = cosw[3 * v + 2] = 0.f;
+            else ecc_host::intrinsics(P, &cosw[3 * v], &cosw[3 * v + 1], &cosw[3 * v + 2]);
+        }
+    }
+    const size_t kernel_b = sizeof(double) * kernel.size();
+    const size_t blanks_b = sizeof(int32_t) * 4 * (size_t)cfg->n_blanks;
+    const size_t cosw_b = sizeof(float) * cosw.size(), valid_b = sizeof(int) * valid.size();
+    const size_t max_b = sizeof(float) * (size_t)n;
+    auto up8 = [](size_t b) { return (b + 7) / 8 * 8; };
+    const size_t table_b = up8(kernel_b) + up8(blanks_b) + up8(cosw_b) + up8(valid_b) + up8(max_b);
+    char* tables = nullptr;
+    float* staging_in = nullptr;   // host input, or in-place scratch
+    float* staging_out = nullptr;
+    hipError_t e = hipMalloc((void**)&tables, table_b);
+    const bool in_place = on_device && images == out;
+    if (e == hipSuccess && (!on_device || in_place)) e = hipMalloc((void**)&staging_out, sizeof(float) * img_floats * n);
+    if (e == hipSuccess && !on_device) e = hipMalloc((void**)&staging_in, sizeof(float) * img_floats * n);
+    auto cleanup = [&]() {
+        if (tables) (void)hipFree(tables);
+        if (staging_in) (void)hipFree(staging_in);
+        if (staging_out) (void)hipFree(staging_out);
+    };
+    if (e != hipSuccess) {
+        cleanup();
+        HIP_TRY(e);
+    }
+    char* t = tables;
+    double* kernel_d = reinterpret_cast<double*>(t); t += up8(kernel_b);
+    int* blanks_d = reinterpret_cast<int*>(t); t += up8(blanks_b);
+    float* cosw_d = reinterpret_cast<float*>(t); t += up8(cosw_b);
+    int* valid_d = reinterpret_cast<int*>(t); t += up8(valid_b);
+    float* max_d = reinterpret_cast<float*>(t);
+    e = hipMemcpyAsync(kernel_d, kernel.data(), kernel_b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && blanks_b) e = hipMemcpyAsync(blanks_d, cfg->blanks, blanks_b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && cosw_b) e = hipMemcpyAsync(cosw_d, cosw.data(), cosw_b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && valid_b) e = hipMemcpyAsync(valid_d, valid.data(), valid_b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && !on_device)
+        e = hipMemcpyAsync(staging_in, images, sizeof(float) * img_floats * n, hipMemcpyHostToDevice, ctx->stream);
+
+    EccPreprocessParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.in = on_device ? images : staging_in;
+    p.out = (on_device && !in_place) ? out : staging_out;
+    p.stride = (int64_t)img_floats;
+    p.n_img = n;
+    p.n_u = n_u;
+    p.n_v = n_v;
+    p.process = cfg->process ? 1 : 0;
+    p.normalize = cfg->normalize ? 1 : 0;
+    p.scale = (float)cfg->scale;  // ref: Gui/PreProccess.cpp:63-64
+    p.bias = (float)cfg->bias;
+    p.max_d = max_d;
+    p.apply_log = cfg->apply_log ? 1 : 0;
+    p.flip_u = cfg->flip_u ? 1 : 0;
+    p.flip_v = cfg->flip_v ? 1 : 0;
+    for (int s = 0; s < 4; ++s) {
+        p.zero[s] = cfg->zero[s];
+        p.feather[s] = cfg->feather[s];
+    }
+    p.n_blanks = cfg->n_blanks;
+    p.blanks = blanks_d;
+    p.k = k;
+    p.kernel = kernel_d;
+    p.cosw = Ps ? cosw_d : nullptr;
+    p.cosw_valid = Ps ? valid_d : nullptr;
+    if (ctx->timing && e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
+    if (e == hipSuccess) e = ecc_launch_preprocess(&p, ctx->stream);
+    if (ctx->timing && e == hipSuccess) {
+        e = hipEventRecord(ctx->ev[5], ctx->stream);
+        ctx->ev_valid[2] = true;
+    }
+    if (e == hipSuccess && in_place)
+        e = hipMemcpyAsync(out, staging_out, sizeof(float) * img_floats * n, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && !on_device)
+        e = hipMemcpyAsync(out, staging_out, sizeof(float) * img_floats * n, hipMemcpyDeviceToHost, ctx->stream);
+    // the host tables and the scratch buffers go out of scope here
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    HIP_TRY(e);
     return ECC_OK;
 }

@@ -179,5 +179,28 @@ ECC_HD inline double object_radius(const double* P, int n_u, int n_v)
     return sin(fov) * sqrt(C[0] * C[0] + C[1] * C[1] + C[2] * C[2]);
 }
 
+// Intrinsics the cosine weighting needs: K(0,0), K(0,2), K(1,2) of P = K [R|t], K upper triangular with
+// positive diagonal and K(2,2) = 1 (ref: LibProjectiveGeometry/ProjectionMatrix.cpp:25-67, getCameraIntrinsics;
+// used at Gui/PreProccess.cpp:152-155).  The reference factorises with Eigen's Householder QR; this is the same
+// RQ factorisation by Gram-Schmidt on the rows of M = P(:,0:3) in binary64 (agrees to ~1e-13).
+ECC_HD inline void intrinsics(const double* P, float* sdd_px, float* ppu, float* ppv)
+{
+    const double m1[3] = {P[0], P[3], P[6]}, m2[3] = {P[1], P[4], P[7]}, m3[3] = {P[2], P[5], P[8]};
+    const double K22 = sqrt(m3[0] * m3[0] + m3[1] * m3[1] + m3[2] * m3[2]);
+    const double r3[3] = {m3[0] / K22, m3[1] / K22, m3[2] / K22};
+    const double K12 = m2[0] * r3[0] + m2[1] * r3[1] + m2[2] * r3[2];
+    const double v[3] = {m2[0] - K12 * r3[0], m2[1] - K12 * r3[1], m2[2] - K12 * r3[2]};
+    const double K11 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const double r2[3] = {v[0] / K11, v[1] / K11, v[2] / K11};
+    const double K02 = m1[0] * r3[0] + m1[1] * r3[1] + m1[2] * r3[2];
+    const double K01 = m1[0] * r2[0] + m1[1] * r2[1] + m1[2] * r2[2];
+    const double w[3] = {m1[0] - K02 * r3[0] - K01 * r2[0], m1[1] - K02 * r3[1] - K01 * r2[1],
+                         m1[2] - K02 * r3[2] - K01 * r2[2]};
+    const double K00 = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    *sdd_px = (float)(K00 / K22);
+    *ppu = (float)(K02 / K22);
+    *ppv = (float)(K12 / K22);
+}
+
 }  // namespace ecc_host
 #endif

@@ -63,6 +63,27 @@ struct EccPairParams {
     int use_corr;              // MetricRadonIntermediate::useCorrelation (ref: ...RadonIntermediate.cu:116-149)
 };
 
+// ---- projection pre-processing ------------------------------------------------
+struct EccPreprocessParams {
+    const float* in;          // n_img images, n_v x n_u, u fastest
+    float* out;               // same shape; must not alias `in` (tiles read halos of their neighbours)
+    int64_t stride;           // floats between images
+    int n_img, n_u, n_v;
+    int process;              // 0: skip PreProccess::process, cosine weighting only
+    int normalize;
+    float scale, bias;
+    float* max_d;             // n_img floats (normalize)
+    int apply_log;
+    int flip_u, flip_v;
+    int zero[4], feather[4];  // left, right, bottom, top
+    int n_blanks;
+    const int* blanks;        // n_blanks x 4 on the device
+    int k;                    // half kernel width of the low-pass, 0 = off
+    const double* kernel;     // 2k+1 doubles on the device
+    const float* cosw;        // n_img x 3 (sdd_px, ppu, ppv) or null
+    const int* cosw_valid;    // n_img flags: 0 when the projection matrix is all zero (ref: PreProccess.cpp:149)
+};
+
 // ---- evaluateForImagePair (E7, visualisation) -------------------------------------------------
 struct EccPairSamplesParams {
     const float* dtr0;       // slab of view i

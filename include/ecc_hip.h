@@ -110,6 +110,37 @@ int ecc_dtr_wrap_device(ecc_ctx* ctx, float* base, int n_alpha, int n_t, int n_u
                         ecc_dtr** out);
 int ecc_dtr_destroy(ecc_dtr* dtr);
 
+/* ---- projection pre-processing (the step in front of R1) ------------------------------------- */
+/* ref: struct EpipolarConsistency::PreProccess (Gui/PreProccess.h:14-50), same fields and defaults
+ * (ecc_preprocess_defaults).  Offsets in zero/feather are left, right, bottom, top; blanks are
+ * n_blanks x 4 int32 (x0, y0, x1, y1) on the host. */
+typedef struct ecc_preprocess_config {
+    int32_t process;            /* 1: run PreProccess::process; 0: cosine weighting only            */
+    int32_t normalize;          /* Intensity/Normalize                                               */
+    double bias, scale;         /* Intensity/Bias, Intensity/Scale                                   */
+    int32_t apply_log;          /* Intensity/Apply Minus Logarithm                                   */
+    double gaussian_sigma;      /* Lowpass Filter/Gaussian Sigma   (1.84)                            */
+    int32_t half_kernel_width;  /* Lowpass Filter/Half Kernel Width (5); at most 16 here            */
+    int32_t flip_u, flip_v;     /* Geometry/Flip u-Axis, Flip v-Axis                                 */
+    int32_t zero[4];            /* Border/Zero Border (1,1,1,1)                                      */
+    int32_t feather[4];         /* Border/Feather (16,16,16,16)                                      */
+    int32_t n_blanks;
+    const int32_t* blanks;      /* Border/Blanks                                                     */
+} ecc_preprocess_config;
+void ecc_preprocess_defaults(ecc_preprocess_config* cfg);
+
+/* ref: PreProccess::process(img) followed by PreProccess::apply_weight_cos_principal_ray(img, P)
+ * (Gui/PreProccess.cpp:57-166; call order of Gui/InputDataDirect.cpp:85-86) for a stack of n images, as ONE
+ * fused device kernel (intensity, border zero/feather, blanks, flips, Gaussian low-pass with the reference's
+ * dropped last tap, cosine weight).  images / out: n * n_u * n_v floats, both on the host
+ * (on_device = 0) or both on ctx's device (= 1); out may equal images (in place, like the reference).
+ * Ps: n x 12 float64 column-major or NULL (no cosine weighting; an all-zero matrix skips that view,
+ * PreProccess.cpp:149).  Asynchronous on the context's stream when on_device = 1 and out != images. */
+int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, float* out, int n, int n_u, int n_v,
+                   const ecc_preprocess_config* cfg, const double* Ps);
+/* K(0,0), K(0,2), K(1,2) of P = K[R|t] (ref: getCameraIntrinsics, ProjectionMatrix.cpp:61-67). */
+void ecc_host_intrinsics(const double* P, float* sdd_px, float* ppu, float* ppv);
+
 /* ---- metric (E1..E5) ----------------------------------------------------------------------- */
 /* ref: MetricRadonIntermediate(Ps, dtrs) / setRadonIntermediates (…RadonIntermediate.cpp:53-66,87-106).
  * The metric borrows the dtrs ("DO NOT delete or change _dtrs during lifetime", .h:45).  Sizes and
@@ -189,7 +220,8 @@ void ecc_host_source_position(const double* P, float* C4);
 double ecc_host_object_radius(const double* P, int n_u, int n_v);
 
 /* Last kernel timings measured with HIP events on the context's stream (ms), for bench.py:
- * which = 0 pair kernel of the last evaluate, 1 Radon kernel of the last radon_compute[_batch].
+ * which = 0 pair kernel of the last evaluate, 1 Radon kernel of the last radon_compute[_batch],
+ * 2 pre-processing kernel of the last ecc_preprocess.
  * Timing is off by default (no events recorded); enable with ecc_ctx_enable_timing. */
 int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable);
 int ecc_ctx_last_kernel_ms(ecc_ctx* ctx, int which, float* ms);

@@ -255,6 +255,51 @@ def evaluate_for_image_pair(Ps, dtrs, i, j, n_u, n_v, object_radius_mm=0.0, dkap
                 radon1=r1[:2 * n].reshape(n, 2), K01=K01)
 
 
+class PreprocessParams(C.Structure):
+    """Mirror of eccor_preprocess_params (defaults = the reference's, Gui/PreProccess.h:19-45)."""
+    _fields_ = [("process", C.c_int), ("normalize", C.c_int), ("bias", C.c_double), ("scale", C.c_double),
+                ("apply_log", C.c_int), ("gaussian_sigma", C.c_double), ("half_kernel_width", C.c_int),
+                ("flip_u", C.c_int), ("flip_v", C.c_int), ("zero", C.c_int * 4), ("feather", C.c_int * 4),
+                ("n_blanks", C.c_int), ("blanks", C.c_void_p)]
+
+
+def preprocess_params(normalize=False, bias=0.0, scale=1.0, apply_log=False, gaussian_sigma=1.84,
+                      half_kernel_width=5, flip_u=False, flip_v=False, zero=(1, 1, 1, 1), feather=(16, 16, 16, 16),
+                      blanks=(), process=True):
+    p = PreprocessParams()
+    p.process, p.normalize, p.bias, p.scale, p.apply_log = int(process), int(normalize), bias, scale, int(apply_log)
+    p.gaussian_sigma, p.half_kernel_width, p.flip_u, p.flip_v = gaussian_sigma, half_kernel_width, int(flip_u), int(flip_v)
+    p.zero = (C.c_int * 4)(*zero)
+    p.feather = (C.c_int * 4)(*feather)
+    bl = np.ascontiguousarray(np.asarray(blanks, np.int32).reshape(-1, 4))
+    p.n_blanks = len(bl)
+    p._keep = bl
+    p.blanks = bl.ctypes.data if len(bl) else None
+    return p
+
+
+def preprocess(img, P=None, **kw):
+    """ref: PreProccess::process + apply_weight_cos_principal_ray (Gui/PreProccess.cpp:57-166); returns a copy."""
+    L = lib()
+    L.eccor_preprocess.argtypes = [_f32p, C.c_int, C.c_int, C.POINTER(PreprocessParams)]
+    L.eccor_cos_weight.argtypes = [_f32p, C.c_int, C.c_int, _f64p]
+    out = np.ascontiguousarray(img, np.float32).copy()
+    n_v, n_u = out.shape
+    p = preprocess_params(**kw)
+    L.eccor_preprocess(out, n_u, n_v, C.byref(p))
+    if P is not None:
+        L.eccor_cos_weight(out, n_u, n_v, _P(P))
+    return out
+
+
+def intrinsics(P):
+    L = lib()
+    L.eccor_intrinsics.argtypes = [_f64p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    L.eccor_intrinsics(_P(P), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 def set_variant(v):
     """0 = normative fp32 path (correctly rounded elementary functions); 1 = line->(angle,distance)
     mapping in binary64 (noise-floor probe); 2 = platform float libm (what oracle/_ref is built on)."""

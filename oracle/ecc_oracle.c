@@ -800,6 +800,184 @@ ECCOR_API int eccor_evaluate_for_image_pair(const double *P0, const double *P1, 
     return n;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* (f-1) projection pre-processing, the step in front of R1                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* ref: LibEpipolarConsistency/Gui/PreProccess.cpp:8-13 (weighting, the double overload used there) */
+static double or_weighting_d(double x)
+{
+    double xx;
+    if (x < -1.0 || x > 1.0) return 0;
+    xx = x * x;
+    return 1.0 - 2 * xx + xx * xx;
+}
+
+typedef struct {
+    int process;              /* 0: skip process(), only the cosine weighting (if P given) */
+    int normalize;            /* Intensity/Normalize */
+    double bias, scale;       /* Intensity/Bias, Intensity/Scale */
+    int apply_log;            /* Intensity/Apply Minus Logarithm */
+    double gaussian_sigma;    /* Lowpass Filter/Gaussian Sigma (default 1.84) */
+    int half_kernel_width;    /* Lowpass Filter/Half Kernel Width (default 5) */
+    int flip_u, flip_v;
+    int zero[4];              /* left, right, bottom, top (default 1) */
+    int feather[4];           /* default 16 */
+    int n_blanks;
+    const int *blanks;        /* n_blanks x 4: x0, y0, x1, y1 */
+} eccor_preprocess_params;
+
+/* ref: HeaderOnly/NRRD/nrrd_lowpass.hxx:19-33 (gaussianKernel): 2k+1 taps, normalised over all of them */
+ECCOR_API void eccor_gaussian_kernel(double sigma, int k, double *kernel)
+{
+    int n = 2 * k + 1, x, i;
+    double sum = 0;
+    for (x = -k; x <= k; x++) {
+        double v = exp(-0.5 * pow(x / sigma, 2));
+        sum += v;
+        kernel[x + k] = v;
+    }
+    for (i = 0; i < n; i++) kernel[i] /= sum;
+}
+
+/* In place on one n_u x n_v float image (row-major, u fastest).
+ * ref: Gui/PreProccess.cpp:57-144 (PreProccess::process), step by step in its order:
+ * intensity (normalise / scale+bias / -log / zero negatives, NaN, Inf), border zero + feather on the four
+ * sides (left and top start at b = 0 and zero b <= zero[.], right and bottom start at b = 1 -- kept as
+ * written), blanks, flips, Gaussian low-pass (HeaderOnly/NRRD/nrrd_lowpass.hxx:45-79: both passes run
+ * o = -k .. k-1, i.e. the last tap is dropped, both use kernelx, sums in double, clamp addressing).
+ * std::log on a float is logf; taken correctly rounded like every elementary function of this oracle.
+ * Not replicated: out-of-bounds writes of the reference when a border band or a blank exceeds the image
+ * (bands and blanks are clipped to the image; the blank's y < img.size(0) bound, :117, is kept AND clipped). */
+ECCOR_API void eccor_preprocess(float *img, int n_u, int n_v, const eccor_preprocess_params *p)
+{
+    const int l = n_u * n_v;
+    int i, x, y, b, q;
+    if (!p->process) return;
+    {
+        float scale = (float)p->scale, bias = (float)p->bias;
+        if (p->normalize) {
+            float max = img[0];
+            for (i = 0; i < l; i++)
+                if (img[i] > max) max = img[i];
+            bias = 0;
+            scale = (float)p->scale / max;
+        }
+        for (i = 0; i < l; i++) {
+            float pixel = img[i] * scale + bias;
+            if (p->apply_log) pixel = (float)-(g_variant == 2 ? logf(pixel) : (float)log((double)pixel));
+            if (pixel < 0 || isnan(pixel) || isinf(pixel)) pixel = 0;
+            img[i] = pixel;
+        }
+    }
+    /* left */
+    for (y = 0; y < n_v; y++)
+        for (b = 0; b < p->zero[0] + p->feather[0] && b < n_u; b++)
+            img[b + (size_t)y * n_u] *= b <= p->zero[0] ? 0 : (float)or_weighting_d(1 - (float)(b - p->zero[0]) / p->feather[0]);
+    /* right */
+    for (y = 0; y < n_v; y++)
+        for (b = 1; b <= p->zero[1] + p->feather[1] && b <= n_u; b++)
+            img[(n_u - b) + (size_t)y * n_u] *= b <= p->zero[1] ? 0 : (float)or_weighting_d(1 - (float)(b - p->zero[1]) / p->feather[1]);
+    /* bottom */
+    for (b = 1; b <= p->zero[2] + p->feather[2] && b <= n_v; b++)
+        for (x = 0; x < n_u; x++)
+            img[x + (size_t)(n_v - b) * n_u] *= b <= p->zero[2] ? 0 : (float)or_weighting_d(1 - (float)(b - p->zero[2]) / p->feather[2]);
+    /* top */
+    for (b = 0; b < p->zero[3] + p->feather[3] && b < n_v; b++)
+        for (x = 0; x < n_u; x++)
+            img[x + (size_t)b * n_u] *= b <= p->zero[3] ? 0 : (float)or_weighting_d(1 - (float)(b - p->zero[3]) / p->feather[3]);
+    /* blanks */
+    for (q = 0; q < p->n_blanks; q++) {
+        const int *bl = p->blanks + 4 * q;
+        for (y = bl[1] > 0 ? bl[1] : 0; y < n_u && y < bl[3] && y < n_v; y++)
+            for (x = bl[0] > 0 ? bl[0] : 0; x < n_u && x < bl[2]; x++) img[x + (size_t)y * n_u] = 0;
+    }
+    /* flips */
+    if (p->flip_u)
+        for (y = 0; y < n_v; y++)
+            for (x = 0; x < n_u / 2; x++) {
+                float t = img[x + (size_t)y * n_u];
+                img[x + (size_t)y * n_u] = img[(n_u - 1 - x) + (size_t)y * n_u];
+                img[(n_u - 1 - x) + (size_t)y * n_u] = t;
+            }
+    if (p->flip_v)
+        for (y = 0; y < n_v / 2; y++)
+            for (x = 0; x < n_u; x++) {
+                float t = img[x + (size_t)y * n_u];
+                img[x + (size_t)y * n_u] = img[x + (size_t)(n_v - 1 - y) * n_u];
+                img[x + (size_t)(n_v - 1 - y) * n_u] = t;
+            }
+    /* low-pass */
+    if (p->gaussian_sigma > 0 && p->half_kernel_width > 1) {
+        const int k = p->half_kernel_width;
+        double *kernel = (double *)malloc(sizeof(double) * (2 * k + 1));
+        float *work = (float *)malloc(sizeof(float) * (size_t)l);
+        int o;
+        eccor_gaussian_kernel(p->gaussian_sigma, k, kernel);
+        for (y = 0; y < n_v; y++)
+            for (x = 0; x < n_u; x++) {
+                double sum = 0;
+                for (o = -k; o < k; o++) {
+                    int xo = x + o < 0 ? 0 : (x + o > n_u - 1 ? n_u - 1 : x + o);
+                    sum += img[xo + (size_t)y * n_u] * kernel[o + k];
+                }
+                work[x + (size_t)y * n_u] = (float)sum;
+            }
+        for (x = 0; x < n_u; x++)
+            for (y = 0; y < n_v; y++) {
+                double sum = 0;
+                for (o = -k; o < k; o++) {
+                    int yo = y + o < 0 ? 0 : (y + o > n_v - 1 ? n_v - 1 : y + o);
+                    sum += work[x + (size_t)yo * n_u] * kernel[o + k];
+                }
+                img[x + (size_t)y * n_u] = (float)sum;
+            }
+        free(kernel);
+        free(work);
+    }
+}
+
+/* Intrinsics used by the cosine weighting: K(0,0), K(0,2), K(1,2) of P = K [R|t] with K upper triangular,
+ * positive diagonal, K(2,2) = 1.  The reference gets K from Eigen's Householder QR of the row-permuted
+ * transpose (ref: LibProjectiveGeometry/ProjectionMatrix.cpp:25-58, projectionMatrixDecomposition); Eigen is
+ * absent here, this is the same RQ factorisation by Gram-Schmidt on the rows of M = P(:,0:3) in binary64
+ * (agrees to ~1e-13 relative, then cast to float as the caller does, Gui/PreProccess.cpp:153-155). */
+ECCOR_API void eccor_intrinsics(const double *P, float *sdd_px, float *ppu, float *ppv)
+{
+    double m1[3] = {P[0], P[3], P[6]}, m2[3] = {P[1], P[4], P[7]}, m3[3] = {P[2], P[5], P[8]};
+    double K22 = sqrt(m3[0] * m3[0] + m3[1] * m3[1] + m3[2] * m3[2]);
+    double r3[3] = {m3[0] / K22, m3[1] / K22, m3[2] / K22};
+    double K12 = m2[0] * r3[0] + m2[1] * r3[1] + m2[2] * r3[2];
+    double v[3] = {m2[0] - K12 * r3[0], m2[1] - K12 * r3[1], m2[2] - K12 * r3[2]};
+    double K11 = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double r2[3] = {v[0] / K11, v[1] / K11, v[2] / K11};
+    double K02 = m1[0] * r3[0] + m1[1] * r3[1] + m1[2] * r3[2];
+    double K01 = m1[0] * r2[0] + m1[1] * r2[1] + m1[2] * r2[2];
+    double w[3] = {m1[0] - K02 * r3[0] - K01 * r2[0], m1[1] - K02 * r3[1] - K01 * r2[1],
+                   m1[2] - K02 * r3[2] - K01 * r2[2]};
+    double K00 = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    *sdd_px = (float)(K00 / K22);
+    *ppu = (float)(K02 / K22);
+    *ppv = (float)(K12 / K22);
+}
+
+/* ref: Gui/PreProccess.cpp:146-166 (apply_weight_cos_principal_ray); P all zero -> no-op (:149) */
+ECCOR_API void eccor_cos_weight(float *img, int n_u, int n_v, const double *P)
+{
+    float sdd_px, ppu, ppv;
+    int u, v, z = 1;
+    for (u = 0; u < 12; u++) z = z && P[u] == 0;
+    if (z) return;
+    eccor_intrinsics(P, &sdd_px, &ppu, &ppv);
+    for (v = 0; v < n_v; v++)
+        for (u = 0; u < n_u; u++) {
+            float pou = (float)u - ppu;
+            float pov = (float)v - ppv;
+            float cos_weight = sdd_px / sqrtf(pou * pou + pov * pov + sdd_px * sdd_px);
+            img[u + (size_t)v * n_u] *= cos_weight;
+        }
+}
+
 ECCOR_API int eccor_num_threads(void)
 {
 #ifdef _OPENMP
