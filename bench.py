@@ -105,6 +105,15 @@ def main():
         radon_ms += ctx.last_kernel_ms("radon")
         del keep, imgs
     ms_per_radon = radon_ms / max(hi - lo, 1)
+    # pre-processing (the step in front of the Radon intermediate) on one sub-batch, device
+    # resident in and out, reference defaults + cosine weighting: HBM-bound, 8 B per pixel algorithmic
+    imgs = synthetic.projections_torch(Ps[lo:min(lo + sub, hi)], S, S, phantom, dev)
+    pre_out = torch.empty_like(imgs)
+    pp = E.PreProccess()
+    for _ in range(2):
+        pp.process(ctx, imgs, Ps[lo:min(lo + sub, hi)], out=pre_out)
+    ms_per_preprocess = ctx.last_kernel_ms("preprocess") / imgs.shape[0]
+    del imgs, pre_out
     if world > 1:
         if args.backend == "nccl":
             gathered = torch.empty_like(slabs_all)
@@ -183,6 +192,8 @@ def main():
                      "kernel": "pairs_kernel<true>", "kernel_ms": pair_ms,
                      "algorithmic_bytes_per_launch": launch_bytes},
         "ms_per_radon_intermediate": ms_per_radon,
+        "ms_per_preprocess": ms_per_preprocess,
+        "preprocess_hbm_GBs": 8.0 * S * S / (ms_per_preprocess * 1e-3) / 1e9 if ms_per_preprocess > 0 else 0.0,
         "pairs_per_s": n_pairs * args.steps / elapsed,
         "kappa_samples_per_s": n_pairs * n_kappa * args.steps / elapsed,
         "last_value": last,

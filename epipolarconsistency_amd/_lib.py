@@ -82,6 +82,16 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -m epipolarconsistency_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime; when libecc_hip.so (linked against /opt/rocm)
+        # initialises the GPU first, a later torch.cuda initialisation in the same process fails with "No HIP GPUs
+        # are available" (seen on the MI355X boxes).  The other order works, so let torch go first when it is there.
+        if not os.environ.get("ECC_NO_TORCH_PRELOAD"):
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol

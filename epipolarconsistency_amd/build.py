@@ -14,6 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libecc_hip.so")
 SOURCES = ["radon_kernel.hip", "ramp_kernel.hip", "preprocess_kernel.hip", "pairs_kernel.hip", "geometry_kernel.hip", "ecc_capi.hip"]
 HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", os.path.join("..", "..", "include", "ecc_hip.h")]
+# radon_kernel.hip: the SLP vectoriser packs the two samples of the derivative pair into v_pk_*_f32 pairs, which
+# cost two issue slots each on gfx950 (no gain, scripts/micro/valu_rate.hip) plus ~12 v_mov per iteration to
+# arrange operands -- scalar code is ~15 % faster there.
+PER_SOURCE_FLAGS = {"radon_kernel.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
@@ -33,7 +37,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
     objs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc] + FLAGS + PER_SOURCE_FLAGS.get(s, []) + list(extra_flags) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

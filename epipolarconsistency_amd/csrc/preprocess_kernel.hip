@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int PP_TW = 64, PP_TH = 64, PP_THREADS = 256;
+constexpr int PP_TW = 64, PP_TH = 64, PP_THREADS = 256;  // PP_TW = one wave per tile row
 
 // ref: Gui/PreProccess.cpp:8-13 (weighting, double)
 __device__ __forceinline__ double weighting_d(double x)
@@ -58,13 +58,24 @@ __device__ __forceinline__ float pointwise(const EccPreprocessParams& p, float v
     return pixel;
 }
 
+// KT: half kernel width known at compile time (taps live in registers, loops unroll), or -1 = runtime k with
+// the taps read from an LDS copy (a scalar load per tap inside the loop serialises on its latency: 10.8 -> x us).
+template <int KT>
 __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(EccPreprocessParams p)
 {
     extern __shared__ float lds[];
-    const int k = p.k;
+    const int k = KT >= 0 ? KT : p.k;
     const int AW = PP_TW + 2 * k, AH = PP_TH + 2 * k;
     float* A = lds;            // AH x AW : pixel-wise result incl. halo (clamped = the convolution's clamp addressing)
     float* B = lds + AH * AW;  // AH x PP_TW : after the horizontal pass
+    double* taps_lds = reinterpret_cast<double*>(B + AH * PP_TW);  // runtime-k path only (8-byte aligned: even counts)
+    double taps[KT > 0 ? 2 * KT : 1];
+    if (KT > 0) {
+#pragma unroll
+        for (int o = 0; o < 2 * KT; ++o) taps[o] = p.kernel[o];
+    } else if (KT < 0) {
+        if ((int)threadIdx.x < 2 * k) taps_lds[threadIdx.x] = p.kernel[threadIdx.x];
+    }
     const int img_i = blockIdx.z;
     const float* __restrict__ src = p.in + (int64_t)img_i * p.stride;
     float* __restrict__ dst = p.out + (int64_t)img_i * p.stride;
@@ -77,37 +88,52 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(EccPreprocessPar
         scale = p.scale / p.max_d[img_i];
     }
 
-    for (int e = threadIdx.x; e < AH * AW; e += PP_THREADS) {
-        const int ly = e / AW, lx = e - ly * AW;
-        const int gx = min(max(x0 + lx - k, 0), W - 1), gy = min(max(y0 + ly - k, 0), H - 1);
-        const int sx = p.flip_u ? W - 1 - gx : gx, sy = p.flip_v ? H - 1 - gy : gy;  // ref: :123-136
-        float v = src[(size_t)sy * W + sx];
-        if (p.process) v = pointwise(p, v, sx, sy, scale, bias);
-        A[e] = v;
+    // thread (tx, ty) walks rows ty, ty+4, ... and columns tx, tx+64, ...: no integer divisions, and the 64
+    // lanes of a wave read 64 consecutive texels (reversed when flipped)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int ly = ty; ly < AH; ly += PP_THREADS / 64) {
+        const int gy = min(max(y0 + ly - k, 0), H - 1);
+        const int sy = p.flip_v ? H - 1 - gy : gy;  // ref: :123-136
+        for (int lx = tx; lx < AW; lx += 64) {
+            const int gx = min(max(x0 + lx - k, 0), W - 1);
+            const int sx = p.flip_u ? W - 1 - gx : gx;
+            float v = src[(size_t)sy * W + sx];
+            if (p.process) v = pointwise(p, v, sx, sy, scale, bias);
+            A[ly * AW + lx] = v;
+        }
     }
     __syncthreads();
     if (k > 0) {
         // horizontal pass, ref: nrrd_lowpass.hxx:52-63 (o = -kx .. kx-1, double sum, result cast to T)
-        for (int e = threadIdx.x; e < AH * PP_TW; e += PP_THREADS) {
-            const int ly = e / PP_TW, lx = e - ly * PP_TW;
+        for (int ly = ty; ly < AH; ly += PP_THREADS / 64) {
             double sum = 0;
-            for (int o = -k; o < k; ++o) sum += A[ly * AW + lx + k + o] * p.kernel[o + k];
-            B[e] = (float)sum;
+            if (KT > 0) {
+#pragma unroll
+                for (int o = 0; o < 2 * KT; ++o) sum += A[ly * AW + tx + o] * taps[o];
+            } else {
+                for (int o = 0; o < 2 * k; ++o) sum += A[ly * AW + tx + o] * taps_lds[o];
+            }
+            B[ly * PP_TW + tx] = (float)sum;
         }
         __syncthreads();
     }
     const float sdd = p.cosw ? p.cosw[3 * img_i] : 0.f;
     const float ppu = p.cosw ? p.cosw[3 * img_i + 1] : 0.f, ppv = p.cosw ? p.cosw[3 * img_i + 2] : 0.f;
     const bool weight = p.cosw && p.cosw_valid[img_i];
-    for (int e = threadIdx.x; e < PP_TH * PP_TW; e += PP_THREADS) {
-        const int ly = e / PP_TW, lx = e - ly * PP_TW;
+    for (int ly = ty; ly < PP_TH; ly += PP_THREADS / 64) {
+        const int lx = tx;
         const int gx = x0 + lx, gy = y0 + ly;
         if (gx >= W || gy >= H) continue;
         float pixel;
         if (k > 0) {
             // vertical pass, ref: nrrd_lowpass.hxx:64-75 (uses kernelx again, o = -ky .. ky-1)
             double sum = 0;
-            for (int o = -k; o < k; ++o) sum += B[(ly + k + o) * PP_TW + lx] * p.kernel[o + k];
+            if (KT > 0) {
+#pragma unroll
+                for (int o = 0; o < 2 * KT; ++o) sum += B[(ly + o) * PP_TW + lx] * taps[o];
+            } else {
+                for (int o = 0; o < 2 * k; ++o) sum += B[(ly + o) * PP_TW + lx] * taps_lds[o];
+            }
             pixel = (float)sum;
         } else {
             pixel = A[ly * AW + lx];
@@ -153,7 +179,7 @@ __global__ __launch_bounds__(1024) void image_max_kernel(const float* __restrict
 extern "C" size_t ecc_preprocess_lds_bytes(int k)
 {
     const int AW = PP_TW + 2 * k, AH = PP_TH + 2 * k;
-    return sizeof(float) * ((size_t)AH * AW + (k > 0 ? (size_t)AH * PP_TW : 0));
+    return sizeof(float) * ((size_t)AH * AW + (k > 0 ? (size_t)AH * PP_TW : 0)) + sizeof(double) * 2 * (size_t)k;
 }
 
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream)
@@ -165,6 +191,12 @@ extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStr
         if (e != hipSuccess) return e;
     }
     dim3 grid((p->n_u + PP_TW - 1) / PP_TW, (p->n_v + PP_TH - 1) / PP_TH, p->n_img);
-    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(PP_THREADS), ecc_preprocess_lds_bytes(p->k), stream, *p);
+    const size_t lds = ecc_preprocess_lds_bytes(p->k);
+    if (p->k == 0)
+        hipLaunchKernelGGL(preprocess_kernel<0>, grid, dim3(PP_THREADS), lds, stream, *p);
+    else if (p->k == 5)  // the reference's default (Gui/PreProccess.h:28)
+        hipLaunchKernelGGL(preprocess_kernel<5>, grid, dim3(PP_THREADS), lds, stream, *p);
+    else
+        hipLaunchKernelGGL(preprocess_kernel<-1>, grid, dim3(PP_THREADS), lds, stream, *p);
     return hipGetLastError();
 }

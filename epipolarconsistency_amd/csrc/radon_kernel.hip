@@ -9,7 +9,8 @@
 //
 // What is different from the reference is the machine mapping:
 //   * no texture unit: the bilinear filter is the exact fp32 rule of SURVEY.md 8c, evaluated from
-//     an LDS tile (4 taps = 2 x ds_read2_b32) instead of 4 scattered global loads;
+//     an LDS tile (4 taps = 2 x ds_read2_b32) instead of 4 scattered global loads; built without the SLP
+//     vectoriser (build.py): v_pk_*_f32 pairs cost two issue slots each on gfx950 plus operand shuffles;
 //   * a workgroup owns RT_A = 16 adjacent angles x RT_T = 16 adjacent distances (256 threads).  Its lines are
 //     (nearly) parallel, so they sweep a narrow band of the image.  The band is walked in chunks
 //     along the line direction; for every chunk the axis-aligned bounding box of all sample
@@ -37,9 +38,17 @@ namespace {
 constexpr int RT_T = 16;                   // distance bins per workgroup (tid & 15)
 constexpr int RT_A = 16;                   // angle bins per workgroup    (tid >> 4)
 constexpr int RT_THREADS = RT_T * RT_A;    // 256
-constexpr int TILE_W = 96;                 // usable LDS tile width (texels)
-constexpr int TILE_H = 96;                 // LDS tile rows
-constexpr int TILE_S_MAX = 97;             // row stride is 97 or 95 floats (odd, see radon_kernel)
+// Tile shape: 96 x 96 floats (37 KB, 4 workgroups per CU) measured best; -DRT_TILE_W/H only for experiments
+// (scripts/radon_variants.sh: 64x64 0.97 ms, 96x80 0.79 ms, 96x96 0.76 ms per 1024^2 image).
+#ifndef RT_TILE_W
+#define RT_TILE_W 96
+#endif
+#ifndef RT_TILE_H
+#define RT_TILE_H 96
+#endif
+constexpr int TILE_W = RT_TILE_W;          // usable LDS tile width (texels)
+constexpr int TILE_H = RT_TILE_H;          // LDS tile rows
+constexpr int TILE_S_MAX = TILE_W + 1;     // row stride is TILE_W+1 or TILE_W-1 floats (odd, see radon_kernel)
 constexpr float RADON_STEP = .66f;         // ref: RadonIntermediate.cu:102
 constexpr int MAX_CHUNKS = 8192;           // bound on the chunk loop (every spin is bounded)
 
@@ -63,15 +72,16 @@ __device__ __forceinline__ float tex_global(const float* __restrict__ img, int W
 // Same rule on the staged tile.  tile_off = by0*TILE_S + bx0 (tile origin in image texels); the
 // tile already holds clamped (replicated) texels, so taps need no index clamps.
 template <int TILE_S>
-__device__ __forceinline__ float tex_lds(const float* tile, int tile_off, float x, float y)
+__device__ __forceinline__ float tex_lds(const float* tile_shifted, float x, float y)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
     float fi = floorf(xb), fj = floorf(yb);
     float fx = xb - fi, fy = yb - fj;
-    // fj*TILE_S + fi is an exact small integer in fp32 (|.| < 2^24) whether or not it is fused.
-    int idx = (int)(fj * (float)TILE_S + fi) - tile_off;
-    float T00 = tile[idx], T10 = tile[idx + 1];
-    float T01 = tile[idx + TILE_S], T11 = tile[idx + TILE_S + 1];
+    // fj*TILE_S + fi is an exact small integer in fp32 (|.| < 2^24) whether or not it is fused;
+    // tile_shifted = tile - tile_off folds the tile origin into the base (one v_lshl_add per sample).
+    const float* tp = tile_shifted + (int)(fj * (float)TILE_S + fi);
+    float T00 = tp[0], T10 = tp[1];
+    float T01 = tp[TILE_S], T11 = tp[TILE_S + 1];
     float r0 = (1.f - fx) * T00 + fx * T10;
     float r1 = (1.f - fx) * T01 + fx * T11;
     return (1.f - fy) * r0 + fy * r1;
@@ -107,12 +117,14 @@ struct RadonShared {
 };
 
 // TILE_S is the LDS row stride.  A half-wave is 16 adjacent distance bins x 2 adjacent angles, i.e.
-// sample points spaced 1.9 px along the line NORMAL (nx, ny).  ds_read_b32 banks are
+// sample points spaced 1.9 px along the line NORMAL (nx, ny).  ds_read2_b32 banks are
 // (j*TILE_S + i) mod 32: with stride 97 the bank advances by 1.9 (nx + ny) per lane, with 95 by
 // 1.9 (nx - ny); the kernel picks the one with the larger advance, so a half-wave never walks along an
-// iso-bank direction.  (Measured: bank conflicts are still ~55 % of LDS-active cycles -- 32 lanes
-// spread over ~60 texel rows/columns cannot all land on distinct banks of a linear layout; see
-// DESIGN.md 8.)
+// iso-bank direction.  Measured (profiles/): the LDS pipe is busy ~90 % of the kernel time and bank
+// conflicts are ~55 % of those cycles -- 32 lanes spread over >= 30 px of a line cannot all land on distinct
+// banks of a linear layout.  Tried and rejected: a float2 "texel pair" tile read with ds_read_b64 (256 B/clk,
+// 64 banks) halves the LDS cycles but doubles the tile to 74 KB = 2 workgroups per CU, and this kernel needs
+// >= 4 waves per SIMD to keep the VALU fed (2 WG/CU: 0.96 ms with the plain tile, 1.12 ms with pairs).
 template <bool DERIV, int TILE_S>
 __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared& sh)
 {
@@ -213,51 +225,65 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
         const float reach = fminf(g_far, fabsf(U) + (float)TILE_W);
         const float band = g_band + g_spread * reach;
         const float slack = g_spread * g_tau;
-        const float Lw = g_cs > 1e-3f ? ((float)(TILE_W - 4) - band * g_sn) / g_cs : 1e9f;
-        const float Lh = g_sn > 1e-3f ? ((float)(TILE_H - 4) - band * g_cs) / g_sn : 1e9f;
-        const float L = fminf(fmaxf(fminf(Lw, Lh) - slack, 4.f), 4096.f);
-        const float lim = (U + L) + tc;
+        const float Lw = g_cs > 1e-3f ? ((float)(TILE_W - 3) - band * g_sn) / g_cs : 1e9f;
+        const float Lh = g_sn > 1e-3f ? ((float)(TILE_H - 3) - band * g_cs) / g_sn : 1e9f;
+        float L = fminf(fmaxf(fminf(Lw, Lh) - slack, 4.f), 4096.f);
         const bool pending = active && (t <= t_max);  // samples left at all
-        const bool has = pending && (t < lim);        // samples inside this chunk
-        int bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
-        if (has) {
-            float tb = fminf(t_max, lim);
-            float xa = o0 + t * d0, ya = o1 + t * d1;
-            float xb = o0 + tb * d0, yb = o1 + tb * d1;
-            float xmin = fminf(xa, xb), xmax = fmaxf(xa, xb);
-            float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
-            if (DERIV) {
-                xmin = fminf(xmin, xmin + d1);
-                xmax = fmaxf(xmax, xmax + d1);
-                ymin = fminf(ymin, ymin - d0);
-                ymax = fmaxf(ymax, ymax - d0);
-            }
-            bx0 = (int)floorf(xmin - 0.5f) - 1;
-            bx1 = (int)floorf(xmax - 0.5f) + 2;
-            by0 = (int)floorf(ymin - 0.5f) - 1;
-            by1 = (int)floorf(ymax - 0.5f) + 2;
-        }
-        bx0 = wave_min_i(bx0);
-        by0 = wave_min_i(by0);
-        bx1 = wave_max_i(bx1);
-        by1 = wave_max_i(by1);
         const unsigned long long pend = __ballot(pending);
-        if (lane == 0) {
-            s_box[wave][0] = bx0;
-            s_box[wave][1] = by0;
-            s_box[wave][2] = bx1;
-            s_box[wave][3] = by1;
-            s_pend[wave] = pend != 0ull;
+        // The rule above is an estimate; the exact footprint decides.  If it does not fit, the chunk is halved
+        // (uniform decision, at most 4 times) rather than sampled from global memory, which costs ~200x per
+        // sample.
+        float lim;
+        bool has, fits, any;
+        int bx0, by0, bx1, by1, w, h;
+        for (int attempt = 0;; ++attempt) {
+            lim = (U + L) + tc;
+            has = pending && (t < lim);  // samples inside this chunk
+            bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
+            if (has) {
+                // Samples run over t in [t, min(t_max, pred(lim))]; fp32 o + t*d is monotone in t, so the two end
+                // points bound every sample exactly and the texels needed are floor(. - 0.5) of those bounds and
+                // their +1 neighbours.
+                float tb = fminf(t_max, lim);
+                float xa = o0 + t * d0, ya = o1 + t * d1;
+                float xb = o0 + tb * d0, yb = o1 + tb * d1;
+                float xmin = fminf(xa, xb), xmax = fmaxf(xa, xb);
+                float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
+                if (DERIV) {
+                    xmin = fminf(xmin, xmin + d1);
+                    xmax = fmaxf(xmax, xmax + d1);
+                    ymin = fminf(ymin, ymin - d0);
+                    ymax = fmaxf(ymax, ymax - d0);
+                }
+                bx0 = (int)floorf(xmin - 0.5f);
+                bx1 = (int)floorf(xmax - 0.5f) + 1;
+                by0 = (int)floorf(ymin - 0.5f);
+                by1 = (int)floorf(ymax - 0.5f) + 1;
+            }
+            bx0 = wave_min_i(bx0);
+            by0 = wave_min_i(by0);
+            bx1 = wave_max_i(bx1);
+            by1 = wave_max_i(by1);
+            if (lane == 0) {
+                s_box[wave][0] = bx0;
+                s_box[wave][1] = by0;
+                s_box[wave][2] = bx1;
+                s_box[wave][3] = by1;
+                s_pend[wave] = pend != 0ull;
+            }
+            __syncthreads();  // (A) boxes visible; every thread has left the previous chunk's tile
+            bx0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+            by0 = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
+            bx1 = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
+            by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+            any = bx1 >= bx0;
+            w = bx1 - bx0 + 1, h = by1 - by0 + 1;
+            fits = any && w <= (TILE_S < TILE_W ? TILE_S : TILE_W) && h <= TILE_H;
+            if (fits || !any || attempt == 4) break;
+            L *= 0.5f;
+            __syncthreads();  // everyone has read s_box before it is rewritten
         }
-        __syncthreads();  // (A) boxes visible; every thread has left the previous chunk's tile
         if (!(s_pend[0] | s_pend[1] | s_pend[2] | s_pend[3])) break;  // uniform: all lines done
-        bx0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
-        by0 = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
-        bx1 = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
-        by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
-        const bool any = bx1 >= bx0;
-        const int w = bx1 - bx0 + 1, h = by1 - by0 + 1;
-        const bool fits = any && w <= TILE_W && h <= TILE_H;
         if (tid == 0) { RSTAT(0, 1); RSTAT(1, fits ? 1 : 0); RSTAT(2, any ? 1 : 0); RSTAT(5, w > 0 ? w : 0); RSTAT(6, h > 0 ? h : 0); }
         if (fits) {
             // Stage the footprint: all of a thread's (up to 36) global loads are issued before the first
@@ -290,13 +316,15 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
         __syncthreads();  // (B) tile complete; s_box/s_pend may be rewritten by the next chunk
         if (has) {
             if (fits) {
-                const int tile_off = by0 * TILE_S + bx0;
+                const float* tile_shifted = tile - (by0 * TILE_S + bx0);
+                // t <= t_max && t < lim  <=>  t <= min(t_max, pred(lim)): one compare per step
+                const float t_end = fminf(t_max, nextafterf(lim, -FLT_MAX));
                 // ref: RadonIntermediate.cu:105-123 (t += step accumulates in fp32)
-                for (; t <= t_max && t < lim; t += RADON_STEP) {
+                for (; t <= t_end; t += RADON_STEP) {
                     RSTAT(4, 1);
                     float x = o0 + t * d0, y = o1 + t * d1;
-                    sum += tex_lds<TILE_S>(tile, tile_off, x, y);
-                    if (DERIV) sumo += tex_lds<TILE_S>(tile, tile_off, x + d1, y - d0);
+                    sum += tex_lds<TILE_S>(tile_shifted, x, y);
+                    if (DERIV) sumo += tex_lds<TILE_S>(tile_shifted, x + d1, y - d0);
                 }
             } else {
                 for (; t <= t_max && t < lim; t += RADON_STEP) {
@@ -339,9 +367,9 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
     const int ix0 = min((int)blockIdx.x * RT_A, p.n_alpha - 1);
     const float nx = -p.trig[2 * ix0], ny = p.trig[2 * ix0 + 1];
     if (fabsf(nx + ny) >= fabsf(nx - ny))
-        radon_body<DERIV, 97>(p, sh);
+        radon_body<DERIV, TILE_W + 1>(p, sh);
     else
-        radon_body<DERIV, 95>(p, sh);
+        radon_body<DERIV, TILE_W - 1>(p, sh);
 }
 
 // Replicate the border rows/columns of the private layout (clamp addressing, ecc_layout.h).
