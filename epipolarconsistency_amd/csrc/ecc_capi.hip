@@ -30,6 +30,7 @@ extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
+extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream);
 extern "C" size_t ecc_preprocess_lds_bytes(int k);
@@ -120,6 +121,8 @@ struct ecc_metric {
     int64_t indices_capacity = 0;
     float* K01_d = nullptr;
     int64_t K01_capacity = 0;
+    EccPairRecord* records_d = nullptr;  // per-pair geometry between k01_kernel and pairs_kernel
+    int64_t records_capacity = 0;
     double* sum_d = nullptr;
     double* Ps_d = nullptr;   // n x 12 float64 as handed over by the caller
     // pinned host staging
@@ -594,6 +597,7 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->cost_d) (void)hipFree(m->cost_d);
     if (m->indices_d) (void)hipFree(m->indices_d);
     if (m->K01_d) (void)hipFree(m->K01_d);
+    if (m->records_d) (void)hipFree(m->records_d);
     if (m->sum_d) (void)hipFree(m->sum_d);
     if (m->Ps_d) (void)hipFree(m->Ps_d);
     if (m->Ps_h) (void)hipHostFree(m->Ps_h);
@@ -710,11 +714,15 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     EccPairParams p;
     int rc = fill_pair_params(m, &p);
     if (rc) return rc;
+    rc = ensure_capacity(&m->records_d, &m->records_capacity, count > 0 ? count : 1, ctx->stream);
+    if (rc) return rc;
     p.first = first;
     p.count = count;
     p.pair_values = pair_values_d;
     p.cost = cost_d;
     p.K01_out = K01_d;
+    p.records = m->records_d;
+    HIP_TRY(ecc_launch_k01(&p, ctx->stream));
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
     if (ctx->timing) {
@@ -821,10 +829,14 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     EccPairParams p;
     rc = fill_pair_params(m, &p);
     if (rc) return rc;
+    rc = ensure_capacity(&m->records_d, &m->records_capacity, n_pairs, ctx->stream);
+    if (rc) return rc;
     p.indices = m->indices_d;
     p.first = 0;
     p.count = n_pairs;
     p.pair_values = m->pair_values_d;
+    p.records = m->records_d;
+    HIP_TRY(ecc_launch_k01(&p, ctx->stream));
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
     if (ctx->timing) {

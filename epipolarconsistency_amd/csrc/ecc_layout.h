@@ -41,6 +41,16 @@ struct EccRadonParams {
 };
 
 // ---- pair kernel ---------------------------------------------------------------------------
+// What k01_kernel hands to pairs_kernel for one pair (96 bytes, read with scalar loads).
+struct EccPairRecord {
+    float K0[8];   // ref: computeK01 (EpipolarConsistencyCommon.hxx:93-149): K0[6] baseline distance, K0[7] view angle
+    float K1[8];   // K1[6] dkappa, K1[7] kappa_max
+    int iD0, iD1;  // Radon intermediates of the two views
+    int ci, cj;    // cost-image position (all-pairs mode)
+    int it_small;  // reserved (0)
+    int pad[3];
+};
+
 struct EccPairParams {
     const float* const* dtrs;  // device table of slab base pointers, one per dtr
     const float* Cs;           // 4 floats per view  (source positions, w = 1)
@@ -49,6 +59,7 @@ struct EccPairParams {
     float* pair_values;        // optional, `count` floats (local pair order)
     float* cost;               // optional n x n cost image (index i + j*n)
     float* K01_out;            // optional debug output, 16 floats per pair
+    EccPairRecord* records;    // `count` records, written by k01_kernel, read by pairs_kernel
     int64_t first;             // first pair (get_ij order) handled by this launch
     int64_t count;             // pairs handled by this launch
     int n_views;

@@ -1,10 +1,10 @@
 // pairs_kernel.hip -- all-pairs / index-list epipolar-consistency kernel for gfx950.
 //
-// One launch does what the reference needs two kernels, two device-wide syncs and N_kappa float
-// atomics per pair for (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cu):
-//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> computed in-kernel by the wave that owns the
-//                                                    pair, kept in SGPRs, never written to HBM;
-//   kernelEpipolarCosistency<deriv,false> (:152-276) -> one wave64 per pair, kappa samples strided
+// Two stream-ordered launches do what the reference needs two kernels, two device-wide syncs and N_kappa
+// float atomics per pair for (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cu):
+//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> k01_kernel, one thread per pair, 96-byte records that the
+//                                                    pair kernel reads with scalar loads (no sync in between);
+//   kernelEpipolarCosistency<deriv,false> (:152-276) -> pairs_kernel: one wave64 per pair, kappa samples strided
 //                                                    over the lanes, shuffle reduction, ONE plain store.
 // Sampling replaces tex2D on a normalised, clamped, bilinear texture (ref: RadonIntermediate.cpp:192)
 // by the exact fp32 rule of SURVEY.md 8c on the padded, distance-fast slab of ecc_layout.h: two
@@ -90,8 +90,8 @@ __device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0
 // The pair kernel.  Same algorithm as the reference, restructured for the CDNA4 vector ALU -- it is
 // bound by VALU issue (4 x (sqrt + atan2 + 2 divisions + bilinear) per kappa sample), not by memory:
 //   * one WAVE per pair (4 pairs per 256-thread workgroup, no barrier, no LDS): 64 lanes x 23
-//     iterations cover N_kappa = 1448 with 98 % lane utilisation; K01 is wave-uniform and lives in
-//     SGPRs (readfirstlane);
+//     iterations cover N_kappa = 1448 with 98 % lane utilisation; K01 comes from k01_kernel's record by
+//     scalar loads and lives in SGPRs;
 //   * +kappa and -kappa share the six products K[:,0]*cos, K[:,1]*sin (x(-kappa) = (-cos, sin));
 //   * the (alpha+pi, -t) periodicity fold is a sign-bit operation on the line instead of the
 //     reference's atan2 range tests: a line with l1 < 0 is negated (same point set), which maps
@@ -115,11 +115,13 @@ __device__ __forceinline__ float uniformf(float v)
 }
 
 // sin and cos of kappa in [0, pi/2]: reduce to [0, pi/4] by kappa -> pi/2 - kappa (exact subtraction
-// of the high part, Sterbenz), then degree-7 / degree-8 kernels.
+// of the high part, Sterbenz), then degree-7 / degree-8 kernels.  REDUCE = false when the whole pair stays
+// below pi/4 (kappa_max <= pi/4, wave-uniform): no reduction, no selects.
+template <bool REDUCE>
 __device__ __forceinline__ void sincos_quadrant(float kappa, float& s, float& c)
 {
     const float pio2_hi = 1.57079637050628662109375f, pio2_lo = -4.37113900018624283e-8f;
-    const bool swap = kappa > 0.785398163397448f;
+    const bool swap = REDUCE && kappa > 0.785398163397448f;
     const float r = swap ? (pio2_hi - kappa) + pio2_lo : kappa;
     const float z = r * r;
     float ps = fmaf(fmaf(-1.958291686605662e-04f, z, 8.332724682986736e-03f), z, -1.66666641831398e-01f);
@@ -167,35 +169,40 @@ __device__ __forceinline__ float atan_over_pi_small(float t)
 // Instruction selection follows measured gfx950 issue costs (scripts/micro/valu_rate.hip):
 // v_fma/v_add/v_xor 2 cycles per wave64, v_floor/v_fract/v_cvt 4, v_cmp+v_cndmask 8 per pair,
 // v_rcp/v_rsq 8.6 -- so selects are replaced by sign-bit arithmetic and a wave-uniform branch.
-template <bool DERIV>
+// PITCH4 > 0: row pitch in bytes known at
+// compile time (the 768-bin default), the second row's load then uses an immediate offset.
+template <bool DERIV, int PITCH4>
 __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
-                                             float n_t_f, float inv_range_t, float pitch4_f)
+                                             float n_t_f, float dist_scale, float dist_bias, float pitch4_f)
 {
-    // fold: negate the line when its normal points to negative y (the reference's a > 1 branch)
+    // fold: a line whose normal points to negative y is negated (the reference's a > 1 branch).  l0/l1 is
+    // invariant under the negation, so only the distance term and the sample take the sign.
     const unsigned m = __float_as_uint(l1) & 0x80000000u;
-    l0 = __uint_as_float(__float_as_uint(l0) ^ m);
-    l1 = __uint_as_float(__float_as_uint(l1) ^ m);
-    l2 = __uint_as_float(__float_as_uint(l2) ^ m);
     const float inv = __builtin_amdgcn_rsqf(fmaf(l0, l0, l1 * l1));
-    const float d = fmaf(-(l2 * inv), inv_range_t, 0.5f);
+    const float l2f = __uint_as_float(__float_as_uint(l2) ^ m);
+    const float al1 = fabsf(l1);
 
-    // r = angle(l0, l1) / pi in [0, 1] as cq + u, cq in {0, 1/2, 1}, |u| <= 1/4 (l1 >= 0 here).
+    // r = angle(l0, l1) / pi in [0, 1] as cq + u, cq in {0, 1/2, 1}, |u| <= 1/4 (for the folded line, l1 >= 0).
     float cq, u;
+    const float fl0 = __uint_as_float(__float_as_uint(l0) ^ m);
     const float ax = fabsf(l0);
-    if (__builtin_amdgcn_ballot_w64(ax > 0.3f * l1) == 0) {
+    if (__builtin_amdgcn_ballot_w64(ax > 0.3f * al1) == 0) {
         // every lane of the wave has a line within 16.7 deg of the image x axis (normal close to y):
         // r = 1/2 - atan(l0 / l1) / pi with the short polynomial.  This is the case almost all pairs of a
-        // circular C-arm scan are in.
+        // circular C-arm scan are in.  (Deciding it once per pair from a bound on K instead of per sample
+        // was tried -- as a separate branch-free loop, 0.57 ms, and as a scalar flag, no change from this
+        // form's 0.49 ms: the test and the ballot are cheap, and the branches give the scheduler block
+        // boundaries that keep each sample's loads ahead of the next sample's arithmetic.)
         cq = 0.5f;
-        u = -atan_over_pi_small(l0 * __builtin_amdgcn_rcpf(l1));
-    } else if (__builtin_amdgcn_ballot_w64(l1 < ax) == 0) {
+        u = -atan_over_pi_small(fl0 * __builtin_amdgcn_rcpf(al1));
+    } else if (__builtin_amdgcn_ballot_w64(al1 < ax) == 0) {
         cq = 0.5f;  // within 45 deg
-        u = -atan_over_pi(l0 * __builtin_amdgcn_rcpf(l1));
+        u = -atan_over_pi(fl0 * __builtin_amdgcn_rcpf(al1));
     } else {
-        const bool steep = l1 >= ax;
-        const float num = steep ? l0 : l1, den = steep ? l1 : l0;  // signed quotient, |num/den| <= 1
+        const bool steep = al1 >= ax;
+        const float num = steep ? fl0 : al1, den = steep ? al1 : fl0;  // signed quotient, |num/den| <= 1
         const float p = atan_over_pi(num * __builtin_amdgcn_rcpf(den));
-        cq = steep ? 0.5f : (l0 < 0.f ? 1.0f : 0.0f);
+        cq = steep ? 0.5f : (fl0 < 0.f ? 1.0f : 0.0f);
         u = steep ? -p : p;
     }
     // The reference divides by the FLOAT constant Pi = 3.14159265359f = pi (1 + e), e = 2.78e-8
@@ -203,26 +210,123 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     // a = r + e (1 - r) on the folded (+2, -1) branch.  That 1e-5-bin shift of the sampling angle moves
     // the 400-view metric by 1.7e-5 (profiles/r01_parity_probes.txt), so it is reproduced here; the
     // correction is added to the small term u BEFORE the one rounding against cq, otherwise it would
-    // vanish below half an ulp of a.
+    // vanish below half an ulp of a.  folded ? 1 : 0 = 0.5 * bitcast(m >> 1) (0x40000000 = 2.0f).
     const float e = 2.7827534e-8f;
-    const float folded01 = __uint_as_float((unsigned)((int)m >> 31) & 0x3f800000u);  // 1.0f if folded else 0.0f
-    const float a = cq + fmaf(folded01 - (cq + u), e, u);
+    const float f_minus_r = fmaf(__uint_as_float(m >> 1), 0.5f, -(cq + u));
+    const float a = cq + fmaf(f_minus_r, e, u);
 
     // texel position a*n_alpha - .5, d*n_t - .5 (normalised coordinates), expressed
     // directly in the slab's padded coordinates (+1): the replicated border stands in for clamp
-    // addressing and all byte offsets are non-negative (saddr + 32-bit voffset loads)
+    // addressing and all byte offsets are non-negative (saddr + 32-bit voffset loads).
+    // d*n_t + .5 = (-(l2/len)/range_t + .5)*n_t + .5 in one fma: dist_scale = n_t/range_t, dist_bias = .5 n_t + .5.
     const float xa = fmaf(a, n_alpha_f, 0.5f);
-    float yd = fmaf(d, n_t_f, 0.5f);
+    float yd = fmaf(-(l2f * inv), dist_scale, dist_bias);
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
     // byte offset floor(xa)*pitch4 + floor(yd)*4 formed exactly in fp32 (< 2^24), one conversion
-    const unsigned off = (unsigned)fmaf(xa - fx, pitch4_f, (yd - fy) * 4.0f);
-    const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);                // (i, j), (i, j+1)
-    const F2 c1 = *reinterpret_cast<const F2*>(sv.origin + (off + sv.pitch4));  // (i+1, j), (i+1, j+1)
+    const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 4.0f);
+#if defined(PK_EXP_NO_LOAD)   // timing experiment: no memory traffic at all (wrong results)
+    const F2 c0 = {__uint_as_float(off), fx}, c1 = {fy, xa};
+#elif defined(PK_EXP_ONE_LOAD)  // timing experiment: one 8-byte load per sample (wrong results)
+    const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);
+    const F2 c1 = {c0.y, c0.x};
+#else
+    const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);  // (i, j), (i, j+1)
+    const F2 c1 = PITCH4 > 0 ? *reinterpret_cast<const F2*>(sv.origin + off + PITCH4)
+                             : *reinterpret_cast<const F2*>(sv.origin + (off + sv.pitch4));  // (i+1, j), (i+1, j+1)
+#endif
     const float r0 = fmaf(fx, c1.x - c0.x, c0.x);
     const float r1 = fmaf(fx, c1.y - c0.y, c0.y);
     const float v = fmaf(fy, r1 - r0, r0);
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ m) : v;
+}
+
+// One kappa sample (four bilinear samples) of the pair loop; returns false when kappa is past kappa_max.
+template <bool DERIV, bool CORR, bool REDUCE, int PITCH4>
+__device__ __forceinline__ bool kappa_step(int k, const float (&K0)[8], const float (&K1)[8], float dkappa, float kappa_max,
+                                           const SlabView sv0, const SlabView sv1, float n_alpha_f, float n_t_f,
+                                           float dist_scale, float dist_bias, float pitch4_f, double& acc, double& mom2,
+                                           double& mom3, double& mom4)
+{
+    const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
+    if (kappa >= kappa_max) return false;
+    float sn, cs;
+    sincos_quadrant<REDUCE>(kappa, sn, cs);
+    // view 0
+    const float a00 = K0[0] * cs, a01 = K0[1] * cs, a02 = K0[2] * cs;
+    const float b00 = K0[3] * sn, b01 = K0[4] * sn, b02 = K0[5] * sn;
+    // view 1
+    const float a10 = K1[0] * cs, a11 = K1[1] * cs, a12 = K1[2] * cs;
+    const float b10 = K1[3] * sn, b11 = K1[4] * sn, b12 = K1[5] * sn;
+    const float v0p = sample_line<DERIV, PITCH4>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v1p = sample_line<DERIV, PITCH4>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v0m = sample_line<DERIV, PITCH4>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v1m = sample_line<DERIV, PITCH4>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    if (!CORR) {
+        const float vp = v0p - v1p, vm = v0m - v1m;
+        const float consistency = (vp * vp + vm * vm) * K0[6];  // ref: ...RadonIntermediate.cu:112
+        acc += (double)(consistency * dkappa);                  // ref: ...RadonIntermediate.cu:269
+    } else {
+        // ref: ...RadonIntermediate.cu:116-149; the launcher passes kappa_max/kappa as "1/n" (:211,274)
+        const float one_over_n = kappa_max / kappa;
+        mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
+        mom3 += (double)(one_over_n * (v1p * v1p + v1m * v1m));
+        mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
+    }
+    return true;
+}
+
+// The kappa loop of one pair.
+template <bool DERIV, bool CORR, bool REDUCE, int PITCH4>
+__device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&K0)[8], const float (&K1)[8],
+                                           const SlabView sv0, const SlabView sv1, float n_alpha_f, float n_t_f,
+                                           float dist_scale, float dist_bias, float pitch4_f, double& acc, double& mom2,
+                                           double& mom3, double& mom4)
+{
+    const float dkappa = K1[6], kappa_max = K1[7];
+    for (int k = lane; k < k_limit; k += 64)
+        if (!kappa_step<DERIV, CORR, REDUCE, PITCH4>(k, K0, K1, dkappa, kappa_max, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+                                                     dist_bias, pitch4_f, acc, mom2, mom3, mom4))
+            return;  // kappa only grows: this lane is done
+}
+
+// Pair geometry, ONE THREAD PER PAIR (ref: kernelEpipolarConsistencyComputeK01, ...RadonIntermediate.cu:13-67).
+// A wave of the pair kernel would spend ~900 vector instructions (float64 asin, ~25 IEEE divisions, get_ij) on
+// this per pair with all 64 lanes doing the same thing -- a sixth of its time; here 64 pairs share those
+// instructions and the pair kernel picks the result up with scalar loads.  Unlike the reference there is no
+// device-wide sync in between, the two kernels are just ordered on the stream.
+__global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
+{
+    const long long local = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= p.count) return;
+    int iP0, iP1, iD0, iD1, ci = 0, cj = 0;
+    if (p.indices) {
+        const int32_t* q = p.indices + 4 * (p.first + local);
+        iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
+    } else {
+        get_ij_closed(p.first + local, p.n_views, ci, cj);
+        iP0 = iD0 = ci;
+        iP1 = iD1 = cj;
+    }
+    EccPairRecord r;
+    if (iP0 == iP1) {
+        for (int i = 0; i < 8; i++) r.K0[i] = r.K1[i] = 0.f;
+    } else {
+        compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0, p.PinvTs + 12 * iP1,
+                    p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, r.K0, r.K1);
+    }
+    r.iD0 = iD0;
+    r.iD1 = iD1;
+    r.ci = ci;
+    r.cj = cj;
+    r.it_small = 0;
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    p.records[local] = r;
+    if (p.K01_out)
+        for (int i = 0; i < 8; i++) {
+            p.K01_out[16 * local + i] = r.K0[i];
+            p.K01_out[16 * local + 8 + i] = r.K1[i];
+        }
 }
 
 template <bool DERIV, bool CORR>
@@ -235,77 +339,42 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     const long long per_xcd = (nblk + 7) / 8;
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (blk >= nblk) return;
-    const long long local = blk * 4 + wave;
+    long long local = blk * 4 + wave;
     if (local >= p.count) return;  // no barriers below: waves leave independently
-
-    int iP0, iP1, iD0, iD1, ci = 0, cj = 0;
-    if (p.indices) {
-        const int32_t* q = p.indices + 4 * (p.first + local);
-        iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
-    } else {
-        get_ij_closed(p.first + local, p.n_views, ci, cj);
-        iP0 = iD0 = ci;
-        iP1 = iD1 = cj;
-    }
-    iP0 = __builtin_amdgcn_readfirstlane(iP0);
-    iP1 = __builtin_amdgcn_readfirstlane(iP1);
-    iD0 = __builtin_amdgcn_readfirstlane(iD0);
-    iD1 = __builtin_amdgcn_readfirstlane(iD1);
-
+    // wave-uniform record -> SGPRs (readfirstlane makes the address provably uniform: scalar loads)
+    local = ((long long)__builtin_amdgcn_readfirstlane((int)(local >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)local);
+    const EccPairRecord* __restrict__ rec = p.records + local;
     float K0[8], K1[8];
-    if (iP0 == iP1) {
-        for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
-    } else {
-        compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0, p.PinvTs + 12 * iP1,
-                    p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, K0, K1);
-    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        K0[i] = uniformf(K0[i]);
-        K1[i] = uniformf(K1[i]);
+        K0[i] = uniformf(rec->K0[i]);
+        K1[i] = uniformf(rec->K1[i]);
     }
-    if (p.K01_out && lane == 0)
-        for (int i = 0; i < 8; i++) {
-            p.K01_out[16 * local + i] = K0[i];
-            p.K01_out[16 * local + 8 + i] = K1[i];
-        }
+    const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
+    const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
 
     const unsigned pitch4 = (unsigned)p.pitch * 4u;
     const SlabView sv0 = {reinterpret_cast<const char*>(p.dtrs[iD0]), pitch4};
     const SlabView sv1 = {reinterpret_cast<const char*>(p.dtrs[iD1]), pitch4};
     const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
-    const float inv_range_t = 1.0f / p.range_t;
+    const float dist_scale = n_t_f / p.range_t, dist_bias = fmaf(0.5f, n_t_f, 0.5f);
     const float pitch4_f = (float)pitch4;
-    const float dkappa = K1[6], kappa_max = K1[7], w06 = K0[6];
+    const float kappa_max = K1[7];
 
     double acc = 0.0;
     double mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;  // CORR: sums of x*x, y*y, x*y (x, y alone are not used by cc())
-    for (int k = lane; k < p.k_limit; k += 64) {
-        const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
-        if (kappa >= kappa_max) break;
-        float sn, cs;
-        sincos_quadrant(kappa, sn, cs);
-        // view 0
-        const float a00 = K0[0] * cs, a01 = K0[1] * cs, a02 = K0[2] * cs;
-        const float b00 = K0[3] * sn, b01 = K0[4] * sn, b02 = K0[5] * sn;
-        // view 1
-        const float a10 = K1[0] * cs, a11 = K1[1] * cs, a12 = K1[2] * cs;
-        const float b10 = K1[3] * sn, b11 = K1[4] * sn, b12 = K1[5] * sn;
-        const float v0p = sample_line<DERIV>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
-        const float v1p = sample_line<DERIV>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
-        const float v0m = sample_line<DERIV>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
-        const float v1m = sample_line<DERIV>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, inv_range_t, pitch4_f);
-        if (!CORR) {
-            const float vp = v0p - v1p, vm = v0m - v1m;
-            const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
-            acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
-        } else {
-            // ref: ...RadonIntermediate.cu:116-149; the launcher passes kappa_max/kappa as "1/n" (:211,274)
-            const float one_over_n = kappa_max / kappa;
-            mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
-            mom3 += (double)(one_over_n * (v1p * v1p + v1m * v1m));
-            mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
-        }
+    const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
+    if (pitch4 == 3200u) {  // 768 distance bins, the reference's default (Gui/ComputeRadonIntermediate.hxx:43-44)
+        if (reduce)
+            kappa_loop<DERIV, CORR, true, 3200>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+                                                dist_bias, pitch4_f, acc, mom2, mom3, mom4);
+        else
+            kappa_loop<DERIV, CORR, false, 3200>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+                                                 dist_bias, pitch4_f, acc, mom2, mom3, mom4);
+    } else {
+        kappa_loop<DERIV, CORR, true, 0>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
+                                         pitch4_f, acc, mom2, mom3, mom4);
     }
     float val;
     if (!CORR) {
@@ -462,6 +531,14 @@ extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hip
     return hipGetLastError();
 }
 
+extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream)
+{
+    if (p->count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k01_kernel, dim3((unsigned)((p->count + 255) / 256)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+// Needs the records of ecc_launch_k01 for the same parameters, earlier on the same stream.
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
