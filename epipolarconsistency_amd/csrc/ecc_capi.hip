@@ -128,6 +128,8 @@ struct ecc_metric {
     // pinned host staging
     double* Ps_h = nullptr;
     double* sum_h = nullptr;
+    double* Ps_h_dev = nullptr;   // the same pinned buffers as the device sees them (zero-copy: the 38 KB of
+    double* sum_h_dev = nullptr;  // matrices and the 8-byte result cross PCIe inside the kernels, no copy commands)
 };
 
 namespace {
@@ -573,7 +575,9 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     }
     hipError_t e = hipMalloc((void**)&m->dtr_table_d, sizeof(float*) * n_dtrs);
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, sizeof(double));
+
+    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&m->sum_h_dev, m->sum_h, 0);
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->dtr_table_d, table.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -626,14 +630,14 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
         HIP_TRY(hipMalloc((void**)&m->Cs_d, sizeof(float) * 4 * n_views));
         HIP_TRY(hipMalloc((void**)&m->PinvTs_d, sizeof(float) * 12 * n_views));
         HIP_TRY(hipMalloc((void**)&m->Ps_d, sizeof(double) * 12 * n_views));
-        HIP_TRY(hipHostMalloc((void**)&m->Ps_h, sizeof(double) * 12 * n_views));
+        HIP_TRY(hipHostMalloc((void**)&m->Ps_h, sizeof(double) * 12 * n_views, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&m->Ps_h_dev, m->Ps_h, 0));
         m->geom_capacity = n_views;
     }
-    // E1 on the device: upload the n x 12 doubles, one thread per view does the reference's binary64
-    // Householder-QR arithmetic (geometry_kernel.hip); nothing else crosses PCIe.
+    // E1 on the device: one thread per view reads its 12 doubles straight from the pinned staging buffer and
+    // does the reference's binary64 Householder-QR arithmetic (geometry_kernel.hip); nothing else crosses PCIe.
     std::memcpy(m->Ps_h, Ps, sizeof(double) * 12 * (size_t)n_views);
-    HIP_TRY(hipMemcpyAsync(m->Ps_d, m->Ps_h, sizeof(double) * 12 * n_views, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ecc_launch_e1(m->Ps_d, n_views, m->PinvTs_d, m->Cs_d, ctx->stream));
+    HIP_TRY(ecc_launch_e1(m->Ps_h_dev, n_views, m->PinvTs_d, m->Cs_d, ctx->stream));
     m->n_views = n_views;
     m->P_first.assign(Ps, Ps + 12);
     return ECC_OK;
@@ -762,9 +766,8 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
     if (rc) return rc;
     rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count > 0 ? count : 1, ctx->stream);
     if (rc) return rc;
-    rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_d);
+    rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_h_dev);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(m->sum_h, m->sum_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (pair_values && count > 0)
         HIP_TRY(hipMemcpyAsync(pair_values, m->pair_values_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -798,9 +801,8 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
         // upload the caller's image so that untouched entries survive, ref: ...RadonIntermediate.cpp:183
         HIP_TRY(hipMemcpyAsync(cost_d, cost_nxn, sizeof(float) * n * n, hipMemcpyHostToDevice, ctx->stream));
     }
-    rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_d);
+    rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_h_dev);  // the sum lands in pinned host memory
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(m->sum_h, m->sum_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (cost_nxn) HIP_TRY(hipMemcpyAsync(cost_nxn, cost_d, sizeof(float) * n * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *mean = *m->sum_h / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
@@ -843,8 +845,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;
     }
-    HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_d, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(m->sum_h, m->sum_d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, ctx->stream));
     if (out) HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *mean = *m->sum_h / (double)n_pairs;

@@ -396,6 +396,9 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
         if (p.pair_values) p.pair_values[local] = val;
         if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
     }
+    // (Fusing the final float64 sum in here -- last-ticket wave reduces -- was measured and dropped: one
+    // device-scope atomic per wave on a single counter serialises, 0.51 -> 1.05 ms, and with acquire/release
+    // fences per wave 3.15 ms: a cross-XCD release writes the L2 back.  The sum stays a 8-us kernel of its own.)
 }
 
 // Deterministic float64 sum of `count` pair values (single workgroup, fixed tree).
