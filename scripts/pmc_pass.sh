@@ -14,7 +14,7 @@ for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k=r["Kernel_Name"]
-    m=re.search(r"(pairs_kernel<\w+>|radon_kernel<\w+>|sum_pairs_kernel|e1_kernel|dtr_border_kernel)", k)
+    m=re.search(r"(pairs_kernel<[\w, ]+>|k01_kernel|radon_kernel<\w+>|sum_pairs_kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w]+>)", k)
     if m:
         acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.summary.txt","w") as f:
