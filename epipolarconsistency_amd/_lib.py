@@ -67,6 +67,14 @@ SIGNATURES = {
     "ecc_host_pinvT": (None, [_vp, _vp]),
     "ecc_host_source_position": (None, [_vp, _vp]),
     "ecc_host_object_radius": (_d, [_vp, _i, _i]),
+    "ecc_direct_create": (_i, [_vp, _i, _vp, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_direct_destroy": (_i, [_vp]),
+    "ecc_direct_set_projections": (_i, [_vp, _vp, _i]),
+    "ecc_direct_set_params": (_i, [_vp, _d, _d, _i]),
+    "ecc_direct_get_object_radius": (_i, [_vp, _pd]),
+    "ecc_direct_evaluate": (_i, [_vp, _vp, _pd]),
+    "ecc_direct_lines_bound": (_i, [_vp, _pi]),
+    "ecc_direct_evaluate_for_image_pair": (_i, [_vp, _i, _i, _i, _pi, _vp, _vp, _vp, _vp, _pd]),
     "ecc_preprocess_defaults": (None, [_vp]),
     "ecc_preprocess": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ecc_host_intrinsics": (None, [_vp, _pf, _pf, _pf]),

@@ -423,6 +423,104 @@ class MetricRadonIntermediate:
             pass
 
 
+class MetricDirect:
+    """ref: class MetricDirect : public Metric (EpipolarConsistencyDirect.h:28-60): epipolar consistency straight
+    from the projection images.  images: (n, n_v, n_u) float32, numpy (uploaded, owned) or a torch tensor on ctx's
+    device (borrowed, like the reference borrows its textures)."""
+
+    def __init__(self, ctx, Ps, images):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        self._params = [0.0, 0.0, 0]
+        self._Ps = None
+        self.setProjectionImages(images)
+        if Ps is not None:
+            self.setProjectionMatrices(Ps)
+
+    def setProjectionImages(self, images):
+        if self._h:
+            _lib.lib().ecc_direct_destroy(self._h)
+            self._h = C.c_void_p()
+        if _is_torch(images):
+            import torch
+            assert images.dtype == torch.float32 and images.is_contiguous() and images.is_cuda and images.dim() == 3
+            self._keep, ptr, on_dev = images, images.data_ptr(), 1
+        else:
+            self._keep = np.ascontiguousarray(images, np.float32)
+            assert self._keep.ndim == 3
+            ptr, on_dev = self._keep.ctypes.data, 0
+        n, n_v, n_u = self._keep.shape
+        self._n = n
+        check(_lib.lib().ecc_direct_create(self.ctx._h, n, C.c_void_p(ptr), on_dev, n_u, n_v, C.byref(self._h)))
+        check(_lib.lib().ecc_direct_set_params(self._h, *self._params))
+        if self._Ps is not None:
+            self.setProjectionMatrices(self._Ps)
+        return self
+
+    def setProjectionMatrices(self, Ps):
+        self._Ps = _Ps_colmajor(Ps)
+        check(_lib.lib().ecc_direct_set_projections(self._h, C.c_void_p(self._Ps.ctypes.data), len(self._Ps)))
+        return self
+
+    def getNumberOfProjetions(self):  # sic
+        return self._n
+
+    def _push(self):
+        check(_lib.lib().ecc_direct_set_params(self._h, *self._params))
+        return self
+
+    def setObjectRadius(self, radius_mm=0.0):
+        self._params[0] = float(radius_mm)
+        return self._push()
+
+    def getObjectRadius(self):
+        r = C.c_double()
+        check(_lib.lib().ecc_direct_get_object_radius(self._h, C.byref(r)))
+        return r.value
+
+    def setEpipolarPlaneStep(self, dkappa_rad=0.0):
+        self._params[1] = float(dkappa_rad)
+        return self._push()
+
+    def setFanBeamConsistency(self, fbcc=True):
+        self._params[2] = 1 if fbcc else 0
+        return self._push()
+
+    def evaluate(self, cost=None):
+        """ref: MetricDirect::evaluate(float* out): the SUM over all pairs; cost (n,n) float32: entry [j, i], i<j."""
+        s = C.c_double()
+        if cost is not None:
+            assert cost.dtype == np.float32 and cost.flags["C_CONTIGUOUS"] and cost.shape == (self._n, self._n)
+        check(_lib.lib().ecc_direct_evaluate(self._h, C.c_void_p(cost.ctypes.data if cost is not None else 0), C.byref(s)))
+        return s.value
+
+    def evaluateForImagePair(self, i, j):
+        """ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas); also returns the lines."""
+        L = _lib.lib()
+        cap = C.c_int()
+        check(L.ecc_direct_lines_bound(self._h, C.byref(cap)))
+        cap = cap.value
+        s0, s1, kap = (np.empty(cap, np.float32) for _ in range(3))
+        lines = np.empty((cap, 6), np.float32)
+        n, m = C.c_int(), C.c_double()
+        check(L.ecc_direct_evaluate_for_image_pair(self._h, int(i), int(j), cap, C.byref(n), C.c_void_p(s0.ctypes.data),
+                                                   C.c_void_p(s1.ctypes.data), C.c_void_p(kap.ctypes.data),
+                                                   C.c_void_p(lines.ctypes.data), C.byref(m)))
+        n = n.value
+        return m.value, dict(redundant_samples0=s0[:n], redundant_samples1=s1[:n], kappas=kap[:n], lines=lines[:n])
+
+    def close(self):
+        if self._h:
+            _lib.lib().ecc_direct_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def slab_floats(n_alpha, n_t):
     """Floats per dtr in the private device layout (csrc/ecc_layout.h)."""
     return _lib.lib().ecc_dtr_slab_floats(int(n_alpha), int(n_t))

@@ -1,0 +1,245 @@
+// direct_kernel.hip -- MetricDirect: epipolar consistency straight from the projection images.
+//
+// The reference evaluates one pair at a time from the host (ref: LibEpipolarConsistency/EpipolarConsistencyDirect.cpp:
+// 67-219,247-259): per pair it builds the kappa grid and the 2 x n_lines epipolar lines on the host in float64,
+// uploads them, launches kernel_computeLineIntegrals twice (EpipolarConsistencyDirect.cu:31-125; 32-thread blocks,
+// texture fetches, a device-wide sync after each), reads both signals back and sums on the host.  Here a batch of
+// pairs is four stream-ordered launches with nothing crossing PCIe but the final scalar:
+//   direct_view_kernel   thread per view: source position and the row-QR factors of P (float64)
+//   direct_pair_kernel   thread per pair: baseline, the two reference planes, kappa range/step, line count
+//   direct_lines_kernel  thread per (pair, image, kappa): the line in float64 -> float, then the reference's
+//                        fp32 line integral (0.4-px steps, two parallel lines half a pixel apart) with the exact
+//                        bilinear rule on the image in global memory; neighbouring threads are neighbouring lines
+//                        of the pencil, so their taps share cache lines
+//   direct_reduce_kernel wave per pair: sum (v0-v1)^2 dkappa in float64 (fixed order), cost image entry
+// Arithmetic follows oracle/ecc_oracle.c (eccor_direct_pair): line integrals are bit-identical for identical
+// lines; the lines themselves differ from the oracle's only through the float64 sin/cos of the two libms.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "ecc_host_geometry.h"
+#include "ecc_layout.h"
+#include "ecc_sampling.h"
+
+namespace {
+
+__global__ __launch_bounds__(64) void direct_view_kernel(const double* __restrict__ Ps, int n, EccDirectView* __restrict__ views,
+                                                         int n_u, int n_v)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    double P[12];
+    for (int k = 0; k < 12; ++k) P[k] = Ps[12 * (size_t)v + k];
+    EccDirectView out;
+    ecc_host::camera_center(P, out.C);
+    ecc_host::RowQR f;
+    ecc_host::row_qr(P, &f);
+    for (int i = 0; i < 3; ++i) {
+        for (int k = 0; k < 4; ++k) out.Q[4 * i + k] = f.Q[i][k];
+        for (int j = 0; j < 3; ++j) out.L[3 * i + j] = f.L[i][j];
+    }
+    out.radius = ecc_host::object_radius(P, n_u, n_v);
+    views[v] = out;
+}
+
+// ref: EpipolarConsistencyDirect.cpp:84-117 + estimateAngularRange (EpipolarConsistency.cpp:49-59)
+__global__ __launch_bounds__(256) void direct_pair_kernel(EccDirectParams p)
+{
+    const long long local = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= p.count) return;
+    int i, j;
+    if (p.idx2) {
+        i = p.idx2[2 * local];
+        j = p.idx2[2 * local + 1];
+    } else {
+        ecc_get_ij_device(p.first + local, p.n_views, i, j);
+    }
+    const EccDirectView& V0 = p.views[i];
+    const EccDirectView& V1 = p.views[j];
+    EccDirectPair r;
+    r.i = i;
+    r.j = j;
+    double B[6];
+    ecc_host::join_points(V0.C, V1.C, B);
+    double radius = p.object_radius_mm;
+    if (radius <= 0) radius = V0.radius > V1.radius ? V0.radius : V1.radius;  // ref: :88-90
+    const double Pi = 3.14159265358979323846264338327950288419716939937510582;
+    const double mom = sqrt(B[3] * B[3] + B[1] * B[1] + B[0] * B[0]);
+    const double dir = sqrt(B[2] * B[2] + B[4] * B[4] + B[5] * B[5]);
+    const double baseline_dist = mom / dir;
+    double k_first, k_second;
+    if (baseline_dist <= radius) {
+        k_first = -0.5 * Pi;
+        k_second = 0.5 * Pi;
+    } else {
+        const double km = fabs(asin(radius / baseline_dist));
+        k_first = -km;
+        k_second = km;
+    }
+    double dkappa = p.dkappa;
+    if (dkappa <= 0) {
+        const double diag = sqrt((double)(p.n_u * p.n_u + p.n_v * p.n_v));
+        dkappa = 0.5 * (k_second - k_first) / diag;
+    }
+    const double nl = (k_second - k_first) / dkappa;
+    int n_lines = nl < 2147483000.0 ? (int)nl : 2147483000;
+    if (!(nl >= 0)) n_lines = 0;            // NaN geometry (coincident source positions)
+    if (n_lines > p.n_max) n_lines = p.n_max;  // cannot happen for the host's bound; keeps the stores in range
+    r.k_first = k_first;
+    r.dkappa = dkappa;
+    r.n_lines = n_lines;
+    const double origin3[4] = {0, 0, 0, 1};
+    ecc_host::join_line_point(B, origin3, r.E0);
+    ecc_host::join_line_point(B, r.E0, r.E90);
+    const double n0 = sqrt(r.E0[0] * r.E0[0] + r.E0[1] * r.E0[1] + r.E0[2] * r.E0[2]);
+    const double n90 = sqrt(r.E90[0] * r.E90[0] + r.E90[1] * r.E90[1] + r.E90[2] * r.E90[2]);
+    for (int k = 0; k < 4; ++k) {
+        r.E0[k] /= n0;
+        r.E90[k] /= n90;
+    }
+    r.pad = 0;
+    p.pairs[local] = r;
+}
+
+// ref: EpipolarConsistencyDirect.cu:31-125 (kernel_computeLineIntegrals, fbcc_d == 0).  The reference's launcher
+// hands n_u over for both image sizes (:137); the evident intent (n_u, n_v) is implemented, identical for square
+// images (oracle/ecc_oracle.c does the same).
+__device__ float direct_line_integral(const float* __restrict__ img, int n_u, int n_v, float l0, float l1, float l2)
+{
+    float o0 = -l2 * l0, o1 = -l2 * l1;
+    const float d0 = l1, d1 = -l0;
+    float ts[4] = {(1 - o0) / d0, (n_u - 1 - o0) / d0, (1 - o1) / d1, (n_v - 1 - o1) / d1};
+    if ((double)(d0 * d0) < 1e-12) ts[0] = -(ts[1] = 1e10f);
+    if ((double)(d1 * d1) < 1e-12) ts[2] = -(ts[3] = 1e10f);
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (ts[i] > ts[i + 1]) {
+                const float tmp = ts[i];
+                ts[i] = ts[i + 1];
+                ts[i + 1] = tmp;
+            }
+    const float t_min = ts[1], t_max = ts[2];
+    {
+        const float u = o0 + t_min * d0, v = o1 + t_min * d1;
+        if (!(u <= n_u && v <= n_v && u >= 0 && v >= 0)) return 0.f;
+    }
+    const float step = 0.4f;
+    o0 += .5f;
+    o1 += .5f;
+    l0 *= 0.5f;
+    l1 *= 0.5f;
+    float sump = 0, summ = 0;
+    // bounded: t_max - t_min <= the image diagonal for a line that passed the test above; a degenerate line
+    // (NaN) fails the loop condition at once
+    for (float t = t_min; t <= t_max; t += step) {
+        const float u = o0 + t * d0;
+        const float v = o1 + t * d1;
+        sump += ecc_tex_global(img, n_u, n_v, u + l0, v + l1) * step;
+        summ += ecc_tex_global(img, n_u, n_v, u - l0, v - l1) * step;
+    }
+    return sump - summ;
+}
+
+__global__ __launch_bounds__(256) void direct_lines_kernel(EccDirectParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pair = blockIdx.y;
+    const int which = blockIdx.z;  // 0: first view of the pair, 1: second
+    const EccDirectPair& r = p.pairs[pair];
+    if (k >= r.n_lines) return;
+    // ref: EpipolarConsistencyDirect.cpp:113-117 (kappa grid, float) and :49-63 (the line of plane kappa)
+    const float kf = (float)(r.k_first + r.dkappa * k);
+    const double kappa = kf, c = cos(kappa), s = sin(kappa);
+    double E[4], l[3];
+    for (int q = 0; q < 4; ++q) E[q] = c * r.E0[q] + s * r.E90[q];
+    const EccDirectView& V = p.views[which ? r.j : r.i];
+    ecc_host::RowQR f;
+    for (int a = 0; a < 3; ++a) {
+        for (int q = 0; q < 4; ++q) f.Q[a][q] = V.Q[4 * a + q];
+        for (int b = 0; b < 3; ++b) f.L[a][b] = V.L[3 * a + b];
+    }
+    ecc_host::plane_to_line(f, E, l);
+    const double nn = sqrt(l[0] * l[0] + l[1] * l[1]);
+    const float lf0 = (float)(l[0] / nn), lf1 = (float)(l[1] / nn), lf2 = (float)(l[2] / nn);
+    const float* img = p.images + (int64_t)(which ? r.j : r.i) * p.image_stride;
+    const float v = direct_line_integral(img, p.n_u, p.n_v, lf0, lf1, lf2);
+    p.samples[((size_t)pair * 2 + which) * p.n_max + k] = v;
+    if (p.debug_lines && pair == 0) {
+        float* dl = p.debug_lines + 6 * (size_t)k + 3 * which;
+        dl[0] = lf0;
+        dl[1] = lf1;
+        dl[2] = lf2;
+        if (which == 0) p.debug_kappas[k] = kf;
+    }
+}
+
+// ref: EpipolarConsistencyDirect.cpp:205-208 (metric += (v0-v1)*(v0-v1)*dkappa, float difference and square)
+__global__ __launch_bounds__(256) void direct_reduce_kernel(EccDirectParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= p.count) return;
+    const EccDirectPair& r = p.pairs[pair];
+    const float* v0 = p.samples + (size_t)pair * 2 * p.n_max;
+    const float* v1 = v0 + p.n_max;
+    double acc = 0.0;
+    for (int k = lane; k < r.n_lines; k += 64) {
+        const float d = v0[k] - v1[k];
+        acc += (double)(d * d) * r.dkappa;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) {
+        p.pair_metric[pair] = acc;
+        if (p.cost) p.cost[(size_t)r.i + (size_t)r.j * p.n_views] = (float)acc;  // ref: :255 cost_image.pixel(i,j)
+        if (p.pair_lines) p.pair_lines[pair] = r.n_lines;
+    }
+}
+
+// Sum of `count` float64 pair metrics in a fixed order, added to *total (ref: :247-259, cost += ecc).
+__global__ __launch_bounds__(1024) void direct_sum_kernel(const double* __restrict__ vals, long long count,
+                                                          double* __restrict__ total)
+{
+    __shared__ double s[1024 / 64];
+    double acc = 0.0;
+    for (long long k = threadIdx.x; k < count; k += 1024) acc += vals[k];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 1024 / 64; w++) tot += s[w];
+        *total += tot;
+    }
+}
+
+}  // namespace
+
+extern "C" hipError_t ecc_launch_direct_views(const double* Ps_d, int n, EccDirectView* views, int n_u, int n_v,
+                                              hipStream_t stream)
+{
+    hipLaunchKernelGGL(direct_view_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, Ps_d, n, views, n_u, n_v);
+    return hipGetLastError();
+}
+
+// One batch: p->count pairs starting at p->first (get_ij order); p->count <= 65535.
+extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* total, hipStream_t stream)
+{
+    if (p->count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(direct_pair_kernel, dim3((unsigned)((p->count + 255) / 256)), dim3(256), 0, stream, *p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    dim3 grid((p->n_max + 255) / 256, (unsigned)p->count, 2);
+    hipLaunchKernelGGL(direct_lines_kernel, grid, dim3(256), 0, stream, *p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(direct_reduce_kernel, dim3((unsigned)((p->count + 3) / 4)), dim3(256), 0, stream, *p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (total) {
+        hipLaunchKernelGGL(direct_sum_kernel, dim3(1), dim3(1024), 0, stream, p->pair_metric, p->count, total);
+        e = hipGetLastError();
+    }
+    return e;
+}

@@ -202,5 +202,75 @@ ECC_HD inline void intrinsics(const double* P, float* sdd_px, float* ppu, float*
     *ppv = (float)(K12 / K22);
 }
 
+// ---- MetricDirect geometry (float64 throughout, like the reference's host code) -------------------------
+// (P^+)^T E for planes E: the reference forms P^+ with Eigen's JacobiSVD (ref:
+// LibProjectiveGeometry/SingularValueDecomposition.cpp:10-25).  Same quantity by modified Gram-Schmidt on the
+// rows of P: P = L Q (L lower triangular, Q with orthonormal rows), (P^+)^T = L^-T Q; works on P itself
+// (condition ~3e5), not on P P^T (~1e11).
+struct RowQR {
+    double Q[3][4];
+    double L[3][3];
+};
+
+ECC_HD inline void row_qr(const double* P, RowQR* f)
+{
+    for (int i = 0; i < 3; ++i) {
+        double v[4];
+        for (int k = 0; k < 4; ++k) v[k] = P[i + 3 * k];
+        for (int j = 0; j < 3; ++j) f->L[i][j] = 0.0;
+        for (int j = 0; j < i; ++j) {
+            double dot = 0;
+            for (int k = 0; k < 4; ++k) dot += v[k] * f->Q[j][k];
+            f->L[i][j] = dot;
+            for (int k = 0; k < 4; ++k) v[k] -= dot * f->Q[j][k];
+        }
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+        f->L[i][i] = n;
+        for (int k = 0; k < 4; ++k) f->Q[i][k] = v[k] / n;
+    }
+}
+
+ECC_HD inline void plane_to_line(const RowQR& f, const double* E, double* l)
+{
+    double y[3];
+    for (int i = 0; i < 3; ++i) {
+        y[i] = 0;
+        for (int k = 0; k < 4; ++k) y[i] += f.Q[i][k] * E[k];
+    }
+    l[2] = y[2] / f.L[2][2];
+    l[1] = (y[1] - f.L[2][1] * l[2]) / f.L[1][1];
+    l[0] = (y[0] - f.L[1][0] * l[1] - f.L[2][0] * l[2]) / f.L[0][0];
+}
+
+// ref: LibProjectiveGeometry/ProjectionMatrix.cpp:70-76 (getCameraCenter; any float64 null space), w = 1.
+ECC_HD inline void camera_center(const double* P, double* C)
+{
+    C[0] = det3(P + 3, P + 6, P + 9);
+    C[1] = -det3(P, P + 6, P + 9);
+    C[2] = det3(P, P + 3, P + 9);
+    C[3] = -det3(P, P + 3, P + 6);
+    if (C[3] < -1e-12 || C[3] > 1e-12) {
+        C[0] /= C[3]; C[1] /= C[3]; C[2] /= C[3]; C[3] = 1.0;
+    }
+}
+
+// ref: LibProjectiveGeometry/ProjectiveGeometry.hxx:188-200, 216-224 (Pluecker joins)
+ECC_HD inline void join_points(const double* A, const double* B, double* L)
+{
+    L[0] = A[0] * B[1] - A[1] * B[0];
+    L[1] = A[0] * B[2] - A[2] * B[0];
+    L[2] = A[0] * B[3] - A[3] * B[0];
+    L[3] = A[1] * B[2] - A[2] * B[1];
+    L[4] = A[1] * B[3] - A[3] * B[1];
+    L[5] = A[2] * B[3] - A[3] * B[2];
+}
+ECC_HD inline void join_line_point(const double* L, const double* X, double* E)
+{
+    E[0] = +X[1] * L[5] - X[2] * L[4] + X[3] * L[3];
+    E[1] = -X[0] * L[5] + X[2] * L[2] - X[3] * L[1];
+    E[2] = +X[0] * L[4] - X[1] * L[2] + X[3] * L[0];
+    E[3] = -X[0] * L[3] + X[1] * L[1] - X[2] * L[0];
+}
+
 }  // namespace ecc_host
 #endif

@@ -19,6 +19,22 @@
 
 #include <stdint.h>
 
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+// ref: EpipolarConsistencyCommon.hxx:52-79 (get_ij), closed form: pairs before row i = i*n - i(i+1)/2.
+__device__ __forceinline__ void ecc_get_ij_device(long long ij, int n, int& i, int& j)
+{
+    double nn = (double)n - 0.5;
+    int r = (int)floor(nn - sqrt(nn * nn - 2.0 * (double)ij));
+    r = max(0, min(r, n - 2));
+    // fix-up against rounding of the square root
+    while (r > 0 && (long long)r * n - (long long)r * (r + 1) / 2 > ij) --r;
+    while ((long long)(r + 1) * n - (long long)(r + 1) * (r + 2) / 2 <= ij) ++r;
+    i = r;
+    j = (int)(ij - ((long long)r * n - (long long)r * (r + 1) / 2)) + r + 1;
+}
+#endif
+
 static inline int ecc_layout_pitch(int n_t) { return ((n_t + 2) + 31) / 32 * 32; }
 static inline int ecc_layout_rows(int n_alpha) { return n_alpha + 2; }
 static inline int64_t ecc_layout_floats(int n_alpha, int n_t)
@@ -93,6 +109,35 @@ struct EccPreprocessParams {
     const double* kernel;     // 2k+1 doubles on the device
     const float* cosw;        // n_img x 3 (sdd_px, ppu, ppv) or null
     const int* cosw_valid;    // n_img flags: 0 when the projection matrix is all zero (ref: PreProccess.cpp:149)
+};
+
+// ---- MetricDirect -----------------------------------------------------------
+struct EccDirectView {
+    double C[4];     // source position, w = 1
+    double Q[12];    // row-QR of P: orthonormal rows (3 x 4)
+    double L[9];     // lower-triangular factor (3 x 3)
+    double radius;   // estimateObjectRadius of this view
+};
+struct EccDirectPair {
+    double E0[4], E90[4];     // the two reference epipolar planes (Hessian normal form)
+    double k_first, dkappa;   // kappa grid: k_first + dkappa * k
+    int n_lines, i, j, pad;
+};
+struct EccDirectParams {
+    const float* images;        // n_views images, n_v x n_u, u fastest
+    int64_t image_stride;
+    const EccDirectView* views;
+    EccDirectPair* pairs;       // `count` records (direct_pair_kernel -> the other kernels)
+    const int32_t* idx2;        // optional explicit (i, j) per pair; null = get_ij order from `first`
+    float* samples;             // count x 2 x n_max line integrals
+    double* pair_metric;        // count float64 pair values
+    float* cost;                // optional n x n cost image (index i + j*n)
+    int* pair_lines;            // optional: n_lines per pair
+    float* debug_lines;         // optional: 6 floats per kappa of pair 0
+    float* debug_kappas;        // optional: kappa grid of pair 0 (with debug_lines)
+    int64_t first, count;
+    int n_views, n_u, n_v, n_max;
+    double object_radius_mm, dkappa;
 };
 
 // ---- evaluateForImagePair (E7, visualisation) -------------------------------------------------

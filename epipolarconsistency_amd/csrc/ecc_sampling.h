@@ -1,0 +1,27 @@
+// ecc_sampling.h -- the normative bilinear rule on a plain row-major image in global memory.
+//
+// Replaces CUDA's un-normalised, clamped, linearly filtered texture fetch (ref:
+// LibUtilsCuda/CudaBindlessTexture.cpp:25-39) by the exact fp32 rule of SURVEY.md 8c:
+// xb = x - .5, yb = y - .5; taps at the clamped floor / floor + 1; weights are the exact fractions.
+#ifndef ECC_SAMPLING_H
+#define ECC_SAMPLING_H
+
+#include <hip/hip_runtime.h>
+
+__device__ __forceinline__ float ecc_tex_global(const float* __restrict__ img, int W, int H, float x, float y)
+{
+    float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float fx = xb - fi, fy = yb - fj;
+    // float -> int saturates on the device; the clamps do the rest
+    int i = (int)fi, j = (int)fj;
+    int i0 = min(max(i, 0), W - 1), i1 = min(max(i + 1, 0), W - 1);
+    int j0 = min(max(j, 0), H - 1), j1 = min(max(j + 1, 0), H - 1);
+    float T00 = img[(size_t)j0 * W + i0], T10 = img[(size_t)j0 * W + i1];
+    float T01 = img[(size_t)j1 * W + i0], T11 = img[(size_t)j1 * W + i1];
+    float r0 = (1.f - fx) * T00 + fx * T10;
+    float r1 = (1.f - fx) * T01 + fx * T11;
+    return (1.f - fy) * r0 + fy * r1;
+}
+
+#endif

@@ -20,19 +20,6 @@ namespace {
 
 constexpr int PK_THREADS = 256;
 
-// ref: EpipolarConsistencyCommon.hxx:52-79 (get_ij), closed form: pairs before row i = i*n - i(i+1)/2.
-__device__ __forceinline__ void get_ij_closed(long long ij, int n, int& i, int& j)
-{
-    double nn = (double)n - 0.5;
-    int r = (int)floor(nn - sqrt(nn * nn - 2.0 * (double)ij));
-    r = max(0, min(r, n - 2));
-    // fix-up against rounding of the square root
-    while (r > 0 && (long long)r * n - (long long)r * (r + 1) / 2 > ij) --r;
-    while ((long long)(r + 1) * n - (long long)(r + 1) * (r + 2) / 2 <= ij) ++r;
-    i = r;
-    j = (int)(ij - ((long long)r * n - (long long)r * (r + 1) / 2)) + r + 1;
-}
-
 // ref: EpipolarConsistencyCommon.hxx:82-90 (shiftOriginAndNormlaize)
 __device__ __forceinline__ void shift_origin_and_normalize(float x, float y, float* Ki)
 {
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
         const int32_t* q = p.indices + 4 * (p.first + local);
         iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
     } else {
-        get_ij_closed(p.first + local, p.n_views, ci, cj);
+        ecc_get_ij_device(p.first + local, p.n_views, ci, cj);
         iP0 = iD0 = ci;
         iP1 = iD1 = cj;
     }

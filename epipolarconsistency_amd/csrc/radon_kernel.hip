@@ -25,6 +25,7 @@
 #include <limits.h>
 
 #include "ecc_layout.h"
+#include "ecc_sampling.h"
 
 #ifdef ECC_RADON_STATS
 __device__ unsigned long long g_radon_stats[8];
@@ -52,21 +53,11 @@ constexpr int TILE_S_MAX = TILE_W + 1;     // row stride is TILE_W+1 or TILE_W-1
 constexpr float RADON_STEP = .66f;         // ref: RadonIntermediate.cu:102
 constexpr int MAX_CHUNKS = 8192;           // bound on the chunk loop (every spin is bounded)
 
-// Exact fp32 bilinear rule on global memory with clamp addressing; slow path used
-// only when a chunk's footprint does not fit the LDS tile.
+// Exact fp32 bilinear rule on global memory with clamp addressing (ecc_sampling.h); slow path used
+// only when a chunk's footprint cannot be made to fit the LDS tile.
 __device__ __forceinline__ float tex_global(const float* __restrict__ img, int W, int H, float x, float y)
 {
-    float xb = x - 0.5f, yb = y - 0.5f;
-    float fi = floorf(xb), fj = floorf(yb);
-    float fx = xb - fi, fy = yb - fj;
-    int i = (int)fi, j = (int)fj;
-    int i0 = min(max(i, 0), W - 1), i1 = min(max(i + 1, 0), W - 1);
-    int j0 = min(max(j, 0), H - 1), j1 = min(max(j + 1, 0), H - 1);
-    float T00 = img[(size_t)j0 * W + i0], T10 = img[(size_t)j0 * W + i1];
-    float T01 = img[(size_t)j1 * W + i0], T11 = img[(size_t)j1 * W + i1];
-    float r0 = (1.f - fx) * T00 + fx * T10;
-    float r1 = (1.f - fx) * T01 + fx * T11;
-    return (1.f - fy) * r0 + fy * r1;
+    return ecc_tex_global(img, W, H, x, y);
 }
 
 // Same rule on the staged tile.  tile_off = by0*TILE_S + bx0 (tile origin in image texels); the

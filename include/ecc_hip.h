@@ -211,6 +211,36 @@ int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, int capacity
  * …RadonIntermediate.cu:13-67), for ij in [first, first+count).  Host output. */
 int ecc_metric_debug_K01(ecc_metric* m, int64_t first, int64_t count, float* K01s);
 
+/* ---- MetricDirect: consistency straight from the projection images ---------------------------- */
+/* ref: class MetricDirect (LibEpipolarConsistency/EpipolarConsistencyDirect.h:28-60) and computeForImagePair
+ * (EpipolarConsistencyDirect.cpp:67-219) -- no Radon intermediates; per pair 2 x n_lines line integrals through
+ * the images (n_lines = twice the image diagonal unless dkappa is given), so it is ~1000x the work of
+ * MetricRadonIntermediate per evaluation and meant for few views / images that change every iteration.
+ * images: n x n_v x n_u float32.  on_device = 1: the metric BORROWS the device pointer (as the reference borrows
+ * its textures); on_device = 0: it uploads and owns a copy.
+ * The rectified fan-beam variant (setFanBeamConsistency, RectifiedFBCC.h) is not implemented: use_fbcc != 0
+ * makes the evaluate calls fail with ECC_ERR_UNSUPPORTED. */
+typedef struct ecc_direct ecc_direct;
+int ecc_direct_create(ecc_ctx* ctx, int n_images, const float* images, int on_device, int n_u, int n_v,
+                      ecc_direct** out);
+int ecc_direct_destroy(ecc_direct* d);
+/* ref: MetricDirect::setProjectionMatrices; n x 12 float64 column-major. */
+int ecc_direct_set_projections(ecc_direct* d, const double* Ps, int n_views);
+/* ref: Metric::setObjectRadius / setEpipolarPlaneStep / MetricDirect::setFanBeamConsistency; 0 = automatic. */
+int ecc_direct_set_params(ecc_direct* d, double object_radius_mm, double dkappa, int use_fbcc);
+int ecc_direct_get_object_radius(const ecc_direct* d, double* radius_mm);
+/* ref: double MetricDirect::evaluate(float* out) (.cpp:247-259): returns the SUM over all pairs (not the mean);
+ * cost_nxn (host, nullable): entry (i,j), i<j at index i + j*n is written, the rest is preserved. */
+int ecc_direct_evaluate(ecc_direct* d, float* cost_nxn, double* cost_sum);
+/* ref: MetricDirect::evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas) (.cpp:261-272).
+ * Host outputs, nullable, `capacity` entries each (lines01: 6 floats per kappa = the two epipolar lines in pixel
+ * coordinates, Hessian normal form); ecc_direct_lines_bound gives a sufficient capacity.  A caller-provided
+ * kappa grid (the reference accepts a non-empty `kappas` as input, .cpp:105-117) is not supported. */
+int ecc_direct_lines_bound(const ecc_direct* d, int* capacity);
+int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, int capacity, int* n_lines,
+                                       float* redundant_samples0, float* redundant_samples1, float* kappas,
+                                       float* lines01, double* metric);
+
 /* ---- helpers shared with callers ------------------------------------------------------------ */
 /* ref: get_ij (EpipolarConsistencyCommon.hxx:52-79), closed form. */
 void ecc_get_ij(int64_t ij, int n, int* i, int* j);

@@ -300,6 +300,42 @@ def intrinsics(P):
     return a.value, b.value, c.value
 
 
+def direct_pair(P0, P1, img0, img1, dkappa=0.0, object_radius_mm=0.0):
+    """MetricDirect for one pair (ref: EpipolarConsistencyDirect.cpp:67-219, fbcc = false).  Returns dict(metric,
+    samples0, samples1, kappas, lines (n,6))."""
+    L = lib()
+    L.eccor_direct_pair.argtypes = [_f64p, _f64p, _f32p, _f32p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                    _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_double)]
+    L.eccor_direct_pair.restype = C.c_int
+    a = np.ascontiguousarray(img0, np.float32)
+    b = np.ascontiguousarray(img1, np.float32)
+    n_v, n_u = a.shape
+    cap = (int(2 * np.sqrt(float(n_u * n_u + n_v * n_v))) if dkappa <= 0 else int(np.pi / dkappa)) + 16
+    v0, v1, kap = (np.zeros(cap, np.float32) for _ in range(3))
+    lines = np.zeros(6 * cap, np.float32)
+    m = C.c_double()
+    n = L.eccor_direct_pair(_P(P0), _P(P1), a, b, n_u, n_v, float(dkappa), float(object_radius_mm), cap, v0, v1, kap,
+                            lines, C.byref(m))
+    assert n <= cap
+    return dict(metric=m.value, samples0=v0[:n], samples1=v1[:n], kappas=kap[:n], lines=lines[:6 * n].reshape(n, 6))
+
+
+def direct_evaluate(Ps, imgs, dkappa=0.0, object_radius_mm=0.0):
+    """ref: MetricDirect::evaluate (EpipolarConsistencyDirect.cpp:247-259): SUM over pairs and the cost image
+    (index i + j*n, i<j); the radius default is Metric::getObjectRadius (first projection)."""
+    n = len(imgs)
+    n_v, n_u = np.asarray(imgs[0]).shape
+    radius = object_radius_mm if object_radius_mm > 0 else object_radius(Ps[0], n_u, n_v)
+    cost = np.zeros((n, n), np.float32)
+    total = 0.0
+    for i in range(n):
+        for j in range(i + 1, n):
+            e = direct_pair(Ps[i], Ps[j], imgs[i], imgs[j], dkappa, radius)["metric"]
+            total += e
+            cost[j, i] = e
+    return dict(sum=total, cost=cost)
+
+
 def set_variant(v):
     """0 = normative fp32 path (correctly rounded elementary functions); 1 = line->(angle,distance)
     mapping in binary64 (noise-floor probe); 2 = platform float libm (what oracle/_ref is built on)."""

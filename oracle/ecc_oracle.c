@@ -978,6 +978,175 @@ ECCOR_API void eccor_cos_weight(float *img, int n_u, int n_v, const double *P)
         }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* (f-4) MetricDirect: ECC straight from the projection images, no Radon intermediate          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* (P^+)^T E for a plane E (4-vector): the epipolar line of plane E in the image of P.  The reference forms
+ * P^+ with Eigen's JacobiSVD (ref: LibProjectiveGeometry/SingularValueDecomposition.cpp:10-25; absent here).
+ * Same quantity by modified Gram-Schmidt on the rows of P in binary64: P = L Q (L lower triangular, Q with
+ * orthonormal rows), (P^+)^T = L^-T Q.  Works on P itself (condition ~3e5), not on P P^T (~1e11). */
+typedef struct { double Q[3][4]; double L[3][3]; } or_rowqr;
+
+static void or_row_qr(const double *P, or_rowqr *f)
+{
+    int i, j, k;
+    double v[4];
+    memset(f, 0, sizeof(*f));
+    for (i = 0; i < 3; i++) {
+        for (k = 0; k < 4; k++) v[k] = P[i + 3 * k];
+        for (j = 0; j < i; j++) {
+            double dot = 0;
+            for (k = 0; k < 4; k++) dot += v[k] * f->Q[j][k];
+            f->L[i][j] = dot;
+            for (k = 0; k < 4; k++) v[k] -= dot * f->Q[j][k];
+        }
+        {
+            double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+            f->L[i][i] = n;
+            for (k = 0; k < 4; k++) f->Q[i][k] = v[k] / n;
+        }
+    }
+}
+
+static void or_plane_to_line(const or_rowqr *f, const double *E, double *l)
+{
+    double y[3];
+    int i, k;
+    for (i = 0; i < 3; i++) {
+        y[i] = 0;
+        for (k = 0; k < 4; k++) y[i] += f->Q[i][k] * E[k];
+    }
+    /* solve L^T l = y (upper triangular) */
+    l[2] = y[2] / f->L[2][2];
+    l[1] = (y[1] - f->L[2][1] * l[2]) / f->L[1][1];
+    l[0] = (y[0] - f->L[1][0] * l[1] - f->L[2][0] * l[2]) / f->L[0][0];
+}
+
+/* ref: LibProjectiveGeometry/ProjectiveGeometry.hxx:188-200 (join of two points) */
+static void or_join_points(const double *A, const double *B, double *L)
+{
+    L[0] = A[0] * B[1] - A[1] * B[0];
+    L[1] = A[0] * B[2] - A[2] * B[0];
+    L[2] = A[0] * B[3] - A[3] * B[0];
+    L[3] = A[1] * B[2] - A[2] * B[1];
+    L[4] = A[1] * B[3] - A[3] * B[1];
+    L[5] = A[2] * B[3] - A[3] * B[2];
+}
+
+/* ref: ProjectiveGeometry.hxx:216-224 (join of a line and a point -> plane) */
+static void or_join_line_point(const double *L, const double *X, double *E)
+{
+    E[0] = +X[1] * L[5] - X[2] * L[4] + X[3] * L[3];
+    E[1] = -X[0] * L[5] + X[2] * L[2] - X[3] * L[1];
+    E[2] = +X[0] * L[4] - X[1] * L[2] + X[3] * L[0];
+    E[3] = -X[0] * L[3] + X[1] * L[1] - X[2] * L[0];
+}
+
+/* One epipolar line integral (derivative form) straight from an image.
+ * ref: LibEpipolarConsistency/EpipolarConsistencyDirect.cu:31-125 (kernel_computeLineIntegrals, fbcc_d == 0):
+ * lines in pixel coordinates (origin at pixel (0,0)), Hessian normal form; clipping as in R1; step 0.4 px; two
+ * parallel lines half a pixel to either side of the line, each sample multiplied by the step before it is added.
+ * Deviation: the reference's launcher passes n_u for BOTH image sizes (:137); the evident
+ * intent (n_u, n_v) is implemented -- identical for square images. */
+static float or_direct_line_integral(const float *img, int n_u, int n_v, const float *line)
+{
+    float l[3] = {line[0], line[1], line[2]};
+    float o[2] = {-l[2] * l[0], -l[2] * l[1]};
+    float d[2] = {l[1], -l[0]};
+    float ts[4], t_min, t_max, t, sump = 0, summ = 0;
+    const float step = 0.4f;
+    ts[0] = (1 - o[0]) / d[0];
+    ts[1] = (n_u - 1 - o[0]) / d[0];
+    ts[2] = (1 - o[1]) / d[1];
+    ts[3] = (n_v - 1 - o[1]) / d[1];
+    if (d[0] * d[0] < 1e-12) ts[0] = -(ts[1] = 1e10f);
+    if (d[1] * d[1] < 1e-12) ts[2] = -(ts[3] = 1e10f);
+    or_sort4(ts);
+    t_min = ts[1];
+    t_max = ts[2];
+    {
+        float u = o[0] + t_min * d[0], v = o[1] + t_min * d[1];
+        if (!(u <= n_u && v <= n_v && u >= 0 && v >= 0)) return 0.f;
+    }
+    o[0] += .5f;
+    o[1] += .5f;
+    l[0] *= 0.5f;
+    l[1] *= 0.5f;
+    for (t = t_min; t <= t_max; t += step) {
+        float u = o[0] + t * d[0];
+        float v = o[1] + t * d[1];
+        sump += eccor_tex2d(img, n_u, n_v, u + l[0], v + l[1]) * step;
+        summ += eccor_tex2d(img, n_u, n_v, u - l[0], v - l[1]) * step;
+    }
+    return sump - summ;
+}
+
+/* ref: EpipolarConsistencyDirect.cpp:67-219 (computeForImagePair, fbcc == false) with computeEpipolarLines
+ * (:23-65) and estimateAngularRange (EpipolarConsistency.cpp:49-59).  object_radius_mm <= 0: the larger of the
+ * two views' estimates (:88-90).  Output arrays hold `capacity` entries (nullable); lines01: 6 floats per kappa.
+ * Returns n_lines; *metric = sum (v0-v1)^2 dkappa (float difference and square, double sum, :206-208). */
+ECCOR_API int eccor_direct_pair(const double *P0, const double *P1, const float *img0, const float *img1,
+                                int n_u, int n_v, double dkappa, double object_radius_mm, int capacity,
+                                float *v0s, float *v1s, float *kappas, float *lines01, double *metric)
+{
+    const double Pi = 3.14159265358979323846264338327950288419716939937510582;
+    double C0[4], C1[4], B[6], E0[4], E90[4], origin3[4] = {0, 0, 0, 1};
+    double mom, dir, baseline_dist, k_first, k_second, n0, n90, acc = 0;
+    or_rowqr f0, f1;
+    int n_lines, i;
+    eccor_camera_center(P0, C0);
+    eccor_camera_center(P1, C1);
+    or_join_points(C0, C1, B);
+    if (object_radius_mm <= 0) {
+        double a = eccor_object_radius(P0, n_u, n_v), b = eccor_object_radius(P1, n_u, n_v);
+        object_radius_mm = a > b ? a : b;
+    }
+    /* ref: ProjectiveGeometry.hxx:238-268 (moment, direction, distance to origin) */
+    mom = sqrt(B[3] * B[3] + B[1] * B[1] + B[0] * B[0]);
+    dir = sqrt(B[2] * B[2] + B[4] * B[4] + B[5] * B[5]);
+    baseline_dist = mom / dir;
+    if (baseline_dist <= object_radius_mm) { k_first = -0.5 * Pi; k_second = 0.5 * Pi; }
+    else { double km = fabs(asin(object_radius_mm / baseline_dist)); k_first = -km; k_second = km; }
+    if (dkappa <= 0) {
+        double diag = sqrt((double)(n_u * n_u + n_v * n_v));
+        dkappa = 0.5 * (k_second - k_first) / diag;
+    }
+    n_lines = (int)((k_second - k_first) / dkappa);
+    or_join_line_point(B, origin3, E0);
+    or_join_line_point(B, E0, E90);
+    n0 = sqrt(E0[0] * E0[0] + E0[1] * E0[1] + E0[2] * E0[2]);
+    n90 = sqrt(E90[0] * E90[0] + E90[1] * E90[1] + E90[2] * E90[2]);
+    for (i = 0; i < 4; i++) { E0[i] /= n0; E90[i] /= n90; }
+    or_row_qr(P0, &f0);
+    or_row_qr(P1, &f1);
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : acc)
+    for (i = 0; i < n_lines; i++) {
+        float kf = (float)(k_first + dkappa * i);
+        double kappa = kf, c = cos(kappa), s = sin(kappa), E[4], l0[3], l1[3], nn;
+        float lf[6], v0, v1;
+        int k;
+        for (k = 0; k < 4; k++) E[k] = c * E0[k] + s * E90[k];
+        or_plane_to_line(&f0, E, l0);
+        or_plane_to_line(&f1, E, l1);
+        nn = sqrt(l0[0] * l0[0] + l0[1] * l0[1]);
+        for (k = 0; k < 3; k++) lf[k] = (float)(l0[k] / nn);
+        nn = sqrt(l1[0] * l1[0] + l1[1] * l1[1]);
+        for (k = 0; k < 3; k++) lf[3 + k] = (float)(l1[k] / nn);
+        v0 = or_direct_line_integral(img0, n_u, n_v, lf);
+        v1 = or_direct_line_integral(img1, n_u, n_v, lf + 3);
+        if (i < capacity) {
+            if (v0s) v0s[i] = v0;
+            if (v1s) v1s[i] = v1;
+            if (kappas) kappas[i] = kf;
+            if (lines01) memcpy(lines01 + 6 * (size_t)i, lf, sizeof(lf));
+        }
+        acc += (v0 - v1) * (v0 - v1) * dkappa;
+    }
+    if (metric) *metric = acc;
+    return n_lines;
+}
+
 ECCOR_API int eccor_num_threads(void)
 {
 #ifdef _OPENMP

@@ -227,3 +227,31 @@ def test_intrinsics_against_scipy_rq(oracle_mod):
         img = np.ones((160, 200), np.float32)
         w = oracle_mod.preprocess(img, P, process=False)
         assert abs(w[int(round(ppv)), int(round(ppu))] - 1) < 1e-5 and w[0, 0] < w[80, 100] <= 1
+
+
+def test_direct_metric_oracle_properties(oracle_mod, small_scan):
+    """MetricDirect restatement (ref: EpipolarConsistencyDirect.cpp:67-219): line grid, unit normals, symmetry under
+    swapping the views, agreement of its redundant signals with the Radon-intermediate path, sensitivity to motion."""
+    from epipolarconsistency_amd import geometry
+    s = small_scan
+    Ps, imgs = s["Ps"], s["imgs"]
+    radius = oracle_mod.object_radius(Ps[0], s["n_u"], s["n_v"])
+    r = oracle_mod.direct_pair(Ps[1], Ps[5], imgs[1], imgs[5], 0.0, radius)
+    n = len(r["kappas"])
+    assert abs(n - 2 * np.sqrt(2.0) * 128) <= 2  # as many lines as twice the image diagonal (.cpp:98-110)
+    assert np.allclose(np.hypot(r["lines"][:, 0], r["lines"][:, 1]), 1, atol=1e-6)
+    assert np.allclose(np.hypot(r["lines"][:, 3], r["lines"][:, 4]), 1, atol=1e-6)
+    assert np.all(np.diff(r["kappas"]) > 0) and abs(r["kappas"][0] + r["kappas"][-1]) < 2 * (r["kappas"][1] - r["kappas"][0])
+    # swapping the views mirrors the kappa axis and flips both signals' signs: same metric
+    q = oracle_mod.direct_pair(Ps[5], Ps[1], imgs[5], imgs[1], 0.0, radius)
+    assert abs(q["metric"] - r["metric"]) < 2e-2 * r["metric"]
+    # the two redundant signals are close for consistent data, and a rigid perturbation drives them apart
+    a, b = r["samples0"], r["samples1"]
+    assert np.corrcoef(a, b)[0, 1] > 0.98
+    bad = oracle_mod.direct_pair(Ps[1], Ps[5] @ geometry.rigid_transform(tx=3.0, ry=0.02), imgs[1], imgs[5], 0.0, radius)
+    assert bad["metric"] > 1.5 * r["metric"]
+    # same curves as the Radon-intermediate route (E7), up to discretisation: compare at matching kappas
+    e7 = oracle_mod.evaluate_for_image_pair(Ps, s["dtrs"], 1, 5, s["n_u"], s["n_v"])
+    direct_at = np.interp(e7["kappas"], r["kappas"], r["samples0"])
+    core = slice(len(e7["kappas"]) // 4, 3 * len(e7["kappas"]) // 4)
+    assert np.corrcoef(direct_at[core], e7["samples0"][core])[0, 1] > 0.9  # 96-bin dtr of a 128-px image is coarse
