@@ -251,9 +251,9 @@ class RadonIntermediate:
         return base.value, pitch.value, rows.value
 
     def close(self):
-        if self._h:
+        if self._h and self.ctx._h:  # after the context is gone its objects must not be touched any more
             _lib.lib().ecc_dtr_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -412,9 +412,9 @@ class MetricRadonIntermediate:
         return out
 
     def close(self):
-        if self._h:
+        if self._h and self.ctx._h:
             _lib.lib().ecc_metric_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -510,9 +510,9 @@ class MetricDirect:
         return m.value, dict(redundant_samples0=s0[:n], redundant_samples1=s1[:n], kappas=kap[:n], lines=lines[:n])
 
     def close(self):
-        if self._h:
+        if self._h and self.ctx._h:
             _lib.lib().ecc_direct_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -4,6 +4,7 @@
 //   EpipolarConsistency::RadonIntermediate        ref: LibEpipolarConsistency/RadonIntermediate.h:18-128
 //   EpipolarConsistency::Metric                   ref: LibEpipolarConsistency/EpipolarConsistency.h:49-94
 //   EpipolarConsistency::MetricRadonIntermediate  ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.h:21-106
+//   EpipolarConsistency::MetricDirect             ref: LibEpipolarConsistency/EpipolarConsistencyDirect.h:28-60
 //
 // A caller such as Gui/SingleImageMotion.h (:37,72,88), Gui/Registration.h (:34,67,80) or
 // tools/Registration/Registration3D3D.hxx (:66-67,95) compiles against this header instead of the
@@ -312,6 +313,76 @@ public:
 
 private:
     MetricRadonIntermediate(const MetricRadonIntermediate&);
+};
+
+/// ref: class MetricDirect : public Metric (EpipolarConsistencyDirect.h:28-60).  The reference takes
+/// UtilsCuda::BindlessTexture2D<float>* per view; here the projection stack is one float array, on the host
+/// (copied to the device) or already on the device (borrowed).
+class MetricDirect : public Metric {
+    ecc_direct* m_h;
+    int n_images;
+    bool use_fbcc;
+
+    void push_params() { detail::check(ecc_direct_set_params(m_h, object_radius_mm, dkappa, use_fbcc ? 1 : 0)); }
+
+public:
+    MetricDirect(const std::vector<ProjectionMatrix>& _Ps, const float* images, int n, int n_u, int n_v,
+                 bool images_on_device = false, ecc_ctx* ctx = nullptr)
+        : m_h(nullptr), n_images(n), use_fbcc(false)
+    {
+        detail::check(ecc_direct_create(ctx ? ctx : detail::default_context(), n, images, images_on_device ? 1 : 0, n_u,
+                                        n_v, &m_h));
+        setProjectionMatrices(_Ps);
+    }
+    ~MetricDirect() { ecc_direct_destroy(m_h); }
+
+    virtual Metric& setProjectionMatrices(const std::vector<ProjectionMatrix>& _Ps)
+    {
+        Metric::setProjectionMatrices(_Ps);
+        if (Ps.empty()) return *this;
+        std::vector<double> flat(12 * Ps.size());
+        for (size_t i = 0; i < Ps.size(); ++i)
+            for (int k = 0; k < 12; ++k) flat[12 * i + k] = Ps[i].data()[k];
+        detail::check(ecc_direct_set_projections(m_h, flat.data(), (int)Ps.size()));
+        return *this;
+    }
+    virtual Metric& setObjectRadius(double radius_mm = 0) { Metric::setObjectRadius(radius_mm); push_params(); return *this; }
+    virtual Metric& setEpipolarPlaneStep(double dkappa_rad = 0) { Metric::setEpipolarPlaneStep(dkappa_rad); push_params(); return *this; }
+    virtual double getObjectRadius() const
+    {
+        double r = 0;
+        detail::check(ecc_direct_get_object_radius(m_h, &r));
+        return r;
+    }
+    virtual int getNumberOfProjetions() { return n_images; }
+
+    /// Evaluates the metric (SUM over pairs, as the reference does) and optionally returns the n*n cost image.
+    virtual double evaluate(float* out = 0x0)
+    {
+        double sum = 0;
+        detail::check(ecc_direct_evaluate(m_h, out, &sum));
+        return sum;
+    }
+
+    virtual double evaluateForImagePair(int i, int j, std::vector<float>* redundant_samples0 = 0x0,
+                                        std::vector<float>* redundant_samples1 = 0x0, std::vector<float>* kappas = 0x0)
+    {
+        int cap = 0, n = 0;
+        detail::check(ecc_direct_lines_bound(m_h, &cap));
+        std::vector<float> s0(cap), s1(cap), kp(cap);
+        double metric = 0;
+        detail::check(ecc_direct_evaluate_for_image_pair(m_h, i, j, cap, &n, s0.data(), s1.data(), kp.data(), 0x0, &metric));
+        if (redundant_samples0) redundant_samples0->assign(s0.begin(), s0.begin() + n);
+        if (redundant_samples1) redundant_samples1->assign(s1.begin(), s1.begin() + n);
+        if (kappas) kappas->assign(kp.begin(), kp.begin() + n);
+        return metric;
+    }
+
+    /// Not implemented (ECC_ERR_UNSUPPORTED at evaluation time): the rectified fan-beam variant.
+    MetricDirect& setFanBeamConsistency(bool fbcc = true) { use_fbcc = fbcc; push_params(); return *this; }
+
+private:
+    MetricDirect(const MetricDirect&);
 };
 
 }  // namespace EpipolarConsistency

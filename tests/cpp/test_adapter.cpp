@@ -50,6 +50,12 @@ int main(int argc, char** argv)
         printf("pair02 %.17g %zu %zu %zu %.9g %.9g\n", pair_ecc, rs0.size(), kappas.size(), loc1.size(), kappas[0], loc0[0].first);
         ecc.setObjectRadius(50.0);
         printf("mean_r50 %.17g\n", ecc.evaluate());
+        {
+            MetricDirect direct(Ps, imgs.data(), n, n_u, n_v);
+            std::vector<float> d0, d1, dk;
+            const double pair = direct.evaluateForImagePair(0, 2, &d0, &d1, &dk);
+            printf("direct %.17g %.17g %zu\n", direct.evaluate(), pair, dk.size());
+        }
         for (size_t k = 0; k < dtrs.size(); ++k) delete dtrs[k];
     } catch (const std::exception& e) {
         fprintf(stderr, "exception: %s\n", e.what());

@@ -57,5 +57,10 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     assert abs(float(f[0]) - e7["ecc"]) < 1e-4 * e7["ecc"]
     assert [int(x) for x in f[1:4]] == [len(e7["kappas"])] * 3
     assert np.float32(f[4]) == e7["kappas"][0] and abs(float(f[5]) - e7["radon0"][0, 0]) < 2e-6
+    f = val["direct"].split()
+    dsum = oracle_mod.direct_evaluate(Ps, imgs)
+    dpair = oracle_mod.direct_pair(Ps[0], Ps[2], imgs[0], imgs[2], 0.0, oracle_mod.object_radius(Ps[0], s["n_u"], s["n_v"]))
+    assert abs(float(f[0]) - dsum["sum"]) < 1e-5 * dsum["sum"] and abs(float(f[1]) - dpair["metric"]) < 1e-5 * dpair["metric"]
+    assert int(f[2]) == len(dpair["kappas"])
     r50 = oracle_mod.evaluate_all(Ps, dtrs, s["n_u"], s["n_v"], object_radius_mm=50.0)
     assert abs(float(val["mean_r50"]) - r50["mean"]) < 1e-5 * r50["mean"]
