@@ -78,6 +78,9 @@ SIGNATURES = {
     "ecc_preprocess_defaults": (None, [_vp]),
     "ecc_preprocess": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ecc_host_intrinsics": (None, [_vp, _pf, _pf, _pf]),
+    "ecc_host_angular_range": (None, [_vp, _vp, _d, _pd, _pd]),
+    "ecc_host_angular_step": (_d, [_vp, _vp, _i, _i]),
+    "ecc_host_iso_center": (None, [_vp, _i, _vp]),
     "ecc_ctx_enable_timing": (_i, [_vp, _i]),
     "ecc_ctx_last_kernel_ms": (_i, [_vp, _i, _pf]),
 }

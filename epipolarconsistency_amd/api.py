@@ -557,3 +557,32 @@ def host_intrinsics(P):
     a, b, c = C.c_float(), C.c_float(), C.c_float()
     _lib.lib().ecc_host_intrinsics(C.c_void_p(P.ctypes.data), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def _P12(P):
+    return np.ascontiguousarray(np.asarray(P, np.float64).reshape(3, 4).T).reshape(12)
+
+
+def estimateAngularRange(P0, P1, object_radius_mm):
+    """ref: estimateAngularRange(join_pluecker(C0, C1), radius) (EpipolarConsistency.cpp:49-59)."""
+    a, b, A, B = C.c_double(), C.c_double(), _P12(P0), _P12(P1)
+    _lib.lib().ecc_host_angular_range(C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data), float(object_radius_mm),
+                                      C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def estimateAngularStep(P0, P1, n_u, n_v):
+    """ref: estimateAngularStep (EpipolarConsistency.cpp:61-68)."""
+    A, B = _P12(P0), _P12(P1)
+    return _lib.lib().ecc_host_angular_step(C.c_void_p(A.ctypes.data), C.c_void_p(B.ctypes.data), int(n_u), int(n_v))
+
+
+def estimateIsoCenter(Ps):
+    """ref: estimateIsoCenter (EpipolarConsistency.cpp:8-33)."""
+    flat = _Ps_colmajor(Ps)
+    O = np.zeros(4)
+    _lib.lib().ecc_host_iso_center(C.c_void_p(flat.ctypes.data), len(flat), C.c_void_p(O.ctypes.data))
+    return O
+
+
+estimateObjectRadius = host_object_radius  # ref: estimateObjectRadius (EpipolarConsistency.cpp:35-47)

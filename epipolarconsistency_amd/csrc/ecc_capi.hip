@@ -1407,3 +1407,55 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
     if (metric) *metric = m;
     return ECC_OK;
 }
+
+// ---- Metric's free helper functions (host, float64) ------------------------------------------------
+ECC_EXPORT void ecc_host_angular_range(const double* P0, const double* P1, double object_radius_mm, double* kappa_first,
+                                       double* kappa_second)
+{
+    double C0[4], C1[4], B[6];
+    ecc_host::camera_center(P0, C0);
+    ecc_host::camera_center(P1, C1);
+    ecc_host::join_points(C0, C1, B);
+    const double Pi = 3.14159265358979323846264338327950288419716939937510582;
+    // ref: ProjectiveGeometry.hxx:238-268: moment (L3,-L1,L0), direction (-L2,-L4,-L5), distance = |moment|/|direction|
+    const double mom = std::sqrt(B[3] * B[3] + B[1] * B[1] + B[0] * B[0]);
+    const double dir = std::sqrt(B[2] * B[2] + B[4] * B[4] + B[5] * B[5]);
+    const double dist = mom / dir;
+    double km = 0.5 * Pi;  // baseline intersects the object: half circle (ref: EpipolarConsistency.cpp:53-55)
+    if (!(dist <= object_radius_mm)) km = std::fabs(std::asin(object_radius_mm / dist));
+    *kappa_first = -km;
+    *kappa_second = km;
+}
+
+ECC_EXPORT double ecc_host_angular_step(const double* P0, const double* P1, int n_u, int n_v)
+{
+    const double r0 = ecc_host::object_radius(P0, n_u, n_v), r1 = ecc_host::object_radius(P1, n_u, n_v);
+    double a, b;
+    ecc_host_angular_range(P0, P1, r0 > r1 ? r0 : r1, &a, &b);
+    return 2.0 * (b - a) / std::sqrt((double)(n_u * n_u + n_v * n_v));
+}
+
+ECC_EXPORT void ecc_host_iso_center(const double* Ps, int n_views, double* O)
+{
+    // A = n I - sum V V^T, b = sum (C - V (V.C)); solve A x = b (3x3, symmetric positive definite for
+    // non-parallel rays; the reference solves it with a JacobiSVD, Cramer's rule gives the same x)
+    double A[9] = {(double)n_views, 0, 0, 0, (double)n_views, 0, 0, 0, (double)n_views}, b[3] = {0, 0, 0};
+    for (int v = 0; v < n_views; ++v) {
+        const double* P = Ps + 12 * (size_t)v;
+        double C[4];
+        ecc_host::camera_center(P, C);
+        double V[3] = {P[2], P[5], P[8]};
+        const double nv = std::sqrt(V[0] * V[0] + V[1] * V[1] + V[2] * V[2]);
+        for (double& x : V) x /= nv;
+        const double vc = V[0] * C[0] + V[1] * C[1] + V[2] * C[2];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) A[r + 3 * c] -= V[r] * V[c];
+            b[r] += C[r] - V[r] * vc;
+        }
+    }
+    const double det = ecc_host::det3(A, A + 3, A + 6);
+    O[0] = ecc_host::det3(b, A + 3, A + 6) / det;
+    O[1] = ecc_host::det3(A, b, A + 6) / det;
+    O[2] = ecc_host::det3(A, A + 3, b) / det;
+    O[3] = 1.0;
+}

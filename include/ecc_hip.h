@@ -249,6 +249,16 @@ void ecc_host_pinvT(const double* P, float* PinvT12);
 void ecc_host_source_position(const double* P, float* C4);
 double ecc_host_object_radius(const double* P, int n_u, int n_v);
 
+/* ref: estimateAngularRange(join_pluecker(C0, C1), radius) (EpipolarConsistency.cpp:49-59): the kappa interval
+ * of epipolar planes through the baseline of P0, P1 that touch a sphere of object_radius_mm about the origin. */
+void ecc_host_angular_range(const double* P0, const double* P1, double object_radius_mm, double* kappa_first,
+                            double* kappa_second);
+/* ref: estimateAngularStep(P0, P1, n_u, n_v) (EpipolarConsistency.cpp:61-68). */
+double ecc_host_angular_step(const double* P0, const double* P1, int n_u, int n_v);
+/* ref: estimateIsoCenter(Ps) (EpipolarConsistency.cpp:8-33): least-squares intersection of the principal rays;
+ * O receives 4 doubles (w = 1). */
+void ecc_host_iso_center(const double* Ps, int n_views, double* O);
+
 /* Last kernel timings measured with HIP events on the context's stream (ms), for bench.py:
  * which = 0 pair kernel of the last evaluate, 1 Radon kernel of the last radon_compute[_batch],
  * 2 pre-processing kernel of the last ecc_preprocess.

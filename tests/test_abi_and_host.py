@@ -68,3 +68,27 @@ def test_slab_layout_size():
     import epipolarconsistency_amd as E
     assert E.slab_floats(768, 768) == 770 * 800
     assert E.slab_floats(96, 80) == 98 * 96
+
+
+def test_metric_helper_functions():
+    """estimateAngularRange / estimateAngularStep / estimateIsoCenter (ref: EpipolarConsistency.cpp:8-68) are host
+    functions of the library; no device needed."""
+    import numpy as np
+    from epipolarconsistency_amd import api, synthetic, geometry
+    Ps = synthetic.short_scan(12, 256, 256, 1.2)
+    # all principal rays of the circular scan pass through the origin
+    O = api.estimateIsoCenter(Ps)
+    assert np.abs(O[:3]).max() < 1e-6 and O[3] == 1.0
+    shifted = [P @ geometry.rigid_transform(tx=-7.0, ty=2.0, tz=3.5) for P in Ps]  # world moved: centre at (7,-2,-3.5)
+    assert np.allclose(api.estimateIsoCenter(shifted)[:3], [7.0, -2.0, -3.5], atol=1e-6)
+    # baseline distance d of two sources at sid on a circle, angle phi apart: sid*cos(phi/2); kappa_max = asin(r/d)
+    sid, r = 744.3, 100.0
+    C0, C1 = geometry.camera_center(Ps[0])[:3], geometry.camera_center(Ps[3])[:3]
+    d = np.linalg.norm(np.cross(C0, C1)) / np.linalg.norm(C1 - C0)
+    a, b = api.estimateAngularRange(Ps[0], Ps[3], r)
+    assert abs(b - np.arcsin(r / d)) < 1e-12 and a == -b
+    a, b = api.estimateAngularRange(Ps[0], Ps[3], 2 * sid)
+    assert abs(b - np.pi / 2) < 1e-15
+    rad = max(api.estimateObjectRadius(Ps[0], 256, 256), api.estimateObjectRadius(Ps[3], 256, 256))
+    a, b = api.estimateAngularRange(Ps[0], Ps[3], rad)
+    assert abs(api.estimateAngularStep(Ps[0], Ps[3], 256, 256) - 2 * (b - a) / np.sqrt(2 * 256 ** 2)) < 1e-15
