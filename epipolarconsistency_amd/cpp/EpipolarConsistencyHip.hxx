@@ -378,7 +378,7 @@ public:
         return metric;
     }
 
-    /// Not implemented (ECC_ERR_UNSUPPORTED at evaluation time): the rectified fan-beam variant.
+    /// ref: setFanBeamConsistency: use the rectified fan-beam weighting instead of the derivative.
     MetricDirect& setFanBeamConsistency(bool fbcc = true) { use_fbcc = fbcc; push_params(); return *this; }
 
 private:

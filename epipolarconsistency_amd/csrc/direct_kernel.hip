@@ -12,6 +12,9 @@
 //                        bilinear rule on the image in global memory; neighbouring threads are neighbouring lines
 //                        of the pencil, so their taps share cache lines
 //   direct_reduce_kernel wave per pair: sum (v0-v1)^2 dkappa in float64 (fixed order), cost image entry
+// setFanBeamConsistency (RectifiedFBCC.h, ...Direct.cpp:133-196): the pair kernel also builds the two rectifying
+// homographies, and each line thread derives its LinePerspectivity weighting in float64 before a weighted plain
+// line integral -- the reference does that per line on the host.
 // Arithmetic follows oracle/ecc_oracle.c (eccor_direct_pair): line integrals are bit-identical for identical
 // lines; the lines themselves differ from the oracle's only through the float64 sin/cos of the two libms.
 #include <hip/hip_runtime.h>
@@ -39,6 +42,7 @@ __global__ __launch_bounds__(64) void direct_view_kernel(const double* __restric
         for (int j = 0; j < 3; ++j) out.L[3 * i + j] = f.L[i][j];
     }
     out.radius = ecc_host::object_radius(P, n_u, n_v);
+    for (int k = 0; k < 12; ++k) out.P[k] = P[k];
     views[v] = out;
 }
 
@@ -98,6 +102,26 @@ __global__ __launch_bounds__(256) void direct_pair_kernel(EccDirectParams p)
         r.E90[k] /= n90;
     }
     r.pad = 0;
+    for (int k = 0; k < 9; ++k) r.H0[k] = r.H1[k] = 0;
+    r.dvec[0] = -B[2]; r.dvec[1] = -B[4]; r.dvec[2] = -B[5];
+    r.Eplane[0] = r.Eplane[1] = r.Eplane[2] = r.Eplane[3] = 0;
+    if (p.use_fbcc) {
+        // virtual detector plane spanned by the baseline direction and its moment, rectifying homographies
+        // (ref: EpipolarConsistencyDirect.cpp:133-151)
+        const double U[3] = {r.dvec[0] / dir, r.dvec[1] / dir, r.dvec[2] / dir};
+        const double Vv[3] = {B[3] / mom, -B[1] / mom, B[0] / mom};
+        ecc_host::cross3(U, Vv, r.Eplane);
+        r.Eplane[3] = 0;
+        ecc_host::RowQR f;
+        for (int which = 0; which < 2; ++which) {
+            const EccDirectView& W = which ? V1 : V0;
+            for (int a = 0; a < 3; ++a) {
+                for (int q = 0; q < 4; ++q) f.Q[a][q] = W.Q[4 * a + q];
+                for (int b = 0; b < 3; ++b) f.L[a][b] = W.L[3 * a + b];
+            }
+            ecc_host::fbcc_homography(f, W.C, U, Vv, r.Eplane, which ? r.H1 : r.H0);
+        }
+    }
     p.pairs[local] = r;
 }
 
@@ -142,6 +166,41 @@ __device__ float direct_line_integral(const float* __restrict__ img, int n_u, in
     return sump - summ;
 }
 
+// ref: EpipolarConsistencyDirect.cu:87-101 (the fbcc_d branch): rectified by weighting, no derivative.
+__device__ float direct_line_integral_fbcc(const float* __restrict__ img, int n_u, int n_v, float l0, float l1, float l2,
+                                           const ecc_host::FbccInfo& fbcc)
+{
+    float o0 = -l2 * l0, o1 = -l2 * l1;
+    const float d0 = l1, d1 = -l0;
+    float ts[4] = {(1 - o0) / d0, (n_u - 1 - o0) / d0, (1 - o1) / d1, (n_v - 1 - o1) / d1};
+    if ((double)(d0 * d0) < 1e-12) ts[0] = -(ts[1] = 1e10f);
+    if ((double)(d1 * d1) < 1e-12) ts[2] = -(ts[3] = 1e10f);
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (ts[i] > ts[i + 1]) {
+                const float tmp = ts[i];
+                ts[i] = ts[i + 1];
+                ts[i + 1] = tmp;
+            }
+    const float t_min = ts[1], t_max = ts[2];
+    {
+        const float u = o0 + t_min * d0, v = o1 + t_min * d1;
+        if (!(u <= n_u && v <= n_v && u >= 0 && v >= 0)) return 0.f;
+    }
+    const float step = 0.4f;
+    o0 += .5f;
+    o1 += .5f;
+    float sum = 0;
+    for (float t = t_min; t <= t_max; t += step) {
+        const float u_prime = fbcc.transform(t) - fbcc.t_prime_ak;
+        const float fbcc_weight = fbcc.derivative(t) / sqrtf(u_prime * u_prime + fbcc.d_l_kappa_C_sq);
+        sum += step * ecc_tex_global(img, n_u, n_v, o0 + t * d0, o1 + t * d1) * fbcc_weight;
+    }
+    return sum;
+}
+
 __global__ __launch_bounds__(256) void direct_lines_kernel(EccDirectParams p)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,7 +223,15 @@ __global__ __launch_bounds__(256) void direct_lines_kernel(EccDirectParams p)
     const double nn = sqrt(l[0] * l[0] + l[1] * l[1]);
     const float lf0 = (float)(l[0] / nn), lf1 = (float)(l[1] / nn), lf2 = (float)(l[2] / nn);
     const float* img = p.images + (int64_t)(which ? r.j : r.i) * p.image_stride;
-    const float v = direct_line_integral(img, p.n_u, p.n_v, lf0, lf1, lf2);
+    float v;
+    if (p.use_fbcc) {
+        ecc_host::FbccInfo info;
+        const float lf[3] = {lf0, lf1, lf2};
+        ecc_host::fbcc_line_info(V.P, V.C, which ? r.H1 : r.H0, r.dvec, r.Eplane, lf, &info);
+        v = direct_line_integral_fbcc(img, p.n_u, p.n_v, lf0, lf1, lf2, info);
+    } else {
+        v = direct_line_integral(img, p.n_u, p.n_v, lf0, lf1, lf2);
+    }
     p.samples[((size_t)pair * 2 + which) * p.n_max + k] = v;
     if (p.debug_lines && pair == 0) {
         float* dl = p.debug_lines + 6 * (size_t)k + 3 * which;

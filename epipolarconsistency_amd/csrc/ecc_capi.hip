@@ -1272,7 +1272,6 @@ ECC_EXPORT int ecc_direct_lines_bound(const ecc_direct* d, int* capacity)
 ECC_EXPORT int ecc_direct_evaluate(ecc_direct* d, float* cost_nxn, double* cost_sum)
 {
     if (!d || !cost_sum) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
-    if (d->use_fbcc) return fail(ECC_ERR_UNSUPPORTED, "fan-beam consistency (FBCC) is not implemented");
     if (d->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     const int64_t n = d->n_images;  // ref: getNumberOfProjetions() = Is.size()
     if (d->n_views < n) return fail(ECC_ERR_INVALID_ARGUMENT, "fewer projection matrices than images");
@@ -1324,6 +1323,7 @@ ECC_EXPORT int ecc_direct_evaluate(ecc_direct* d, float* cost_nxn, double* cost_
             p.n_max = d->n_max_capacity;
             p.object_radius_mm = direct_radius(d);
             p.dkappa = d->dkappa;
+            p.use_fbcc = d->use_fbcc ? 1 : 0;
             HIP_TRY(ecc_launch_direct_batch(&p, d->total_d, ctx->stream));
         }
     }
@@ -1339,7 +1339,6 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
                                                   float* rs1, float* kappas, float* lines01, double* metric)
 {
     if (!d || !n_lines) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
-    if (d->use_fbcc) return fail(ECC_ERR_UNSUPPORTED, "fan-beam consistency (FBCC) is not implemented");
     if (d->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     if (i < 0 || j < 0 || i >= d->n_images || j >= d->n_images || i >= d->n_views || j >= d->n_views)
         return fail(ECC_ERR_INVALID_ARGUMENT, "view index out of range");
@@ -1381,6 +1380,7 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
     p.n_max = n_max;
     p.object_radius_mm = direct_radius(d);
     p.dkappa = d->dkappa;
+    p.use_fbcc = d->use_fbcc ? 1 : 0;
     std::vector<float> v((size_t)n_max * 2), L((size_t)n_max * 6), K((size_t)n_max);
     int n = 0;
     double m = 0;

@@ -272,5 +272,114 @@ ECC_HD inline void join_line_point(const double* L, const double* X, double* E)
     E[3] = -X[0] * L[3] + X[1] * L[1] - X[2] * L[0];
 }
 
+// ---- rectified fan-beam consistency (FBCC), ref: RectifiedFBCC.h, EpipolarConsistencyDirect.cpp:133-196 ----
+// ref: ProjectiveGeometry.hxx:202-214 (meet of two planes -> line), :226-235 (meet of a line and a plane)
+ECC_HD inline void meet_planes(const double* A, const double* B, double* L)
+{
+    L[0] = A[2] * B[3] - A[3] * B[2];
+    L[1] = A[3] * B[1] - A[1] * B[3];
+    L[2] = A[1] * B[2] - A[2] * B[1];
+    L[3] = A[0] * B[3] - A[3] * B[0];
+    L[4] = A[2] * B[0] - A[0] * B[2];
+    L[5] = A[0] * B[1] - A[1] * B[0];
+}
+ECC_HD inline void meet_line_plane(const double* L, const double* P, double* X)
+{
+    X[0] = -P[1] * L[0] - P[2] * L[1] - P[3] * L[2];
+    X[1] = +P[0] * L[0] - P[2] * L[3] - P[3] * L[4];
+    X[2] = +P[0] * L[1] + P[1] * L[3] - P[3] * L[5];
+    X[3] = +P[0] * L[2] + P[1] * L[4] + P[2] * L[5];
+}
+// ref: ProjectiveGeometry.hxx:38-54, 75-91 (dehomogenize)
+ECC_HD inline void dehom3(double* X)
+{
+    if (X[3] > 1e-12 || X[3] < -1e-12) { X[0] /= X[3]; X[1] /= X[3]; X[2] /= X[3]; X[3] = 1; }
+    else { X[3] = 0; const double n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]); X[0] /= n; X[1] /= n; X[2] /= n; }
+}
+ECC_HD inline void dehom2(double* x)
+{
+    if (x[2] > 1e-11 || x[2] < -1e-11) { x[0] /= x[2]; x[1] /= x[2]; x[2] = 1; }
+    else { x[2] = 0; const double n = sqrt(x[0] * x[0] + x[1] * x[1]); x[0] /= n; x[1] /= n; }
+}
+
+// H = P_E * centralProjectionToPlane(C, E) * P^+ (3 x 3, row-major), P^+ = Q^T L^-1 from the row-QR
+// (ref: ...Direct.cpp:143-151, ProjectiveGeometry.hxx:333-342).
+ECC_HD inline void fbcc_homography(const RowQR& f, const double* C, const double* U, const double* V, const double* E,
+                                   double* H)
+{
+    double Linv[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Pinv[4][3], CP[4][4], T[3][4], PE[3][4];
+    for (int i = 0; i < 3; ++i) {
+        Linv[i][i] = 1.0 / f.L[i][i];
+        for (int j = 0; j < i; ++j) {
+            double sum = 0;
+            for (int k = j; k < i; ++k) sum += f.L[i][k] * Linv[k][j];
+            Linv[i][j] = -sum / f.L[i][i];
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double sum = 0;
+            for (int k = 0; k < 3; ++k) sum += f.Q[k][i] * Linv[k][j];
+            Pinv[i][j] = sum;
+        }
+    CP[0][0] = +C[1] * E[1] + C[2] * E[2] + C[3] * E[3]; CP[0][1] = -C[0] * E[1]; CP[0][2] = -C[0] * E[2]; CP[0][3] = -C[0] * E[3];
+    CP[1][0] = -C[1] * E[0]; CP[1][1] = +C[0] * E[0] + C[2] * E[2] + C[3] * E[3]; CP[1][2] = -C[1] * E[2]; CP[1][3] = -C[1] * E[3];
+    CP[2][0] = -C[2] * E[0]; CP[2][1] = -C[2] * E[1]; CP[2][2] = +C[0] * E[0] + C[3] * E[3] + C[1] * E[1]; CP[2][3] = -C[2] * E[3];
+    CP[3][0] = -C[3] * E[0]; CP[3][1] = -C[3] * E[1]; CP[3][2] = -C[3] * E[2]; CP[3][3] = +C[0] * E[0] + C[1] * E[1] + C[2] * E[2];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 4; ++k) PE[i][k] = 0;
+    for (int k = 0; k < 3; ++k) { PE[0][k] = U[k]; PE[1][k] = V[k]; }
+    PE[2][3] = 1.0;  // pixel_spacing
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double sum = 0;
+            for (int k = 0; k < 4; ++k) sum += PE[i][k] * CP[k][j];
+            T[i][j] = sum;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double sum = 0;
+            for (int k = 0; k < 4; ++k) sum += T[i][k] * Pinv[k][j];
+            H[3 * i + j] = sum;
+        }
+}
+
+// ref: RectifiedFBCC.h:18-90 (LinePerspectivity + FBCC_weighting_info; float members, float arithmetic)
+struct FbccInfo {
+    float a, b, c, d, t_prime_ak, d_l_kappa_C_sq;
+    ECC_HD float transform(float t) const { return (a * t + b) / (c * t + d); }
+    ECC_HD float derivative(float t) const { return (a * d - b * c) / (c * c * t * t + 2 * c * d * t + d * d); }
+};
+
+// ref: ...Direct.cpp:153-191: per-line weighting info from the (float) epipolar line lf of the view (P, C, H).
+ECC_HD inline void fbcc_line_info(const double* P, const double* C, const double* H, const double* dvec, const double* E,
+                                  const float* lf, FbccInfo* out)
+{
+    const double l[3] = {lf[0], lf[1], lf[2]};
+    double Ek[4], EB[4], M[6], Ak[4], ak[3], dist = 0;
+    for (int k = 0; k < 4; ++k) Ek[k] = P[0 + 3 * k] * l[0] + P[1 + 3 * k] * l[1] + P[2 + 3 * k] * l[2];  // P^T l
+    EB[0] = dvec[0]; EB[1] = dvec[1]; EB[2] = dvec[2];
+    EB[3] = -(dvec[0] * C[0] + dvec[1] * C[1] + dvec[2] * C[2]);
+    meet_planes(EB, Ek, M);
+    meet_line_plane(M, E, Ak);
+    dehom3(Ak);
+    for (int k = 0; k < 4; ++k) {
+        const double diff = Ak[k] - C[k];
+        dist += diff * diff;
+    }
+    const float d_px = (float)(sqrt(dist) / 1.0);
+    out->d_l_kappa_C_sq = d_px * d_px;
+    for (int k = 0; k < 3; ++k) ak[k] = P[k + 0] * Ak[0] + P[k + 3] * Ak[1] + P[k + 6] * Ak[2] + P[k + 9] * Ak[3];
+    dehom2(ak);
+    const double a = H[0] * l[1] - H[3] * l[0];
+    const double b = H[2] - H[0] * l[0] * l[2];
+    const double c = H[6] * l[1] - H[7] * l[0];
+    const double d = H[8] - H[6] * l[0] * l[2] - H[7] * l[1] * l[2];
+    out->a = (float)a; out->b = (float)b; out->c = (float)c; out->d = (float)d;
+    if (out->a * out->d - out->b * out->c < 0) { out->a *= -1; out->b *= -1; }
+    const double t_ak = l[1] * ak[0] / ak[2] - l[0] * ak[1] / ak[2];
+    out->t_prime_ak = out->transform((float)t_ak);
+}
+
 }  // namespace ecc_host
 #endif

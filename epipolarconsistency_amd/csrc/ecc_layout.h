@@ -117,11 +117,15 @@ struct EccDirectView {
     double Q[12];    // row-QR of P: orthonormal rows (3 x 4)
     double L[9];     // lower-triangular factor (3 x 3)
     double radius;   // estimateObjectRadius of this view
+    double P[12];    // the projection matrix itself (column-major), for the FBCC weighting
 };
 struct EccDirectPair {
     double E0[4], E90[4];     // the two reference epipolar planes (Hessian normal form)
     double k_first, dkappa;   // kappa grid: k_first + dkappa * k
     int n_lines, i, j, pad;
+    // FBCC only (ref: EpipolarConsistencyDirect.cpp:133-151): rectifying homographies (row-major 3 x 3),
+    // baseline direction, virtual detector plane
+    double H0[9], H1[9], dvec[3], Eplane[4];
 };
 struct EccDirectParams {
     const float* images;        // n_views images, n_v x n_u, u fastest
@@ -138,6 +142,7 @@ struct EccDirectParams {
     int64_t first, count;
     int n_views, n_u, n_v, n_max;
     double object_radius_mm, dkappa;
+    int use_fbcc;               // MetricDirect::setFanBeamConsistency
 };
 
 // ---- evaluateForImagePair (E7, visualisation) -------------------------------------------------

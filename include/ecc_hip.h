@@ -218,8 +218,9 @@ int ecc_metric_debug_K01(ecc_metric* m, int64_t first, int64_t count, float* K01
  * MetricRadonIntermediate per evaluation and meant for few views / images that change every iteration.
  * images: n x n_v x n_u float32.  on_device = 1: the metric BORROWS the device pointer (as the reference borrows
  * its textures); on_device = 0: it uploads and owns a copy.
- * The rectified fan-beam variant (setFanBeamConsistency, RectifiedFBCC.h) is not implemented: use_fbcc != 0
- * makes the evaluate calls fail with ECC_ERR_UNSUPPORTED. */
+ * use_fbcc != 0 (setFanBeamConsistency): the rectified fan-beam variant -- plain line integrals weighted by the
+ * line perspectivity onto a virtual detector through the baseline (RectifiedFBCC.h, ...Direct.cpp:133-196)
+ * instead of the derivative. */
 typedef struct ecc_direct ecc_direct;
 int ecc_direct_create(ecc_ctx* ctx, int n_images, const float* images, int on_device, int n_u, int n_v,
                       ecc_direct** out);

@@ -300,10 +300,12 @@ def intrinsics(P):
     return a.value, b.value, c.value
 
 
-def direct_pair(P0, P1, img0, img1, dkappa=0.0, object_radius_mm=0.0):
-    """MetricDirect for one pair (ref: EpipolarConsistencyDirect.cpp:67-219, fbcc = false).  Returns dict(metric,
-    samples0, samples1, kappas, lines (n,6))."""
+def direct_pair(P0, P1, img0, img1, dkappa=0.0, object_radius_mm=0.0, fbcc=False):
+    """MetricDirect for one pair (ref: EpipolarConsistencyDirect.cpp:67-219; fbcc: the rectified fan-beam
+    weighting of :133-196 instead of the derivative).  Returns dict(metric, samples0, samples1, kappas, lines (n,6))."""
     L = lib()
+    L.eccor_set_direct_fbcc.argtypes = [C.c_int]
+    L.eccor_set_direct_fbcc(1 if fbcc else 0)
     L.eccor_direct_pair.argtypes = [_f64p, _f64p, _f32p, _f32p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
                                     _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_double)]
     L.eccor_direct_pair.restype = C.c_int
@@ -320,7 +322,7 @@ def direct_pair(P0, P1, img0, img1, dkappa=0.0, object_radius_mm=0.0):
     return dict(metric=m.value, samples0=v0[:n], samples1=v1[:n], kappas=kap[:n], lines=lines[:6 * n].reshape(n, 6))
 
 
-def direct_evaluate(Ps, imgs, dkappa=0.0, object_radius_mm=0.0):
+def direct_evaluate(Ps, imgs, dkappa=0.0, object_radius_mm=0.0, fbcc=False):
     """ref: MetricDirect::evaluate (EpipolarConsistencyDirect.cpp:247-259): SUM over pairs and the cost image
     (index i + j*n, i<j); the radius default is Metric::getObjectRadius (first projection)."""
     n = len(imgs)
@@ -330,7 +332,7 @@ def direct_evaluate(Ps, imgs, dkappa=0.0, object_radius_mm=0.0):
     total = 0.0
     for i in range(n):
         for j in range(i + 1, n):
-            e = direct_pair(Ps[i], Ps[j], imgs[i], imgs[j], dkappa, radius)["metric"]
+            e = direct_pair(Ps[i], Ps[j], imgs[i], imgs[j], dkappa, radius, fbcc)["metric"]
             total += e
             cost[j, i] = e
     return dict(sum=total, cost=cost)

@@ -1082,7 +1082,160 @@ static float or_direct_line_integral(const float *img, int n_u, int n_v, const f
     return sump - summ;
 }
 
-/* ref: EpipolarConsistencyDirect.cpp:67-219 (computeForImagePair, fbcc == false) with computeEpipolarLines
+/* ---- rectified fan-beam consistency (FBCC) weighting, ref: RectifiedFBCC.h + ...Direct.cpp:133-196 ---- */
+
+/* ref: RectifiedFBCC.h:18-90 (LinePerspectivity: a, b, c, d as floats; transform, derivative in float) */
+typedef struct { float a, b, c, d; float t_prime_ak, d_l_kappa_C_sq; } or_fbcc_info;
+
+static float or_phi_transform(const or_fbcc_info *f, float t) { return (f->a * t + f->b) / (f->c * t + f->d); }
+static float or_phi_derivative(const or_fbcc_info *f, float t)
+{
+    return (f->a * f->d - f->b * f->c) / (f->c * f->c * t * t + 2 * f->c * f->d * t + f->d * f->d);
+}
+
+/* ref: ProjectiveGeometry.hxx:202-214 (meet of two planes -> line) and :226-235 (meet of a line and a plane) */
+static void or_meet_planes(const double *A, const double *B, double *L)
+{
+    L[0] = A[2] * B[3] - A[3] * B[2];
+    L[1] = A[3] * B[1] - A[1] * B[3];
+    L[2] = A[1] * B[2] - A[2] * B[1];
+    L[3] = A[0] * B[3] - A[3] * B[0];
+    L[4] = A[2] * B[0] - A[0] * B[2];
+    L[5] = A[0] * B[1] - A[1] * B[0];
+}
+static void or_meet_line_plane(const double *L, const double *P, double *X)
+{
+    X[0] = -P[1] * L[0] - P[2] * L[1] - P[3] * L[2];
+    X[1] = +P[0] * L[0] - P[2] * L[3] - P[3] * L[4];
+    X[2] = +P[0] * L[1] + P[1] * L[3] - P[3] * L[5];
+    X[3] = +P[0] * L[2] + P[1] * L[4] + P[2] * L[5];
+}
+/* ref: ProjectiveGeometry.hxx:75-91 / :38-54 (dehomogenize) */
+static void or_dehom3(double *X)
+{
+    if (X[3] > 1e-12 || X[3] < -1e-12) { X[0] /= X[3]; X[1] /= X[3]; X[2] /= X[3]; X[3] = 1; }
+    else { double n; X[3] = 0; n = sqrt(X[0] * X[0] + X[1] * X[1] + X[2] * X[2]); X[0] /= n; X[1] /= n; X[2] /= n; }
+}
+static void or_dehom2(double *x)
+{
+    if (x[2] > 1e-11 || x[2] < -1e-11) { x[0] /= x[2]; x[1] /= x[2]; x[2] = 1; }
+    else { double n; x[2] = 0; n = sqrt(x[0] * x[0] + x[1] * x[1]); x[0] /= n; x[1] /= n; }
+}
+
+/* Pair-level part: the rectifying homography H = P_E * centralProjectionToPlane(C, E) * P^+ of one view
+ * (ref: ...Direct.cpp:133-151, ProjectiveGeometry.hxx:333-342).  H is 3x3 row-major here. */
+static void or_fbcc_homography(const double *P, const double *C, const double *U, const double *V,
+                               const double *E, double *H)
+{
+    or_rowqr f;
+    double Linv[3][3], Pinv[4][3], CP[4][4], T[3][4], PE[3][4];
+    int i, j, k;
+    or_row_qr(P, &f);
+    /* L^-1 (lower triangular), then P^+ = Q^T L^-1 */
+    memset(Linv, 0, sizeof(Linv));
+    for (i = 0; i < 3; i++) {
+        Linv[i][i] = 1.0 / f.L[i][i];
+        for (j = 0; j < i; j++) {
+            double sum = 0;
+            for (k = j; k < i; k++) sum += f.L[i][k] * Linv[k][j];
+            Linv[i][j] = -sum / f.L[i][i];
+        }
+    }
+    for (i = 0; i < 4; i++)
+        for (j = 0; j < 3; j++) {
+            double sum = 0;
+            for (k = 0; k < 3; k++) sum += f.Q[k][i] * Linv[k][j];
+            Pinv[i][j] = sum;
+        }
+    CP[0][0] = +C[1] * E[1] + C[2] * E[2] + C[3] * E[3]; CP[0][1] = -C[0] * E[1]; CP[0][2] = -C[0] * E[2]; CP[0][3] = -C[0] * E[3];
+    CP[1][0] = -C[1] * E[0]; CP[1][1] = +C[0] * E[0] + C[2] * E[2] + C[3] * E[3]; CP[1][2] = -C[1] * E[2]; CP[1][3] = -C[1] * E[3];
+    CP[2][0] = -C[2] * E[0]; CP[2][1] = -C[2] * E[1]; CP[2][2] = +C[0] * E[0] + C[3] * E[3] + C[1] * E[1]; CP[2][3] = -C[2] * E[3];
+    CP[3][0] = -C[3] * E[0]; CP[3][1] = -C[3] * E[1]; CP[3][2] = -C[3] * E[2]; CP[3][3] = +C[0] * E[0] + C[1] * E[1] + C[2] * E[2];
+    memset(PE, 0, sizeof(PE));
+    for (k = 0; k < 3; k++) { PE[0][k] = U[k]; PE[1][k] = V[k]; }
+    PE[2][3] = 1.0; /* pixel_spacing */
+    for (i = 0; i < 3; i++)
+        for (j = 0; j < 4; j++) {
+            double sum = 0;
+            for (k = 0; k < 4; k++) sum += PE[i][k] * CP[k][j];
+            T[i][j] = sum;
+        }
+    for (i = 0; i < 3; i++)
+        for (j = 0; j < 3; j++) {
+            double sum = 0;
+            for (k = 0; k < 4; k++) sum += T[i][k] * Pinv[k][j];
+            H[3 * i + j] = sum;
+        }
+}
+
+/* Line-level part (ref: ...Direct.cpp:153-191): l is the epipolar line (float, as uploaded), dvec the baseline
+ * direction, E the virtual detector plane. */
+static void or_fbcc_line_info(const double *P, const double *C, const double *H, const double *dvec,
+                              const double *E, const float *lf, or_fbcc_info *out)
+{
+    double l[3] = {lf[0], lf[1], lf[2]}, Ek[4], EB[4], M[6], Ak[4], ak[3], diff, dist = 0, t_ak;
+    double a, b, c, d;
+    int k;
+    for (k = 0; k < 4; k++) Ek[k] = P[0 + 3 * k] * l[0] + P[1 + 3 * k] * l[1] + P[2 + 3 * k] * l[2]; /* P^T l */
+    EB[0] = dvec[0]; EB[1] = dvec[1]; EB[2] = dvec[2];
+    EB[3] = -(dvec[0] * C[0] + dvec[1] * C[1] + dvec[2] * C[2]);
+    or_meet_planes(EB, Ek, M);
+    or_meet_line_plane(M, E, Ak);
+    or_dehom3(Ak);
+    for (k = 0; k < 4; k++) { diff = Ak[k] - C[k]; dist += diff * diff; }
+    {
+        float d_px = (float)(sqrt(dist) / 1.0);
+        out->d_l_kappa_C_sq = d_px * d_px;
+    }
+    for (k = 0; k < 3; k++) ak[k] = P[k + 0] * Ak[0] + P[k + 3] * Ak[1] + P[k + 6] * Ak[2] + P[k + 9] * Ak[3];
+    or_dehom2(ak);
+    /* ref: RectifiedFBCC.h:46-56 (LinePerspectivity(H, l)) */
+    a = H[0] * l[1] - H[3] * l[0];
+    b = H[2] - H[0] * l[0] * l[2];
+    c = H[6] * l[1] - H[7] * l[0];
+    d = H[8] - H[6] * l[0] * l[2] - H[7] * l[1] * l[2];
+    out->a = (float)a; out->b = (float)b; out->c = (float)c; out->d = (float)d;
+    if (out->a * out->d - out->b * out->c < 0) { out->a *= -1; out->b *= -1; }
+    t_ak = l[1] * ak[0] / ak[2] - l[0] * ak[1] / ak[2]; /* project_to_line, :33-35 */
+    out->t_prime_ak = or_phi_transform(out, (float)t_ak);
+}
+
+/* ref: EpipolarConsistencyDirect.cu:87-101 (the fbcc_d branch of kernel_computeLineIntegrals) */
+static float or_direct_line_integral_fbcc(const float *img, int n_u, int n_v, const float *line,
+                                          const or_fbcc_info *fbcc)
+{
+    float l[3] = {line[0], line[1], line[2]};
+    float o[2] = {-l[2] * l[0], -l[2] * l[1]};
+    float d[2] = {l[1], -l[0]};
+    float ts[4], t_min, t_max, t, sum = 0;
+    const float step = 0.4f;
+    ts[0] = (1 - o[0]) / d[0];
+    ts[1] = (n_u - 1 - o[0]) / d[0];
+    ts[2] = (1 - o[1]) / d[1];
+    ts[3] = (n_v - 1 - o[1]) / d[1];
+    if (d[0] * d[0] < 1e-12) ts[0] = -(ts[1] = 1e10f);
+    if (d[1] * d[1] < 1e-12) ts[2] = -(ts[3] = 1e10f);
+    or_sort4(ts);
+    t_min = ts[1];
+    t_max = ts[2];
+    {
+        float u = o[0] + t_min * d[0], v = o[1] + t_min * d[1];
+        if (!(u <= n_u && v <= n_v && u >= 0 && v >= 0)) return 0.f;
+    }
+    o[0] += .5f;
+    o[1] += .5f;
+    for (t = t_min; t <= t_max; t += step) {
+        float u_prime = or_phi_transform(fbcc, t) - fbcc->t_prime_ak;
+        float fbcc_weight = or_phi_derivative(fbcc, t) / sqrtf(u_prime * u_prime + fbcc->d_l_kappa_C_sq);
+        sum += step * eccor_tex2d(img, n_u, n_v, o[0] + t * d[0], o[1] + t * d[1]) * fbcc_weight;
+    }
+    return sum;
+}
+
+static int g_direct_fbcc = 0;
+ECCOR_API void eccor_set_direct_fbcc(int v) { g_direct_fbcc = v; }
+
+/* ref: EpipolarConsistencyDirect.cpp:67-219 (computeForImagePair; fbcc via eccor_set_direct_fbcc) with computeEpipolarLines
  * (:23-65) and estimateAngularRange (EpipolarConsistency.cpp:49-59).  object_radius_mm <= 0: the larger of the
  * two views' estimates (:88-90).  Output arrays hold `capacity` entries (nullable); lines01: 6 floats per kappa.
  * Returns n_lines; *metric = sum (v0-v1)^2 dkappa (float difference and square, double sum, :206-208). */
@@ -1120,6 +1273,15 @@ ECCOR_API int eccor_direct_pair(const double *P0, const double *P1, const float 
     for (i = 0; i < 4; i++) { E0[i] /= n0; E90[i] /= n90; }
     or_row_qr(P0, &f0);
     or_row_qr(P1, &f1);
+    double dvec[3] = {-B[2], -B[4], -B[5]}, mvec[3] = {B[3], -B[1], B[0]}, U[3], V[3], Eplane[4], H0[9], H1[9];
+    if (g_direct_fbcc) {
+        /* virtual detector plane spanned by the baseline direction and its moment (ref: :133-141) */
+        for (i = 0; i < 3; i++) { U[i] = dvec[i] / dir; V[i] = mvec[i] / mom; }
+        or_cross(U, V, Eplane);
+        Eplane[3] = 0;
+        or_fbcc_homography(P0, C0, U, V, Eplane, H0);
+        or_fbcc_homography(P1, C1, U, V, Eplane, H1);
+    }
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : acc)
     for (i = 0; i < n_lines; i++) {
         float kf = (float)(k_first + dkappa * i);
@@ -1133,8 +1295,16 @@ ECCOR_API int eccor_direct_pair(const double *P0, const double *P1, const float 
         for (k = 0; k < 3; k++) lf[k] = (float)(l0[k] / nn);
         nn = sqrt(l1[0] * l1[0] + l1[1] * l1[1]);
         for (k = 0; k < 3; k++) lf[3 + k] = (float)(l1[k] / nn);
-        v0 = or_direct_line_integral(img0, n_u, n_v, lf);
-        v1 = or_direct_line_integral(img1, n_u, n_v, lf + 3);
+        if (g_direct_fbcc) {
+            or_fbcc_info i0, i1;
+            or_fbcc_line_info(P0, C0, H0, dvec, Eplane, lf, &i0);
+            or_fbcc_line_info(P1, C1, H1, dvec, Eplane, lf + 3, &i1);
+            v0 = or_direct_line_integral_fbcc(img0, n_u, n_v, lf, &i0);
+            v1 = or_direct_line_integral_fbcc(img1, n_u, n_v, lf + 3, &i1);
+        } else {
+            v0 = or_direct_line_integral(img0, n_u, n_v, lf);
+            v1 = or_direct_line_integral(img1, n_u, n_v, lf + 3);
+        }
         if (i < capacity) {
             if (v0s) v0s[i] = v0;
             if (v1s) v1s[i] = v1;

@@ -73,9 +73,30 @@ def test_non_square_images_and_errors(gpu_ctx, oracle_mod):
     assert len(got["kappas"]) == len(want["kappas"]) and _rel(val, want["metric"]) < 1e-5
     with pytest.raises(E.EccError):
         m.evaluateForImagePair(0, 3)
-    with pytest.raises(E.EccError) as ei:
-        m.setFanBeamConsistency(True).evaluate()
-    assert ei.value.code == 5
     m2 = E.MetricDirect(gpu_ctx, None, imgs)
     with pytest.raises(E.EccError):
         m2.evaluate()
+
+
+def test_fan_beam_consistency_variant(gpu_ctx, oracle_mod, small_scan):
+    """setFanBeamConsistency (ref: RectifiedFBCC.h, EpipolarConsistencyDirect.cpp:133-196, .cu:87-101)."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    imgs = np.ascontiguousarray(s["imgs"][:4], np.float32)
+    Ps = s["Ps"][:4]
+    radius = oracle_mod.object_radius(Ps[0], s["n_u"], s["n_v"])
+    m = E.MetricDirect(gpu_ctx, Ps, imgs).setFanBeamConsistency(True)
+    for (i, j) in ((0, 3), (2, 1)):
+        val, got = m.evaluateForImagePair(i, j)
+        want = oracle_mod.direct_pair(Ps[i], Ps[j], imgs[i], imgs[j], 0.0, radius, fbcc=True)
+        assert len(got["kappas"]) == len(want["kappas"])
+        scale = np.abs(want["samples0"]).max()
+        assert np.abs(got["redundant_samples0"] - want["samples0"]).max() <= 1e-4 * scale
+        assert np.abs(got["redundant_samples1"] - want["samples1"]).max() <= 1e-4 * scale
+        # the fan-beam condition: the two weighted signals agree for consistent data
+        assert np.corrcoef(got["redundant_samples0"], got["redundant_samples1"])[0, 1] > 0.999
+        assert _rel(val, want["metric"]) < 1e-3
+    want = oracle_mod.direct_evaluate(Ps, imgs, fbcc=True)
+    assert _rel(m.evaluate(), want["sum"]) < 1e-3
+    # switching back gives the derivative form again
+    assert _rel(m.setFanBeamConsistency(False).evaluate(), oracle_mod.direct_evaluate(Ps, imgs)["sum"]) < 1e-5
