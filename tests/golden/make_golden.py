@@ -9,6 +9,8 @@ container that has /root/reference):
   synthetic8_128.npz    8-view 128x128 synthetic scan (tests/conftest.py:make_small_scan): oracle pair
                         values, mean, K01s and per-dtr checksums.
 
+  example_pair_256_rows.npz  the rows of SURVEY.md 8(f) on the example pair (see widened_rows()).
+
 The reference has no golden vectors for this path: these pin the ORACLE against
 regressions and travel to the GPU box, where /root/reference does not exist.
 """
@@ -69,6 +71,37 @@ def synthetic8():
     print("synthetic8: mean %.9g" % res["mean"])
 
 
+def widened_rows():
+    """example_pair_256_rows.npz: oracle outputs of the SURVEY.md 8(f) rows on the same example pair (its images and
+    matrices are read from example_pair_256.npz): ramp-filtered dtr, pre-processed image (defaults + -log +
+    cosine weight), evaluateForImagePair, useCorrelation, MetricDirect (derivative and FBCC form)."""
+    g = np.load(os.path.join(HERE, "example_pair_256.npz"))
+    imgs, Ps = g["images"], list(g["Ps"])
+    n_u, n_v, n_alpha, n_t = 256, 190, int(g["n_alpha"]), int(g["n_t"])
+    bins = g["sample_bins"]
+    ramp = oracle.radon(imgs[0], n_alpha, n_t, filter=1)
+    pre = oracle.preprocess(imgs[1] + 1.0, Ps[1], apply_log=True, scale=0.01)
+    dtrs = [oracle.radon(im, n_alpha, n_t) for im in imgs]
+    e7 = oracle.evaluate_for_image_pair(Ps, dtrs, 0, 1, n_u, n_v)
+    oracle.set_use_corr(True)
+    corr = oracle.evaluate_all(Ps, dtrs, n_u, n_v)["pairs"][0]
+    oracle.set_use_corr(False)
+    radius = oracle.object_radius(Ps[0], n_u, n_v)
+    d = oracle.direct_pair(Ps[0], Ps[1], imgs[0], imgs[1], 0.0, radius)
+    f = oracle.direct_pair(Ps[0], Ps[1], imgs[0], imgs[1], 0.0, radius, fbcc=True)
+    pix = np.random.default_rng(7).integers(0, n_u * n_v, size=256)
+    np.savez_compressed(
+        os.path.join(HERE, "example_pair_256_rows.npz"),
+        ramp_checksum=checksum(ramp), ramp_samples=ramp.reshape(-1)[bins],
+        pre_checksum=checksum(pre), pre_pixels=pix, pre_samples=pre.reshape(-1)[pix],
+        e7_ecc=e7["ecc"], e7_n=len(e7["kappas"]), e7_samples0=e7["samples0"][::8], e7_samples1=e7["samples1"][::8],
+        corr_value=corr, direct_metric=d["metric"], direct_n=len(d["kappas"]), direct_samples0=d["samples0"][::16],
+        direct_samples1=d["samples1"][::16], fbcc_metric=f["metric"], fbcc_samples0=f["samples0"][::16])
+    print("widened rows: e7 %.9g corr %.9g direct %.9g fbcc %.9g" % (e7["ecc"], corr, d["metric"], f["metric"]))
+
+
 if __name__ == "__main__":
-    example_pair()
+    if os.path.isdir(REF):
+        example_pair()
     synthetic8()
+    widened_rows()

@@ -64,3 +64,56 @@ def test_hip_matches_synthetic8_golden(gpu_ctx, small_scan):
     total, vals = m.evaluate_range(0, 28, want_pairs=True)
     assert abs(total / 28 - float(g["mean"])) <= 1e-5 * float(g["mean"])
     np.testing.assert_allclose(vals, g["pairs"], rtol=2e-4)
+
+
+def _rows_inputs():
+    g = np.load(os.path.join(G, "example_pair_256.npz"))
+    r = np.load(os.path.join(G, "example_pair_256_rows.npz"))
+    return g, r, g["images"], list(g["Ps"]), int(g["n_alpha"]), int(g["n_t"])
+
+
+def test_oracle_reproduces_widened_rows(oracle_mod):
+    g, r, imgs, Ps, n_alpha, n_t = _rows_inputs()
+    ramp = oracle_mod.radon(imgs[0], n_alpha, n_t, filter=1)
+    assert np.array_equal(_checksum(ramp), r["ramp_checksum"]) and np.array_equal(ramp.reshape(-1)[g["sample_bins"]], r["ramp_samples"])
+    pre = oracle_mod.preprocess(imgs[1] + 1.0, Ps[1], apply_log=True, scale=0.01)
+    assert np.array_equal(_checksum(pre), r["pre_checksum"]) and np.array_equal(pre.reshape(-1)[r["pre_pixels"]], r["pre_samples"])
+    dtrs = [oracle_mod.radon(im, n_alpha, n_t) for im in imgs]
+    e7 = oracle_mod.evaluate_for_image_pair(Ps, dtrs, 0, 1, 256, 190)
+    assert e7["ecc"] == float(r["e7_ecc"]) and len(e7["kappas"]) == int(r["e7_n"])
+    assert np.array_equal(e7["samples0"][::8], r["e7_samples0"]) and np.array_equal(e7["samples1"][::8], r["e7_samples1"])
+    oracle_mod.set_use_corr(True)
+    try:
+        assert oracle_mod.evaluate_all(Ps, dtrs, 256, 190)["pairs"][0] == r["corr_value"]
+    finally:
+        oracle_mod.set_use_corr(False)
+    radius = oracle_mod.object_radius(Ps[0], 256, 190)
+    d = oracle_mod.direct_pair(Ps[0], Ps[1], imgs[0], imgs[1], 0.0, radius)
+    assert d["metric"] == float(r["direct_metric"]) and len(d["kappas"]) == int(r["direct_n"])
+    assert np.array_equal(d["samples0"][::16], r["direct_samples0"]) and np.array_equal(d["samples1"][::16], r["direct_samples1"])
+    f = oracle_mod.direct_pair(Ps[0], Ps[1], imgs[0], imgs[1], 0.0, radius, fbcc=True)
+    assert f["metric"] == float(r["fbcc_metric"]) and np.array_equal(f["samples0"][::16], r["fbcc_samples0"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_widened_rows_golden(gpu_ctx):
+    import epipolarconsistency_amd as E
+    g, r, imgs, Ps, n_alpha, n_t = _rows_inputs()
+    ramp = E.RadonIntermediate.compute(gpu_ctx, imgs[0], n_alpha, n_t, filter=E.FILTER_RAMP).readback()
+    assert np.abs(ramp.reshape(-1)[g["sample_bins"]] - r["ramp_samples"]).max() <= 1e-6 * np.abs(r["ramp_samples"]).max()
+    pp = E.PreProccess()
+    pp.intensity.apply_log, pp.intensity.scale = True, 0.01
+    pre = pp.process(gpu_ctx, (imgs[1] + 1.0)[None], [Ps[1]])[0]
+    assert np.abs(pre.reshape(-1)[r["pre_pixels"]] - r["pre_samples"]).max() <= 2e-7 * np.abs(r["pre_samples"]).max()
+    dtrs = E.RadonIntermediate.compute_batch(gpu_ctx, imgs, n_alpha, n_t)
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    ecc, s = m.evaluateForImagePair(0, 1)
+    assert len(s["kappas"]) == int(r["e7_n"]) and abs(ecc - float(r["e7_ecc"])) <= 1e-4 * float(r["e7_ecc"])
+    corr = np.zeros(1, np.float32)
+    m.useCorrelation(True).evaluate(np.array([[0, 1, 0, 1]], np.int32), corr)
+    assert abs(corr[0] - float(r["corr_value"])) <= 2e-4 * abs(float(r["corr_value"])) + 1e-7
+    d = E.MetricDirect(gpu_ctx, Ps, imgs)
+    val, sd = d.evaluateForImagePair(0, 1)
+    assert len(sd["kappas"]) == int(r["direct_n"]) and abs(val - float(r["direct_metric"])) <= 1e-5 * float(r["direct_metric"])
+    val, _ = d.setFanBeamConsistency(True).evaluateForImagePair(0, 1)
+    assert abs(val - float(r["fbcc_metric"])) <= 1e-3 * float(r["fbcc_metric"])
