@@ -69,6 +69,7 @@ SIGNATURES = {
     "ecc_host_object_radius": (_d, [_vp, _i, _i]),
     "ecc_direct_create": (_i, [_vp, _i, _vp, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_direct_destroy": (_i, [_vp]),
+    "ecc_direct_update_images": (_i, [_vp]),
     "ecc_direct_set_projections": (_i, [_vp, _vp, _i]),
     "ecc_direct_set_params": (_i, [_vp, _d, _d, _i]),
     "ecc_direct_get_object_radius": (_i, [_vp, _pd]),

@@ -465,6 +465,11 @@ class MetricDirect:
     def getNumberOfProjetions(self):  # sic
         return self._n
 
+    def updateImages(self):
+        """Call after changing the pixels of borrowed device images (refreshes the transposed copy)."""
+        check(_lib.lib().ecc_direct_update_images(self._h))
+        return self
+
     def _push(self):
         check(_lib.lib().ecc_direct_set_params(self._h, *self._params))
         return self

@@ -37,6 +37,7 @@ extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStr
 extern "C" size_t ecc_preprocess_lds_bytes(int k);
 extern "C" hipError_t ecc_launch_direct_views(const double* Ps_d, int n, EccDirectView* views, int n_u, int n_v,
                                               hipStream_t stream);
+extern "C" hipError_t ecc_launch_direct_transpose(const float* src, float* dst, int n, int W, int H, hipStream_t stream);
 extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* total, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
@@ -1117,6 +1118,7 @@ struct ecc_direct {
     int n_images = 0, n_u = 0, n_v = 0, n_views = 0;
     const float* images_d = nullptr;
     float* owned_images = nullptr;
+    float* imagesT_d = nullptr;  // transposed copies (see direct_lines_kernel); refreshed by ecc_direct_update_images
     double object_radius_mm = 0, dkappa = 0;
     int use_fbcc = 0;
     std::vector<double> P_first;
@@ -1198,11 +1200,22 @@ ECC_EXPORT int ecc_direct_create(ecc_ctx* ctx, int n_images, const float* images
     } else {
         d->images_d = images;
     }
+    if (e == hipSuccess) e = hipMalloc((void**)&d->imagesT_d, sizeof(float) * (size_t)n_images * n_u * n_v);
+    if (e == hipSuccess) e = ecc_launch_direct_transpose(d->images_d, d->imagesT_d, n_images, n_u, n_v, ctx->stream);
     if (e != hipSuccess) {
         ecc_direct_destroy(d);
         HIP_TRY(e);
     }
     *out = d;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_direct_update_images(ecc_direct* d)
+{
+    if (!d) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    int rc = set_device(d->ctx);
+    if (rc) return rc;
+    HIP_TRY(ecc_launch_direct_transpose(d->images_d, d->imagesT_d, d->n_images, d->n_u, d->n_v, d->ctx->stream));
     return ECC_OK;
 }
 
@@ -1212,6 +1225,7 @@ ECC_EXPORT int ecc_direct_destroy(ecc_direct* d)
     (void)hipSetDevice(d->ctx->device);
     (void)hipStreamSynchronize(d->ctx->stream);
     if (d->owned_images) (void)hipFree(d->owned_images);
+    if (d->imagesT_d) (void)hipFree(d->imagesT_d);
     if (d->Ps_d) (void)hipFree(d->Ps_d);
     if (d->views_d) (void)hipFree(d->views_d);
     if (d->pairs_d) (void)hipFree(d->pairs_d);
@@ -1309,6 +1323,7 @@ ECC_EXPORT int ecc_direct_evaluate(ecc_direct* d, float* cost_nxn, double* cost_
             EccDirectParams p;
             std::memset(&p, 0, sizeof(p));
             p.images = d->images_d;
+            p.imagesT = d->imagesT_d;
             p.image_stride = (int64_t)d->n_u * d->n_v;
             p.views = d->views_d;
             p.pairs = d->pairs_d;
@@ -1363,6 +1378,7 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
     EccDirectParams p;
     std::memset(&p, 0, sizeof(p));
     p.images = d->images_d;
+    p.imagesT = d->imagesT_d;
     p.image_stride = (int64_t)d->n_u * d->n_v;
     p.views = d->views_d;
     p.pairs = d->pairs_d;

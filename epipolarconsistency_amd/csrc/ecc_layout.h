@@ -129,6 +129,7 @@ struct EccDirectPair {
 };
 struct EccDirectParams {
     const float* images;        // n_views images, n_v x n_u, u fastest
+    const float* imagesT;       // the same images transposed (n_u x n_v, v fastest), or null
     int64_t image_stride;
     const EccDirectView* views;
     EccDirectPair* pairs;       // `count` records (direct_pair_kernel -> the other kernels)

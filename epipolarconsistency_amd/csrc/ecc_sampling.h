@@ -24,4 +24,23 @@ __device__ __forceinline__ float ecc_tex_global(const float* __restrict__ img, i
     return (1.f - fy) * r0 + fy * r1;
 }
 
+// Same rule with explicit element strides: texel (i, j) lives at img[i * si + j * sj].  (si, sj) = (1, W) is the
+// row-major image, (H, 1) its transposed copy -- MetricDirect picks per line whichever makes the wave's lanes
+// (adjacent, nearly parallel lines at the same step) land in the same cache lines.  Identical arithmetic.
+__device__ __forceinline__ float ecc_tex_global_strided(const float* __restrict__ img, int W, int H, int si, int sj, float x,
+                                                        float y)
+{
+    float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float fx = xb - fi, fy = yb - fj;
+    int i = (int)fi, j = (int)fj;
+    int i0 = min(max(i, 0), W - 1), i1 = min(max(i + 1, 0), W - 1);
+    int j0 = min(max(j, 0), H - 1), j1 = min(max(j + 1, 0), H - 1);
+    float T00 = img[(size_t)j0 * sj + (size_t)i0 * si], T10 = img[(size_t)j0 * sj + (size_t)i1 * si];
+    float T01 = img[(size_t)j1 * sj + (size_t)i0 * si], T11 = img[(size_t)j1 * sj + (size_t)i1 * si];
+    float r0 = (1.f - fx) * T00 + fx * T10;
+    float r1 = (1.f - fx) * T01 + fx * T11;
+    return (1.f - fy) * r0 + fy * r1;
+}
+
 #endif

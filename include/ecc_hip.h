@@ -225,6 +225,10 @@ typedef struct ecc_direct ecc_direct;
 int ecc_direct_create(ecc_ctx* ctx, int n_images, const float* images, int on_device, int n_u, int n_v,
                       ecc_direct** out);
 int ecc_direct_destroy(ecc_direct* d);
+/* The metric keeps a transposed copy of the images (coalesced access for near-horizontal epipolar lines).  After
+ * changing the pixels of borrowed device images call this before the next evaluation (asynchronous, a few
+ * microseconds per image) -- the counterpart of re-binding the reference's textures. */
+int ecc_direct_update_images(ecc_direct* d);
 /* ref: MetricDirect::setProjectionMatrices; n x 12 float64 column-major. */
 int ecc_direct_set_projections(ecc_direct* d, const double* Ps, int n_views);
 /* ref: Metric::setObjectRadius / setEpipolarPlaneStep / MetricDirect::setFanBeamConsistency; 0 = automatic. */
