@@ -61,6 +61,7 @@ int ecc_device_count(void);
  * copies of objects created from this context are ordered on it.  Replaces the reference's
  * implicit "current device, default stream, cudaDeviceSynchronize after every launch". */
 int ecc_ctx_create(int device, void* stream, ecc_ctx** out);
+/* Destroy every dtr / metric created from a context BEFORE the context itself (they keep a pointer to it). */
 int ecc_ctx_destroy(ecc_ctx* ctx);
 int ecc_ctx_synchronize(ecc_ctx* ctx);
 

@@ -1282,7 +1282,8 @@ ECCOR_API int eccor_direct_pair(const double *P0, const double *P1, const float 
         or_fbcc_homography(P0, C0, U, V, Eplane, H0);
         or_fbcc_homography(P1, C1, U, V, Eplane, H1);
     }
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : acc)
+    float *dv = (float *)malloc(sizeof(float) * 2 * (size_t)(n_lines > 0 ? n_lines : 1));
+#pragma omp parallel for schedule(dynamic, 16)
     for (i = 0; i < n_lines; i++) {
         float kf = (float)(k_first + dkappa * i);
         double kappa = kf, c = cos(kappa), s = sin(kappa), E[4], l0[3], l1[3], nn;
@@ -1311,8 +1312,12 @@ ECCOR_API int eccor_direct_pair(const double *P0, const double *P1, const float 
             if (kappas) kappas[i] = kf;
             if (lines01) memcpy(lines01 + 6 * (size_t)i, lf, sizeof(lf));
         }
-        acc += (v0 - v1) * (v0 - v1) * dkappa;
+        dv[2 * i] = v0;
+        dv[2 * i + 1] = v1;
     }
+    /* ref: :205-208, the host sums in line order (deterministic here too) */
+    for (i = 0; i < n_lines; i++) acc += (dv[2 * i] - dv[2 * i + 1]) * (dv[2 * i] - dv[2 * i + 1]) * dkappa;
+    free(dv);
     if (metric) *metric = acc;
     return n_lines;
 }
