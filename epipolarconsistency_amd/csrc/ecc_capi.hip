@@ -31,6 +31,8 @@ extern "C" hipError_t ecc_launch_dtr_import(const float* src, float* slab, int n
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n_alpha, int n_t, int pitch,
                                             hipStream_t stream);
+extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, float* paired_d, int64_t paired_stride, int n,
+                                              int rows, int pitch, hipStream_t stream);
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream);
@@ -92,6 +94,8 @@ struct ecc_ctx {
     // circular-convolution kernel of Filter::Ramp (2*n_t doubles), cached per n_t
     double* ramp_d = nullptr;
     int ramp_n_t = 0;
+    // constant tables of the pair kernel's polynomial path
+    EccPolyTables* poly_d = nullptr;
 };
 
 struct ecc_dtr {
@@ -114,7 +118,9 @@ struct ecc_metric {
     int n_views = 0;
     std::vector<double> P_first;  // first projection matrix (object radius estimate)
     // device state
-    const float** dtr_table_d = nullptr;
+    const float** dtr_table_d = nullptr;     // the dtrs' slabs (borrowed)
+    float* paired_d = nullptr;               // row-paired copies of all dtrs (owned; what the pair kernel samples)
+    const float** paired_table_d = nullptr;  // per dtr: base of its paired copy
     float* Cs_d = nullptr;
     float* PinvTs_d = nullptr;
     int geom_capacity = 0;
@@ -209,6 +215,47 @@ int ensure_ramp(ecc_ctx* ctx, int n_t)
     HIP_TRY(hipMemcpyAsync(ctx->ramp_d, h2.data(), h2.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // h2 goes out of scope
     ctx->ramp_n_t = n_t;
+    return ECC_OK;
+}
+
+// Chebyshev nodes, check abscissae and the inverse Vandermonde matrix of the per-pair polynomial fit
+// (pairs_kernel.hip, fit_sample_polynomials); float64, built once per context.
+int ensure_poly_tables(ecc_ctx* ctx)
+{
+    if (ctx->poly_d) return ECC_OK;
+    constexpr int N = ECC_POLY_DEG + 1;
+    EccPolyTables t;
+    for (int j = 0; j < N; ++j) t.nodes[j] = std::cos(3.14159265358979323846 * (j + 0.5) / N);
+    const double checks[ECC_POLY_CHECKS] = {-0.93, 0.13, 0.97};
+    for (int j = 0; j < ECC_POLY_CHECKS; ++j) t.checks[j] = checks[j];
+    // A = V^-1, V[j][k] = node_j^k: Gauss-Jordan with partial pivoting in long double
+    long double M[N][2 * N];
+    for (int j = 0; j < N; ++j) {
+        long double pw = 1;
+        for (int k = 0; k < N; ++k) {
+            M[j][k] = pw;
+            pw *= (long double)t.nodes[j];
+            M[j][N + k] = j == k ? 1 : 0;
+        }
+    }
+    for (int col = 0; col < N; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < N; ++r)
+            if (fabsl(M[r][col]) > fabsl(M[piv][col])) piv = r;
+        for (int k = 0; k < 2 * N; ++k) std::swap(M[col][k], M[piv][k]);
+        const long double d = M[col][col];
+        for (int k = 0; k < 2 * N; ++k) M[col][k] /= d;
+        for (int r = 0; r < N; ++r) {
+            if (r == col) continue;
+            const long double f = M[r][col];
+            for (int k = 0; k < 2 * N; ++k) M[r][k] -= f * M[col][k];
+        }
+    }
+    for (int k = 0; k < N; ++k)
+        for (int j = 0; j < N; ++j) t.A[k * N + j] = (double)M[k][N + j];
+    HIP_TRY(hipMalloc((void**)&ctx->poly_d, sizeof(EccPolyTables)));
+    HIP_TRY(hipMemcpyAsync(ctx->poly_d, &t, sizeof(t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // t goes out of scope
     return ECC_OK;
 }
 
@@ -336,6 +383,7 @@ ECC_EXPORT int ecc_ctx_destroy(ecc_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->trig_d) (void)hipFree(ctx->trig_d);
     if (ctx->ramp_d) (void)hipFree(ctx->ramp_d);
+    if (ctx->poly_d) (void)hipFree(ctx->poly_d);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -588,13 +636,29 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
         }
         table[k] = dtrs[k]->base;
     }
+    // one fp32 conversion forms the byte offset inside a paired copy: it has to stay below 2^24
+    const int64_t paired_floats = (int64_t)(m->n_alpha + 1) * m->pitch * 2;
+    if (paired_floats * 4 >= (int64_t)1 << 24) {
+        delete m;
+        return fail(ECC_ERR_UNSUPPORTED, "Radon intermediates above ~2 M bins (e.g. 1448 x 1448) are not supported by the pair kernel");
+    }
+    std::vector<const float*> ptable(n_dtrs);
     hipError_t e = hipMalloc((void**)&m->dtr_table_d, sizeof(float*) * n_dtrs);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->paired_table_d, sizeof(float*) * n_dtrs);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->paired_d, sizeof(float) * (size_t)paired_floats * n_dtrs);
+    for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) ptable[k] = m->paired_d + (size_t)paired_floats * k;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(m->paired_table_d, ptable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
 
     if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, sizeof(double), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&m->sum_h_dev, m->sum_h, 0);
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->dtr_table_d, table.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
+    // the metric borrows the dtrs and they must not change during its lifetime (ref: ...RadonIntermediate.h:45), so
+    // the paired copies are built once, here
+    if (e == hipSuccess)
+        e = ecc_launch_build_paired(m->dtr_table_d, m->paired_d, paired_floats, n_dtrs, m->n_alpha + 1, m->pitch, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ecc_metric_destroy(m);
@@ -610,6 +674,8 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->dtr_table_d) (void)hipFree((void*)m->dtr_table_d);
+    if (m->paired_table_d) (void)hipFree((void*)m->paired_table_d);
+    if (m->paired_d) (void)hipFree(m->paired_d);
     if (m->Cs_d) (void)hipFree(m->Cs_d);
     if (m->PinvTs_d) (void)hipFree(m->PinvTs_d);
     if (m->pair_values_d) (void)hipFree(m->pair_values_d);
@@ -697,7 +763,7 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p)
     double radius = 0;
     ecc_metric_get_object_radius(m, &radius);
     std::memset(p, 0, sizeof(*p));
-    p->dtrs = m->dtr_table_d;
+    p->dtrs = m->paired_table_d;  // the pair kernel samples the row-paired copies
     p->Cs = m->Cs_d;
     p->PinvTs = m->PinvTs_d;
     p->n_views = m->n_views;
@@ -717,6 +783,9 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p)
     p->k_limit = (max_num_samples + 255) / 256 * 256;
     p->is_derivative = m->is_derivative ? 1 : 0;
     p->use_corr = m->use_corr ? 1 : 0;
+    int rc = ensure_poly_tables(m->ctx);
+    if (rc) return rc;
+    p->poly = m->ctx->poly_d;
     return ECC_OK;
 }
 

@@ -57,18 +57,38 @@ struct EccRadonParams {
 };
 
 // ---- pair kernel ---------------------------------------------------------------------------
-// What k01_kernel hands to pairs_kernel for one pair (96 bytes, read with scalar loads).
+// Degree of the per-pair, per-view polynomials xa(kappa), yd(kappa) on [-kappa_max, kappa_max] (see pairs_kernel.hip):
+// 11 coefficients each plus a low part of the constant term (the constant is ~n/2 bins; its float rounding alone
+// would shift a whole curve by up to 1.5e-5 bins).
+#define ECC_POLY_DEG 10
+#define ECC_POLY_CHECKS 3
+
+// What k01_kernel hands to pairs_kernel for one pair (312 bytes, read with scalar loads).
 struct EccPairRecord {
     float K0[8];   // ref: computeK01 (EpipolarConsistencyCommon.hxx:93-149): K0[6] baseline distance, K0[7] view angle
     float K1[8];   // K1[6] dkappa, K1[7] kappa_max
     int iD0, iD1;  // Radon intermediates of the two views
     int ci, cj;    // cost-image position (all-pairs mode)
-    int it_small;  // reserved (0)
-    int pad[3];
+    int poly_ok;   // 1: the sample coordinates of both views are given by the polynomials below
+    float x_scale; // x = kappa * x_scale in (0, 1]; the -kappa samples are the same polynomials at -x
+    unsigned fold[2];                  // per view: 0x80000000 when the (alpha+pi, -t) fold applies on the +kappa side
+                                       // (it is the opposite on the -kappa side: the line is negated there)
+    float ca[2][ECC_POLY_DEG + 3];     // angle coordinate (padded texel units): monomial coefficients in x, c0 first;
+                                       // [DEG+1] is c0's low part (c0 = c[0] + c[DEG+1]), [DEG+2] the low part to use at
+                                       // -x: the reference's float Pi puts the two fold states 2.78e-8 * n_alpha bins apart
+    float cd[2][ECC_POLY_DEG + 2];     // distance coordinate, same layout without the last entry
+};
+
+// Constant tables of the polynomial fit (float64, device memory): Chebyshev nodes, check abscissae, and the inverse
+// Vandermonde matrix A (row k, column j) so that monomial coefficient k = sum_j A[k][j] * f(node j).
+struct EccPolyTables {
+    double nodes[ECC_POLY_DEG + 1];
+    double checks[ECC_POLY_CHECKS];
+    double A[(ECC_POLY_DEG + 1) * (ECC_POLY_DEG + 1)];
 };
 
 struct EccPairParams {
-    const float* const* dtrs;  // device table of slab base pointers, one per dtr
+    const float* const* dtrs;  // device table of the dtrs' ROW-PAIRED copies (build_paired_kernel), one per dtr
     const float* Cs;           // 4 floats per view  (source positions, w = 1)
     const float* PinvTs;       // 12 floats per view ((P^+)^T, 3x4 column-major)
     const int32_t* indices;    // optional n_pairs x 4 (P0, P1, dtr0, dtr1); null = all pairs
@@ -76,6 +96,7 @@ struct EccPairParams {
     float* cost;               // optional n x n cost image (index i + j*n)
     float* K01_out;            // optional debug output, 16 floats per pair
     EccPairRecord* records;    // `count` records, written by k01_kernel, read by pairs_kernel
+    const EccPolyTables* poly; // constant tables of the polynomial fit (null: exact path for every pair)
     int64_t first;             // first pair (get_ij order) handled by this launch
     int64_t count;             // pairs handled by this launch
     int n_views;

@@ -95,6 +95,10 @@ __device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0
 struct __attribute__((packed, aligned(4))) F2 {
     float x, y;
 };
+// One bilinear footprint of the row-paired copy (see build_paired_kernel): (i,j), (i+1,j), (i,j+1), (i+1,j+1).
+struct __attribute__((packed, aligned(4))) F4 {
+    float x, y, z, w;
+};
 
 __device__ __forceinline__ float uniformf(float v)
 {
@@ -120,8 +124,8 @@ __device__ __forceinline__ void sincos_quadrant(float kappa, float& s, float& c)
 }
 
 struct SlabView {
-    const char* origin;  // slab base = padded element (row 0, column 0) = (ix = -1, iy = -1)
-    unsigned pitch4;     // row pitch in bytes
+    const char* origin;  // base of the dtr's ROW-PAIRED copy: padded element (row 0, column 0) = (ix = -1, iy = -1)
+    unsigned pitch4;     // row pitch of the paired copy in bytes (8 bytes per distance bin)
 };
 
 // atan(t)/pi for |t| <= 1 as t * P(t^2): degree-8 minimax fit of atan(q)/(pi q) on q^2 in [0,1]
@@ -210,20 +214,12 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     float yd = fmaf(-(l2f * inv), dist_scale, dist_bias);
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
-    // byte offset floor(xa)*pitch4 + floor(yd)*4 formed exactly in fp32 (< 2^24), one conversion
-    const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 4.0f);
-#if defined(PK_EXP_NO_LOAD)   // timing experiment: no memory traffic at all (wrong results)
-    const F2 c0 = {__uint_as_float(off), fx}, c1 = {fy, xa};
-#elif defined(PK_EXP_ONE_LOAD)  // timing experiment: one 8-byte load per sample (wrong results)
-    const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);
-    const F2 c1 = {c0.y, c0.x};
-#else
-    const F2 c0 = *reinterpret_cast<const F2*>(sv.origin + off);  // (i, j), (i, j+1)
-    const F2 c1 = PITCH4 > 0 ? *reinterpret_cast<const F2*>(sv.origin + off + PITCH4)
-                             : *reinterpret_cast<const F2*>(sv.origin + (off + sv.pitch4));  // (i+1, j), (i+1, j+1)
-#endif
-    const float r0 = fmaf(fx, c1.x - c0.x, c0.x);
-    const float r1 = fmaf(fx, c1.y - c0.y, c0.y);
+    // byte offset floor(xa)*pitch4 + floor(yd)*8 in the row-paired copy, formed exactly in fp32 (< 2^24, checked
+    // at metric creation), one conversion; ONE 16-byte load fetches the whole 2x2 footprint
+    const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 8.0f);
+    const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
+    const float r0 = fmaf(fx, q.y - q.x, q.x);
+    const float r1 = fmaf(fx, q.w - q.z, q.z);
     const float v = fmaf(fy, r1 - r0, r0);
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ m) : v;
 }
@@ -263,7 +259,91 @@ __device__ __forceinline__ bool kappa_step(int k, const float (&K0)[8], const fl
     return true;
 }
 
-// The kappa loop of one pair.
+// Both coordinates' values at +x and -x from one polynomial each: even part E(z) and odd part O(z), z = x^2,
+// p(+x) = E + x O, p(-x) = E - x O.  The constant term goes in last, low part first: one rounding at the
+// coordinate's own magnitude, as on the exact path.
+__device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_minus, bool same_lo, float x, float z,
+                                        float& plus, float& minus)
+{
+    static_assert(ECC_POLY_DEG % 2 == 0, "even degree");
+    float E = c[ECC_POLY_DEG], O = c[ECC_POLY_DEG - 1];
+#pragma unroll
+    for (int k = ECC_POLY_DEG - 2; k >= 2; k -= 2) {
+        E = fmaf(E, z, c[k]);
+        O = fmaf(O, z, c[k - 1]);
+    }
+    const float Ep = fmaf(E, z, lo_plus);
+    const float Em = same_lo ? Ep : fmaf(E, z, lo_minus);
+    const float xo = x * O;
+    plus = (Ep + xo) + c[0];
+    minus = (Em - xo) + c[0];
+}
+
+// Addressing, the one 16-byte load and the bilinear rule for a sample whose coordinates are already known.
+template <bool DERIV, int PITCH4>
+__device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f)
+{
+    yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
+    const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
+    const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 8.0f);
+#if defined(PK_EXP_NO_LOAD)   // timing experiment: no memory traffic at all (wrong results)
+    const F4 q = {__uint_as_float(off), fx, fy, xa};
+#else
+    const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
+#endif
+    const float r0 = fmaf(fx, q.y - q.x, q.x);
+    const float r1 = fmaf(fx, q.w - q.z, q.z);
+    const float v = fmaf(fy, r1 - r0, r0);
+    return DERIV ? __uint_as_float(__float_as_uint(v) ^ fold) : v;
+}
+
+// The kappa loop of one pair on the polynomial path (see fit_sample_polynomials).
+template <bool DERIV, bool CORR, int PITCH4>
+__device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
+                                                float kappa_max, float w06, const SlabView sv0, const SlabView sv1,
+                                                float n_t_f, float pitch4_f, double& acc, double& mom2, double& mom3,
+                                                double& mom4)
+{
+    float ca[2][ECC_POLY_DEG + 3], cd[2][ECC_POLY_DEG + 2];
+    unsigned fold[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        fold[v] = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->fold[v]);
+#pragma unroll
+        for (int k = 0; k <= ECC_POLY_DEG + 1; ++k) {
+            ca[v][k] = uniformf(rec->ca[v][k]);
+            cd[v][k] = uniformf(rec->cd[v][k]);
+        }
+        ca[v][ECC_POLY_DEG + 2] = uniformf(rec->ca[v][ECC_POLY_DEG + 2]);
+    }
+    const float xs = uniformf(rec->x_scale);
+    for (int k = lane; k < k_limit; k += 64) {
+        const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
+        if (kappa >= kappa_max) break;
+        const float x = kappa * xs, z = x * x;
+        float xa0p, xa0m, yd0p, yd0m, xa1p, xa1m, yd1p, yd1m;
+        poly_pm(ca[0], ca[0][ECC_POLY_DEG + 1], ca[0][ECC_POLY_DEG + 2], false, x, z, xa0p, xa0m);
+        poly_pm(cd[0], cd[0][ECC_POLY_DEG + 1], 0.f, true, x, z, yd0p, yd0m);
+        poly_pm(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa1p, xa1m);
+        poly_pm(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd1p, yd1m);
+        const float v0p = sample_at<DERIV, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f);
+        const float v1p = sample_at<DERIV, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f);
+        const float v0m = sample_at<DERIV, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f);
+        const float v1m = sample_at<DERIV, PITCH4>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f);
+        if (!CORR) {
+            const float vp = v0p - v1p, vm = v0m - v1m;
+            const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
+            acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
+        } else {
+            const float one_over_n = kappa_max / kappa;
+            mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
+            mom3 += (double)(one_over_n * (v1p * v1p + v1m * v1m));
+            mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
+        }
+    }
+}
+
+// The kappa loop of one pair, exact per-sample path.
 template <bool DERIV, bool CORR, bool REDUCE, int PITCH4>
 __device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&K0)[8], const float (&K1)[8],
                                            const SlabView sv0, const SlabView sv1, float n_alpha_f, float n_t_f,
@@ -275,6 +355,125 @@ __device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&
         if (!kappa_step<DERIV, CORR, REDUCE, PITCH4>(k, K0, K1, dkappa, kappa_max, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
                                                      dist_bias, pitch4_f, acc, mom2, mom3, mom4))
             return;  // kappa only grows: this lane is done
+}
+
+// -------------------------------------------------------------------------------------------------
+// Sample coordinates as polynomials in kappa.
+// For one pair and one of its views the epipolar line of plane angle kappa is l(kappa) = K[:,0] cos + K[:,1] sin,
+// and its sample position in the Radon intermediate -- angle coordinate xa(kappa), distance coordinate yd(kappa),
+// in padded texel units, after the (alpha+pi, -t) fold -- is an analytic function of kappa on [-kappa_max, kappa_max]
+// as long as the fold does not switch.  The reference's "-kappa" sample x = (-cos, sin) is the NEGATED line of
+// plane -kappa: the same point of the Radon intermediate with the fold (sign) toggled.  So ONE polynomial pair per
+// view serves both signs (evaluated at +x and -x, even and odd parts shared), and it is a very smooth function:
+// interpolation of degree 10 at Chebyshev nodes is good to < 1e-6 bins up to kappa_max ~ 1 rad (a C-arm short
+// scan: 1e-11 ... 3e-7 bins).  The thread that owns the pair in k01_kernel evaluates the reference's mapping
+// (computeK01 lines -> lineToSampleDtr, float constant Pi and float range_t included) at the 11 nodes in float64,
+// solves for the monomial coefficients, CHECKS them against the exact mapping at three more abscissae (tolerance
+// 1e-5 bins, fold state constant) and records the verdict; the pair kernel then spends ~14 instructions per view
+// and coordinate on BOTH samples instead of sin/cos, line products, 1/len, a reciprocal, the atan polynomial and
+// the fold bookkeeping for each.  Pairs that fail the check (fold inside the range, baseline through the object,
+// degenerate geometry) take the exact per-sample path.
+// -------------------------------------------------------------------------------------------------
+struct CurvePoint {
+    double xa, yd;
+    bool fold;
+};
+
+// ref: getRedundancy's line (…RadonIntermediate.cu:74) + lineToSampleDtr (EpipolarConsistencyCommon.hxx:152-171)
+// + the texel mapping of a normalised texture, evaluated in float64 with the reference's float constants.
+__device__ __forceinline__ CurvePoint exact_curve_point(const float* K, double c, double s, double range_t, double n_alpha,
+                                                        double n_t)
+{
+    const double Pi = (double)3.14159265359f;
+    const double l0 = (double)K[0] * c + (double)K[3] * s;
+    const double l1 = (double)K[1] * c + (double)K[4] * s;
+    const double l2 = (double)K[2] * c + (double)K[5] * s;
+    double a = atan2(l1, l0) / Pi;
+    if (a < 0) a += 2;
+    double d = -(l2 / sqrt(l0 * l0 + l1 * l1)) / range_t + 0.5;
+    CurvePoint q;
+    q.fold = a > 1;
+    if (q.fold) {
+        a -= 1;
+        d = 1 - d;
+    }
+    q.xa = a * n_alpha + 0.5;  // texel position a*n_alpha - .5, +1 for the slab's border row
+    q.yd = d * n_t + 0.5;
+    return q;
+}
+
+__device__ void fit_sample_polynomials(const EccPairParams& p, EccPairRecord& r)
+{
+    constexpr int N = ECC_POLY_DEG + 1;
+    r.poly_ok = 0;
+    r.x_scale = 0.f;
+    for (int v = 0; v < 2; ++v) {
+        r.fold[v] = 0u;
+        for (int k = 0; k <= N; ++k) r.ca[v][k] = r.cd[v][k] = 0.f;
+        r.ca[v][N + 1] = 0.f;
+    }
+    const float kappa_max = r.K1[7], dkappa = r.K1[6];
+    if (!p.poly || !(kappa_max > 0.f) || !(dkappa > 0.f)) return;
+    const EccPolyTables& T = *p.poly;
+    const double km = (double)kappa_max;
+    const double range_t = (double)p.range_t, n_alpha = (double)p.n_alpha, n_t = (double)p.n_t;
+    double cs[N + ECC_POLY_CHECKS], sn[N + ECC_POLY_CHECKS];
+    for (int j = 0; j < N + ECC_POLY_CHECKS; ++j) {
+        const double x = j < N ? T.nodes[j] : T.checks[j - N];
+        cs[j] = cos(x * km);
+        sn[j] = sin(x * km);
+    }
+    bool ok = true;
+    for (int v = 0; v < 2; ++v) {
+        const float* K = v ? r.K1 : r.K0;
+        double fa[N], fd[N];
+        bool fold0 = false;
+        for (int j = 0; j < N; ++j) {
+            const CurvePoint q = exact_curve_point(K, cs[j], sn[j], range_t, n_alpha, n_t);
+            fa[j] = q.xa;
+            fd[j] = q.yd;
+            if (j == 0) fold0 = q.fold;
+            ok = ok && q.fold == fold0;
+        }
+        double ca[N], cd[N];
+        for (int k = 0; k < N; ++k) {
+            double a = 0, d = 0;
+            for (int j = 0; j < N; ++j) {
+                a += T.A[k * N + j] * fa[j];
+                d += T.A[k * N + j] * fd[j];
+            }
+            ca[k] = a;
+            cd[k] = d;
+        }
+        // the check measures the interpolation error (float64 coefficients); the float rounding of the
+        // coefficients is evaluation noise of the same kind as the exact path's own fp32 rounding
+        for (int j = 0; j < ECC_POLY_CHECKS; ++j) {
+            const CurvePoint q = exact_curve_point(K, cs[N + j], sn[N + j], range_t, n_alpha, n_t);
+            const double x = T.checks[j];
+            double pa = ca[N - 1], pd = cd[N - 1];
+            for (int k = N - 2; k >= 0; --k) {
+                pa = pa * x + ca[k];
+                pd = pd * x + cd[k];
+            }
+            ok = ok && q.fold == fold0 && fabs(pa - q.xa) <= 1e-5 && fabs(pd - q.yd) <= 1e-5;  // NaN fails
+        }
+        r.fold[v] = fold0 ? 0x80000000u : 0u;
+        for (int k = 0; k < N; ++k) {
+            r.ca[v][k] = (float)ca[k];
+            r.cd[v][k] = (float)cd[k];
+        }
+        r.ca[v][N] = (float)(ca[0] - (double)r.ca[v][0]);
+        r.cd[v][N] = (float)(cd[0] - (double)r.cd[v][0]);
+        // The negated line of the -kappa sample is in the OTHER fold state.  With the reference's float Pi
+        // (= pi (1 + 2.78e-8), EpipolarConsistencyCommon.hxx:155,159) the direct branch gives a = r (1 - e) and the
+        // folded one a = r (1 - e) + e for the same geometric line, e = 1 - pi / Pi: a constant offset of
+        // e * n_alpha bins between the two states (2.1e-5 bins at 768 -- the systematic shift DESIGN.md 2 is about).
+        const double Pi_f = (double)3.14159265359f, e = 1.0 - 3.14159265358979323846 / Pi_f;
+        const double delta = (fold0 ? -e : e) * n_alpha;
+        r.ca[v][N + 1] = (float)(ca[0] + delta - (double)r.ca[v][0]);
+    }
+    r.poly_ok = ok ? 1 : 0;
+    r.x_scale = (float)(1.0 / km);
 }
 
 // Pair geometry, ONE THREAD PER PAIR (ref: kernelEpipolarConsistencyComputeK01, ...RadonIntermediate.cu:13-67).
@@ -306,8 +505,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     r.iD1 = iD1;
     r.ci = ci;
     r.cj = cj;
-    r.it_small = 0;
-    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    fit_sample_polynomials(p, r);
     p.records[local] = r;
     if (p.K01_out)
         for (int i = 0; i < 8; i++) {
@@ -341,7 +539,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
     const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
 
-    const unsigned pitch4 = (unsigned)p.pitch * 4u;
+    const unsigned pitch4 = (unsigned)p.pitch * 8u;  // row pitch of the paired copies in bytes
     const SlabView sv0 = {reinterpret_cast<const char*>(p.dtrs[iD0]), pitch4};
     const SlabView sv1 = {reinterpret_cast<const char*>(p.dtrs[iD1]), pitch4};
     const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
@@ -352,12 +550,20 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     double acc = 0.0;
     double mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;  // CORR: sums of x*x, y*y, x*y (x, y alone are not used by cc())
     const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
-    if (pitch4 == 3200u) {  // 768 distance bins, the reference's default (Gui/ComputeRadonIntermediate.hxx:43-44)
+    const int poly_ok = __builtin_amdgcn_readfirstlane(rec->poly_ok);
+    if (poly_ok) {
+        if (pitch4 == 6400u)
+            kappa_loop_poly<DERIV, CORR, 6400>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc,
+                                               mom2, mom3, mom4);
+        else
+            kappa_loop_poly<DERIV, CORR, 0>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2,
+                                            mom3, mom4);
+    } else if (pitch4 == 6400u) {  // 768 distance bins, the reference's default (Gui/ComputeRadonIntermediate.hxx:43-44)
         if (reduce)
-            kappa_loop<DERIV, CORR, true, 3200>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+            kappa_loop<DERIV, CORR, true, 6400>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
                                                 dist_bias, pitch4_f, acc, mom2, mom3, mom4);
         else
-            kappa_loop<DERIV, CORR, false, 3200>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+            kappa_loop<DERIV, CORR, false, 6400>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
                                                  dist_bias, pitch4_f, acc, mom2, mom3, mom4);
     } else {
         kappa_loop<DERIV, CORR, true, 0>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
@@ -518,6 +724,37 @@ __global__ __launch_bounds__(256) void pair_samples_kernel(EccPairSamplesParams 
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream)
 {
     hipLaunchKernelGGL(pair_samples_kernel, dim3((p->capacity + 255) / 256), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+namespace {
+
+// Row-paired copy of a dtr for the pair kernel: element (row r, bin j, h) = slab(r + h, j), i.e. the four taps of a
+// bilinear footprint are 16 contiguous bytes and one global_load_dwordx4 fetches them.  The vector memory path
+// takes ~16 cycles per wave-level gather instruction whatever its width, and with the coordinates coming from
+// polynomials the two 8-byte loads per sample had become the kernel's bottleneck (measured: 0.50 ms with them,
+// 0.36 ms with one, 0.33 ms with none).  Costs a second, twice as large copy of the stack in HBM (2 GB of 288).
+__global__ __launch_bounds__(256) void build_paired_kernel(const float* const* __restrict__ slabs, float* __restrict__ paired,
+                                                           int64_t paired_stride, int rows, int pitch)
+{
+    const float* __restrict__ s = slabs[blockIdx.z];
+    float* __restrict__ d = paired + (int64_t)blockIdx.z * paired_stride;
+    const int r = blockIdx.y;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < pitch; j += gridDim.x * blockDim.x) {
+        F2 v = {s[(size_t)r * pitch + j], s[(size_t)(r + 1) * pitch + j]};
+        *reinterpret_cast<F2*>(d + ((size_t)r * pitch + j) * 2) = v;
+    }
+}
+
+}  // namespace
+
+// slabs_tbl_d: device table of n slab pointers (private layout, rows+1 rows each); paired_d: n paired copies of
+// `rows` x pitch x 2 floats each, rows = n_alpha + 1.
+extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, float* paired_d, int64_t paired_stride, int n,
+                                              int rows, int pitch, hipStream_t stream)
+{
+    dim3 grid((pitch + 255) / 256, rows, n);
+    hipLaunchKernelGGL(build_paired_kernel, grid, dim3(256), 0, stream, slabs_tbl_d, paired_d, paired_stride, rows, pitch);
     return hipGetLastError();
 }
 
