@@ -228,31 +228,39 @@ int ensure_poly_tables(ecc_ctx* ctx)
     for (int j = 0; j < N; ++j) t.nodes[j] = std::cos(3.14159265358979323846 * (j + 0.5) / N);
     const double checks[ECC_POLY_CHECKS] = {-0.93, 0.13, 0.97};
     for (int j = 0; j < ECC_POLY_CHECKS; ++j) t.checks[j] = checks[j];
-    // A = V^-1, V[j][k] = node_j^k: Gauss-Jordan with partial pivoting in long double
-    long double M[N][2 * N];
-    for (int j = 0; j < N; ++j) {
-        long double pw = 1;
-        for (int k = 0; k < N; ++k) {
-            M[j][k] = pw;
-            pw *= (long double)t.nodes[j];
-            M[j][N + k] = j == k ? 1 : 0;
+    // inverse Vandermonde matrices in z = x^2 for the even part (nodes z_0..z_H, z_H = 0) and the odd part
+    // (nodes z_0..z_{H-1}): Gauss-Jordan with partial pivoting in long double
+    constexpr int H = ECC_POLY_DEG / 2;
+    auto invert_vandermonde = [&](int n, double* out) {
+        long double M[H + 1][2 * (H + 1)];
+        for (int j = 0; j < n; ++j) {
+            const long double z = (long double)t.nodes[j] * (long double)t.nodes[j];
+            long double pw = 1;
+            for (int k = 0; k < n; ++k) {
+                M[j][k] = pw;
+                pw *= z;
+                M[j][n + k] = j == k ? 1 : 0;
+            }
         }
-    }
-    for (int col = 0; col < N; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < N; ++r)
-            if (fabsl(M[r][col]) > fabsl(M[piv][col])) piv = r;
-        for (int k = 0; k < 2 * N; ++k) std::swap(M[col][k], M[piv][k]);
-        const long double d = M[col][col];
-        for (int k = 0; k < 2 * N; ++k) M[col][k] /= d;
-        for (int r = 0; r < N; ++r) {
-            if (r == col) continue;
-            const long double f = M[r][col];
-            for (int k = 0; k < 2 * N; ++k) M[r][k] -= f * M[col][k];
+        for (int col = 0; col < n; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < n; ++r)
+                if (fabsl(M[r][col]) > fabsl(M[piv][col])) piv = r;
+            for (int k = 0; k < 2 * n; ++k) std::swap(M[col][k], M[piv][k]);
+            const long double d = M[col][col];
+            for (int k = 0; k < 2 * n; ++k) M[col][k] /= d;
+            for (int r = 0; r < n; ++r) {
+                if (r == col) continue;
+                const long double f = M[r][col];
+                for (int k = 0; k < 2 * n; ++k) M[r][k] -= f * M[col][k];
+            }
         }
-    }
-    for (int k = 0; k < N; ++k)
-        for (int j = 0; j < N; ++j) t.A[k * N + j] = (double)M[k][N + j];
+        for (int k = 0; k < n; ++k)
+            for (int j = 0; j < n; ++j) out[k * n + j] = (double)M[k][n + j];
+    };
+    t.nodes[H] = 0.0;  // exactly
+    invert_vandermonde(H + 1, t.Ae);
+    invert_vandermonde(H, t.Ao);
     HIP_TRY(hipMalloc((void**)&ctx->poly_d, sizeof(EccPolyTables)));
     HIP_TRY(hipMemcpyAsync(ctx->poly_d, &t, sizeof(t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // t goes out of scope

@@ -79,12 +79,15 @@ struct EccPairRecord {
     float cd[2][ECC_POLY_DEG + 2];     // distance coordinate, same layout without the last entry
 };
 
-// Constant tables of the polynomial fit (float64, device memory): Chebyshev nodes, check abscissae, and the inverse
-// Vandermonde matrix A (row k, column j) so that monomial coefficient k = sum_j A[k][j] * f(node j).
+// Constant tables of the polynomial fit (float64, device memory).  The Chebyshev nodes are symmetric
+// (x[N-1-j] = -x[j], x[H] = 0, N = DEG+1, H = DEG/2), so the fit splits into an even part E(z) of degree H in
+// z = x^2 through the H+1 values (f[j] + f[N-1-j])/2 (j <= H) and an odd part x O(z), O of degree H-1 through the H
+// values (f[j] - f[N-1-j])/(2 x[j]) (j < H):  e_k = sum_j Ae[k][j] fe[j],  o_k = sum_j Ao[k][j] fo[j].
 struct EccPolyTables {
     double nodes[ECC_POLY_DEG + 1];
     double checks[ECC_POLY_CHECKS];
-    double A[(ECC_POLY_DEG + 1) * (ECC_POLY_DEG + 1)];
+    double Ae[(ECC_POLY_DEG / 2 + 1) * (ECC_POLY_DEG / 2 + 1)];
+    double Ao[(ECC_POLY_DEG / 2) * (ECC_POLY_DEG / 2)];
 };
 
 struct EccPairParams {

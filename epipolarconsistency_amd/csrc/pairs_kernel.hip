@@ -367,7 +367,7 @@ __device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&
 // view serves both signs (evaluated at +x and -x, even and odd parts shared), and it is a very smooth function:
 // interpolation of degree 10 at Chebyshev nodes is good to < 1e-6 bins up to kappa_max ~ 1 rad (a C-arm short
 // scan: 1e-11 ... 3e-7 bins).  The thread that owns the pair in k01_kernel evaluates the reference's mapping
-// (computeK01 lines -> lineToSampleDtr, float constant Pi and float range_t included) at the 11 nodes in float64,
+// (computeK01 lines -> lineToSampleDtr, float constant Pi and float range_t included) at the 11 (symmetric) nodes in float64,
 // solves for the monomial coefficients, CHECKS them against the exact mapping at three more abscissae (tolerance
 // 1e-5 bins, fold state constant) and records the verdict; the pair kernel then spends ~14 instructions per view
 // and coordinate on BOTH samples instead of sin/cos, line products, 1/len, a reciprocal, the atan polynomial and
@@ -377,103 +377,172 @@ __device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&
 struct CurvePoint {
     double xa, yd;
     bool fold;
+    bool valid;
 };
 
-// ref: getRedundancy's line (…RadonIntermediate.cu:74) + lineToSampleDtr (EpipolarConsistencyCommon.hxx:152-171)
-// + the texel mapping of a normalised texture, evaluated in float64 with the reference's float constants.
-__device__ __forceinline__ CurvePoint exact_curve_point(const float* K, double c, double s, double range_t, double n_alpha,
-                                                        double n_t)
+// sin and cos in float64 for |t| <= pi/2 by their Taylor series (t^24/24! < 1e-19 there): 25 multiply-adds, no
+// range reduction -- the fit needs them at a handful of node angles and inside one Newton step per point.
+__device__ __forceinline__ void sincos_taylor(double t, double& s, double& c)
 {
-    const double Pi = (double)3.14159265359f;
+    const double z = t * t;
+    double pc = 1.0 / 620448401733239439360000.0;   // 1/24!
+    pc = pc * z - 1.0 / 1124000727777607680000.0;    // 1/22!
+    pc = pc * z + 1.0 / 2432902008176640000.0;       // 1/20!
+    pc = pc * z - 1.0 / 6402373705728000.0;          // 1/18!
+    pc = pc * z + 1.0 / 20922789888000.0;            // 1/16!
+    pc = pc * z - 1.0 / 87178291200.0;               // 1/14!
+    pc = pc * z + 1.0 / 479001600.0;                 // 1/12!
+    pc = pc * z - 1.0 / 3628800.0;                   // 1/10!
+    pc = pc * z + 1.0 / 40320.0;
+    pc = pc * z - 1.0 / 720.0;
+    pc = pc * z + 1.0 / 24.0;
+    pc = pc * z - 0.5;
+    c = pc * z + 1.0;
+    double ps = -1.0 / 25852016738884976640000.0;    // -1/23!
+    ps = ps * z + 1.0 / 51090942171709440000.0;      // 1/21!
+    ps = ps * z - 1.0 / 121645100408832000.0;        // 1/19!
+    ps = ps * z + 1.0 / 355687428096000.0;           // 1/17!
+    ps = ps * z - 1.0 / 1307674368000.0;             // 1/15!
+    ps = ps * z + 1.0 / 6227020800.0;                // 1/13!
+    ps = ps * z - 1.0 / 39916800.0;                  // 1/11!
+    ps = ps * z + 1.0 / 362880.0;
+    ps = ps * z - 1.0 / 5040.0;
+    ps = ps * z + 1.0 / 120.0;
+    ps = ps * z - 1.0 / 6.0;
+    s = ps * z * t + t;
+}
+
+// The reference's mapping line -> (angle, distance) texel coordinates for one point of a view's curve
+// (ref: getRedundancy's line, ...RadonIntermediate.cu:74; lineToSampleDtr, EpipolarConsistencyCommon.hxx:152-171;
+// the texel mapping of a normalised texture), in float64 with the reference's float constants, one coordinate
+// at a time.
+// The angle of (l0, l1) is taken RELATIVE to the curve's line at kappa = 0, whose normal (K[0], K[1]) is a unit
+// vector by construction (shiftOriginAndNormlaize): theta = theta_ref + D, D = angle of (dot, cross); D comes from
+// a float seed (the pair kernel's atan polynomial, 2e-7 rad) and ONE Newton step on the rotation in float64
+// (residual ~1e-20) -- a fraction of a float64 atan2.  1/len likewise: float rsqrt + two Newton steps.
+// Not valid (-> the pair takes the exact path) when the line turns by 90 degrees or more against kappa = 0.
+// The fold state is decided by the angle.
+struct CurveGeom {
+    double theta_ref, inv_range_t, n_alpha, n_t;
+};
+
+__device__ __forceinline__ double exact_angle_coord(const float* K, const CurveGeom& g, double c, double s, bool& fold, bool& valid)
+{
+    const double pi = 3.14159265358979323846, Pi_f = (double)3.14159265359f;
+    const double l0 = (double)K[0] * c + (double)K[3] * s;
+    const double l1 = (double)K[1] * c + (double)K[4] * s;
+    const double dot = l0 * (double)K[0] + l1 * (double)K[1];
+    const double cross = l1 * (double)K[0] - l0 * (double)K[1];
+    valid = dot > 0.0 && fabs(cross) < 1e30 && dot < 1e30;
+    // seed: atan(cross/dot) to ~2e-7 rad from the float polynomial (|cross/dot| <= 1) or its complement
+    const float fd = (float)dot, fc = (float)cross;
+    float seed;
+    if (fabsf(fc) <= fd) seed = 3.14159265358979f * atan_over_pi(fc * __builtin_amdgcn_rcpf(fd));
+    else seed = copysignf(1.57079632679490f, fc) - 3.14159265358979f * atan_over_pi(fd * __builtin_amdgcn_rcpf(fc));
+    double s0, c0;
+    sincos_taylor((double)seed, s0, c0);
+    const double D = (double)seed + (cross * c0 - dot * s0) / (dot * c0 + cross * s0);
+    double theta = g.theta_ref + D;     // in (-3pi/2, 3pi/2): bring back to atan2's range (-pi, pi]
+    if (theta > pi) theta -= 2.0 * pi;
+    else if (theta <= -pi) theta += 2.0 * pi;
+    double a = theta / Pi_f;
+    if (a < 0) a += 2;
+    fold = a > 1;
+    if (fold) a -= 1;
+    return a * g.n_alpha + 0.5;  // texel position a*n_alpha - .5, +1 for the slab's border row
+}
+
+__device__ __forceinline__ double exact_distance_coord(const float* K, const CurveGeom& g, double c, double s, bool fold)
+{
     const double l0 = (double)K[0] * c + (double)K[3] * s;
     const double l1 = (double)K[1] * c + (double)K[4] * s;
     const double l2 = (double)K[2] * c + (double)K[5] * s;
-    double a = atan2(l1, l0) / Pi;
-    if (a < 0) a += 2;
-    double d = -(l2 / sqrt(l0 * l0 + l1 * l1)) / range_t + 0.5;
-    CurvePoint q;
-    q.fold = a > 1;
-    if (q.fold) {
-        a -= 1;
-        d = 1 - d;
-    }
-    q.xa = a * n_alpha + 0.5;  // texel position a*n_alpha - .5, +1 for the slab's border row
-    q.yd = d * n_t + 0.5;
-    return q;
+    const double len2 = l0 * l0 + l1 * l1;
+    double y = (double)__builtin_amdgcn_rsqf((float)len2);
+    y = y * (1.5 - 0.5 * len2 * y * y);
+    y = y * (1.5 - 0.5 * len2 * y * y);  // relative error ~1e-7 -> 1e-14 -> 1e-28
+    double d = -(l2 * y) * g.inv_range_t + 0.5;
+    if (fold) d = 1 - d;
+    return d * g.n_t + 0.5;
 }
 
-__device__ void fit_sample_polynomials(const EccPairParams& p, EccPairRecord& r)
+// Monomial coefficients (float64) of one coordinate from its even/odd node combinations.
+__device__ __forceinline__ void solve_even_odd(const EccPolyTables& T, const double* fe, const double* fo, double* c)
 {
-    constexpr int N = ECC_POLY_DEG + 1;
-    r.poly_ok = 0;
-    r.x_scale = 0.f;
-    for (int v = 0; v < 2; ++v) {
-        r.fold[v] = 0u;
-        for (int k = 0; k <= N; ++k) r.ca[v][k] = r.cd[v][k] = 0.f;
-        r.ca[v][N + 1] = 0.f;
+    constexpr int H = ECC_POLY_DEG / 2;
+    for (int k = 0; k <= H; ++k) {
+        double e = 0;
+        for (int j = 0; j <= H; ++j) e += T.Ae[k * (H + 1) + j] * fe[j];
+        c[2 * k] = e;
     }
-    const float kappa_max = r.K1[7], dkappa = r.K1[6];
-    if (!p.poly || !(kappa_max > 0.f) || !(dkappa > 0.f)) return;
-    const EccPolyTables& T = *p.poly;
-    const double km = (double)kappa_max;
-    const double range_t = (double)p.range_t, n_alpha = (double)p.n_alpha, n_t = (double)p.n_t;
-    double cs[N + ECC_POLY_CHECKS], sn[N + ECC_POLY_CHECKS];
-    for (int j = 0; j < N + ECC_POLY_CHECKS; ++j) {
-        const double x = j < N ? T.nodes[j] : T.checks[j - N];
-        cs[j] = cos(x * km);
-        sn[j] = sin(x * km);
+    for (int k = 0; k < H; ++k) {
+        double o = 0;
+        for (int j = 0; j < H; ++j) o += T.Ao[k * H + j] * fo[j];
+        c[2 * k + 1] = o;
     }
-    bool ok = true;
-    for (int v = 0; v < 2; ++v) {
-        const float* K = v ? r.K1 : r.K0;
-        double fa[N], fd[N];
-        bool fold0 = false;
-        for (int j = 0; j < N; ++j) {
-            const CurvePoint q = exact_curve_point(K, cs[j], sn[j], range_t, n_alpha, n_t);
-            fa[j] = q.xa;
-            fd[j] = q.yd;
-            if (j == 0) fold0 = q.fold;
-            ok = ok && q.fold == fold0;
+}
+
+// Fits the two polynomials of ONE view of one pair and checks them; ca_out: DEG+3 floats, cd_out: DEG+2 floats.
+__device__ bool fit_view_polynomials(const EccPolyTables& T, const float* K, const CurveGeom& g, double km, unsigned* fold_out,
+                                     float* ca_out, float* cd_out)
+{
+    constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
+    bool ok = true, fold0 = false;
+    double fe_a[H + 1], fo_a[H], fe_d[H + 1], fo_d[H];
+    for (int j = 0; j <= H; ++j) {
+        double sn, cs;
+        sincos_taylor(T.nodes[j] * km, sn, cs);
+        bool f1 = false, f2 = false, v1 = true, v2 = true;
+        const double ap = exact_angle_coord(K, g, cs, sn, f1, v1);
+        if (j == 0) fold0 = f1;
+        // the mirrored node: cos(-t) = cos t, sin(-t) = -sin t
+        const double am = j < H ? exact_angle_coord(K, g, cs, -sn, f2, v2) : ap;
+        if (j == H) f2 = f1;
+        ok = ok && v1 && v2 && f1 == fold0 && f2 == fold0;
+        const double dp = exact_distance_coord(K, g, cs, sn, fold0);
+        const double dm = j < H ? exact_distance_coord(K, g, cs, -sn, fold0) : dp;
+        fe_a[j] = 0.5 * (ap + am);
+        fe_d[j] = 0.5 * (dp + dm);
+        if (j < H) {
+            const double h = 0.5 / T.nodes[j];
+            fo_a[j] = (ap - am) * h;
+            fo_d[j] = (dp - dm) * h;
         }
-        double ca[N], cd[N];
-        for (int k = 0; k < N; ++k) {
-            double a = 0, d = 0;
-            for (int j = 0; j < N; ++j) {
-                a += T.A[k * N + j] * fa[j];
-                d += T.A[k * N + j] * fd[j];
-            }
-            ca[k] = a;
-            cd[k] = d;
-        }
-        // the check measures the interpolation error (float64 coefficients); the float rounding of the
-        // coefficients is evaluation noise of the same kind as the exact path's own fp32 rounding
-        for (int j = 0; j < ECC_POLY_CHECKS; ++j) {
-            const CurvePoint q = exact_curve_point(K, cs[N + j], sn[N + j], range_t, n_alpha, n_t);
-            const double x = T.checks[j];
-            double pa = ca[N - 1], pd = cd[N - 1];
-            for (int k = N - 2; k >= 0; --k) {
-                pa = pa * x + ca[k];
-                pd = pd * x + cd[k];
-            }
-            ok = ok && q.fold == fold0 && fabs(pa - q.xa) <= 1e-5 && fabs(pd - q.yd) <= 1e-5;  // NaN fails
-        }
-        r.fold[v] = fold0 ? 0x80000000u : 0u;
-        for (int k = 0; k < N; ++k) {
-            r.ca[v][k] = (float)ca[k];
-            r.cd[v][k] = (float)cd[k];
-        }
-        r.ca[v][N] = (float)(ca[0] - (double)r.ca[v][0]);
-        r.cd[v][N] = (float)(cd[0] - (double)r.cd[v][0]);
-        // The negated line of the -kappa sample is in the OTHER fold state.  With the reference's float Pi
-        // (= pi (1 + 2.78e-8), EpipolarConsistencyCommon.hxx:155,159) the direct branch gives a = r (1 - e) and the
-        // folded one a = r (1 - e) + e for the same geometric line, e = 1 - pi / Pi: a constant offset of
-        // e * n_alpha bins between the two states (2.1e-5 bins at 768 -- the systematic shift DESIGN.md 2 is about).
-        const double Pi_f = (double)3.14159265359f, e = 1.0 - 3.14159265358979323846 / Pi_f;
-        const double delta = (fold0 ? -e : e) * n_alpha;
-        r.ca[v][N + 1] = (float)(ca[0] + delta - (double)r.ca[v][0]);
     }
-    r.poly_ok = ok ? 1 : 0;
-    r.x_scale = (float)(1.0 / km);
+    double ca[N], cd[N];
+    solve_even_odd(T, fe_a, fo_a, ca);
+    solve_even_odd(T, fe_d, fo_d, cd);
+    // the check measures the interpolation error (float64 coefficients); the float rounding of the
+    // coefficients is evaluation noise of the same kind as the exact path's own fp32 rounding
+    for (int j = 0; j < ECC_POLY_CHECKS; ++j) {
+        const double x = T.checks[j];
+        double sn, cs;
+        sincos_taylor(x * km, sn, cs);
+        bool f = false, v = true;
+        const double qa = exact_angle_coord(K, g, cs, sn, f, v);
+        const double qd = exact_distance_coord(K, g, cs, sn, fold0);
+        double pa = ca[N - 1], pd = cd[N - 1];
+        for (int k = N - 2; k >= 0; --k) {
+            pa = pa * x + ca[k];
+            pd = pd * x + cd[k];
+        }
+        ok = ok && v && f == fold0 && fabs(pa - qa) <= 1e-5 && fabs(pd - qd) <= 1e-5;  // NaN fails
+    }
+    *fold_out = fold0 ? 0x80000000u : 0u;
+    for (int k = 0; k < N; ++k) {
+        ca_out[k] = (float)ca[k];
+        cd_out[k] = (float)cd[k];
+    }
+    ca_out[N] = (float)(ca[0] - (double)ca_out[0]);
+    cd_out[N] = (float)(cd[0] - (double)cd_out[0]);
+    // The negated line of the -kappa sample is in the OTHER fold state.  With the reference's float Pi
+    // (= pi (1 + 2.78e-8), EpipolarConsistencyCommon.hxx:155,159) the direct branch gives a = r (1 - e) and the
+    // folded one a = r (1 - e) + e for the same geometric line, e = 1 - pi / Pi: a constant offset of
+    // e * n_alpha bins between the two states (2.1e-5 bins at 768 -- the systematic shift DESIGN.md 2 is about).
+    const double Pi_f = (double)3.14159265359f, e = 1.0 - 3.14159265358979323846 / Pi_f;
+    const double delta = (fold0 ? -e : e) * g.n_alpha;
+    ca_out[N + 1] = (float)(ca[0] + delta - (double)ca_out[0]);
+    return ok;
 }
 
 // Pair geometry, ONE THREAD PER PAIR (ref: kernelEpipolarConsistencyComputeK01, ...RadonIntermediate.cu:13-67).
@@ -483,35 +552,79 @@ __device__ void fit_sample_polynomials(const EccPairParams& p, EccPairRecord& r)
 // device-wide sync in between, the two kernels are just ordered on the stream.
 __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 {
-    const long long local = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (local >= p.count) return;
-    int iP0, iP1, iD0, iD1, ci = 0, cj = 0;
-    if (p.indices) {
-        const int32_t* q = p.indices + 4 * (p.first + local);
-        iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
-    } else {
-        ecc_get_ij_device(p.first + local, p.n_views, ci, cj);
-        iP0 = iD0 = ci;
-        iP1 = iD1 = cj;
+    // two adjacent threads per pair: both compute K01 (cheap), thread v fits view v's polynomials
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long local = tid >> 1;
+    const int v = (int)(tid & 1);
+    const bool live = local < p.count;
+    int iP0 = 0, iP1 = 0, iD0 = 0, iD1 = 0, ci = 0, cj = 0;
+    if (live) {
+        if (p.indices) {
+            const int32_t* q = p.indices + 4 * (p.first + local);
+            iP0 = q[0]; iP1 = q[1]; iD0 = q[2]; iD1 = q[3];
+        } else {
+            ecc_get_ij_device(p.first + local, p.n_views, ci, cj);
+            iP0 = iD0 = ci;
+            iP1 = iD1 = cj;
+        }
     }
-    EccPairRecord r;
-    if (iP0 == iP1) {
-        for (int i = 0; i < 8; i++) r.K0[i] = r.K1[i] = 0.f;
+    float K0[8], K1[8];
+    if (!live || iP0 == iP1) {
+        for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
     } else {
         compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0, p.PinvTs + 12 * iP1,
-                    p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, r.K0, r.K1);
+                    p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, K0, K1);
     }
-    r.iD0 = iD0;
-    r.iD1 = iD1;
-    r.ci = ci;
-    r.cj = cj;
-    fit_sample_polynomials(p, r);
-    p.records[local] = r;
-    if (p.K01_out)
+    const float kappa_max = K1[7], dkappa = K1[6];
+    const float* K = v ? K1 : K0;
+    unsigned fold = 0u;
+    float ca[ECC_POLY_DEG + 3], cd[ECC_POLY_DEG + 2];
+    for (int k = 0; k < ECC_POLY_DEG + 3; ++k) ca[k] = 0.f;
+    for (int k = 0; k < ECC_POLY_DEG + 2; ++k) cd[k] = 0.f;
+    int ok = 0;
+    if (live && p.poly && kappa_max > 0.f && dkappa > 0.f) {
+        CurveGeom g;
+        g.theta_ref = atan2((double)K[1], (double)K[0]);
+        g.inv_range_t = 1.0 / (double)p.range_t;
+        g.n_alpha = (double)p.n_alpha;
+        g.n_t = (double)p.n_t;
+        ok = fit_view_polynomials(*p.poly, K, g, (double)kappa_max, &fold, ca, cd) ? 1 : 0;
+    }
+    ok &= __shfl_xor(ok, 1);  // both views of the pair (adjacent lanes; dead lanes carry 0 and have no live partner)
+    // The records are assembled in LDS and leave the workgroup as one contiguous, coalesced block: written straight
+    // from the threads every store instruction would scatter its 64 lanes over 32 records 312 bytes apart.
+    __shared__ EccPairRecord recs[128];
+    static_assert(sizeof(EccPairRecord) % 8 == 0, "record copied as 8-byte words");
+    EccPairRecord* r = &recs[threadIdx.x >> 1];
+    r->fold[v] = fold;
+    for (int k = 0; k < ECC_POLY_DEG + 3; ++k) r->ca[v][k] = ca[k];
+    for (int k = 0; k < ECC_POLY_DEG + 2; ++k) r->cd[v][k] = cd[k];
+    if (v == 0) {
         for (int i = 0; i < 8; i++) {
-            p.K01_out[16 * local + i] = r.K0[i];
-            p.K01_out[16 * local + 8 + i] = r.K1[i];
+            r->K0[i] = K0[i];
+            r->K1[i] = K1[i];
         }
+        r->iD0 = iD0;
+        r->iD1 = iD1;
+        r->ci = ci;
+        r->cj = cj;
+        r->poly_ok = ok;
+        r->x_scale = ok ? (float)(1.0 / (double)kappa_max) : 0.f;
+        if (live && p.K01_out)
+            for (int i = 0; i < 8; i++) {
+                p.K01_out[16 * local + i] = K0[i];
+                p.K01_out[16 * local + 8 + i] = K1[i];
+            }
+    }
+    __syncthreads();
+    const long long first_pair = (long long)blockIdx.x * 128;
+    const long long n_here = min((long long)128, p.count - first_pair);
+    if (n_here > 0) {
+        const int words = (int)(n_here * (sizeof(EccPairRecord) / 8));
+        const double* src = reinterpret_cast<const double*>(recs);
+        double* dst = reinterpret_cast<double*>(p.records + first_pair);
+        for (int q = threadIdx.x; q < words; q += 256) dst[q] = src[q];
+    }
 }
 
 template <bool DERIV, bool CORR>
@@ -761,7 +874,7 @@ extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, f
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k01_kernel, dim3((unsigned)((p->count + 255) / 256)), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(k01_kernel, dim3((unsigned)((2 * p->count + 255) / 256)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 
