@@ -61,6 +61,7 @@ SIGNATURES = {
     "ecc_metric_evaluate_range_async": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "ecc_metric_evaluate_pairs": (_i, [_vp, _vp, _i, _vp, _pd]),
     "ecc_metric_debug_K01": (_i, [_vp, _i64, _i64, _vp]),
+    "ecc_metric_debug_polynomials": (_i, [_vp, _i64, _i64, _vp]),
     "ecc_metric_pair_samples_bound": (_i, [_vp, _pi]),
     "ecc_metric_evaluate_for_image_pair": (_i, [_vp, _i, _i, _i, _pi, _vp, _vp, _vp, _vp, _vp, _vp, _pd]),
     "ecc_get_ij": (None, [_i64, _i, _pi, _pi]),

@@ -226,7 +226,7 @@ int ensure_poly_tables(ecc_ctx* ctx)
     constexpr int N = ECC_POLY_DEG + 1;
     EccPolyTables t;
     for (int j = 0; j < N; ++j) t.nodes[j] = std::cos(3.14159265358979323846 * (j + 0.5) / N);
-    const double checks[ECC_POLY_CHECKS] = {-0.93, 0.13, 0.97};
+    const double checks[ECC_POLY_CHECKS] = {-1.0, 0.13, 1.0};  // both ends: largest interpolation error, and the fold state there
     for (int j = 0; j < ECC_POLY_CHECKS; ++j) t.checks[j] = checks[j];
     // inverse Vandermonde matrices in z = x^2 for the even part (nodes z_0..z_H, z_H = 0) and the odd part
     // (nodes z_0..z_{H-1}): Gauss-Jordan with partial pivoting in long double
@@ -1561,4 +1561,35 @@ ECC_EXPORT void ecc_host_iso_center(const double* Ps, int n_views, double* O)
     O[1] = ecc_host::det3(A, b, A + 6) / det;
     O[2] = ecc_host::det3(A, A + 3, b) / det;
     O[3] = 1.0;
+}
+
+// ---- debug: the fitted sample-coordinate polynomials ---------------------------------------------
+ECC_EXPORT int ecc_metric_debug_polynomials(ecc_metric* m, int64_t first, int64_t count, float* out)
+{
+    static_assert(ECC_POLY_RECORD_FLOATS == 4 + 2 * (ECC_POLY_DEG + 3) + 2 * (ECC_POLY_DEG + 2), "header and layout disagree");
+    if (!m || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (count < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "empty range");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count, ctx->stream);
+    if (rc) return rc;
+    rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, nullptr);  // fills m->records_d[0..count)
+    if (rc) return rc;
+    std::vector<EccPairRecord> recs((size_t)count);
+    HIP_TRY(hipMemcpyAsync(recs.data(), m->records_d, sizeof(EccPairRecord) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int64_t q = 0; q < count; ++q) {
+        const EccPairRecord& r = recs[(size_t)q];
+        float* o = out + (size_t)q * ECC_POLY_RECORD_FLOATS;
+        *o++ = (float)r.poly_ok;
+        *o++ = r.x_scale;
+        *o++ = r.fold[0] ? 1.f : 0.f;
+        *o++ = r.fold[1] ? 1.f : 0.f;
+        for (int v = 0; v < 2; ++v)
+            for (int k = 0; k < ECC_POLY_DEG + 3; ++k) *o++ = r.ca[v][k];
+        for (int v = 0; v < 2; ++v)
+            for (int k = 0; k < ECC_POLY_DEG + 2; ++k) *o++ = r.cd[v][k];
+    }
+    return ECC_OK;
 }

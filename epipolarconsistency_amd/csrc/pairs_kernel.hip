@@ -368,8 +368,8 @@ __device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&
 // interpolation of degree 10 at Chebyshev nodes is good to < 1e-6 bins up to kappa_max ~ 1 rad (a C-arm short
 // scan: 1e-11 ... 3e-7 bins).  The thread that owns the pair in k01_kernel evaluates the reference's mapping
 // (computeK01 lines -> lineToSampleDtr, float constant Pi and float range_t included) at the 11 (symmetric) nodes in float64,
-// solves for the monomial coefficients, CHECKS them against the exact mapping at three more abscissae (tolerance
-// 1e-5 bins, fold state constant) and records the verdict; the pair kernel then spends ~14 instructions per view
+// solves for the monomial coefficients, CHECKS them against the exact mapping at both ends of the range and one
+// interior abscissa (tolerance 1e-5 bins, fold state constant) and records the verdict; the pair kernel then spends ~14 instructions per view
 // and coordinate on BOTH samples instead of sin/cos, line products, 1/len, a reciprocal, the atan polynomial and
 // the fold bookkeeping for each.  Pairs that fail the check (fold inside the range, baseline through the object,
 // degenerate geometry) take the exact per-sample path.

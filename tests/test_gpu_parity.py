@@ -208,3 +208,63 @@ def test_full_size_radon_spot_check(gpu_ctx, oracle_mod):
     assert np.array_equal(g, want), "max abs diff %g" % np.abs(g - want).max()
     # odd symmetry partner is implicit in the layout; non-trivial content
     assert np.abs(got).max() > 10
+
+
+def _exact_coords(K, kappa, n_alpha, n_t, range_t):
+    """float64 statement of line -> padded texel coordinates with the reference's float constants
+    (ref: ...RadonIntermediate.cu:74, EpipolarConsistencyCommon.hxx:152-171)."""
+    K = K.astype(np.float64)
+    c, s = np.cos(kappa), np.sin(kappa)
+    l0, l1, l2 = K[0] * c + K[3] * s, K[1] * c + K[4] * s, K[2] * c + K[5] * s
+    a = np.arctan2(l1, l0) / np.float64(np.float32(3.14159265359))
+    a = np.where(a < 0, a + 2, a)
+    d = -(l2 / np.hypot(l0, l1)) / np.float64(range_t) + 0.5
+    fold = a > 1
+    a = np.where(fold, a - 1, a)
+    d = np.where(fold, 1 - d, d)
+    return a * n_alpha + 0.5, d * n_t + 0.5, fold
+
+
+def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
+    """The per-pair polynomials of the pair-geometry kernel reproduce the exact line -> texel mapping to 2e-5 bins on
+    both the +kappa and the -kappa side (incl. the float-Pi offset between the two fold states), and pairs whose
+    fold state switches inside the kappa range are sent to the exact path."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    n, S, B = 24, 512, 384
+    Ps = synthetic.short_scan(n, S, S, 0.616)
+    rng = np.random.default_rng(3)
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(n)]
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    n_pairs = n * (n - 1) // 2
+    recs = m.debug_polynomials(0, n_pairs)
+    K01 = m.debug_K01(0, n_pairs)
+    range_t = np.float32(B) * np.float32(np.sqrt(2.0) * S / B)
+    n_ok, worst = 0, 0.0
+    for ij, (r, K) in enumerate(zip(recs, K01)):
+        kmax = float(K[15])
+        if not r["poly_ok"]:
+            # the exact mapping of such a pair has a fold switch (or the baseline passes through the object)
+            kap = np.linspace(-kmax, kmax, 2001)
+            sw = any(len(np.unique(_exact_coords(K[8 * v:8 * v + 8], kap, B, B, range_t)[2])) > 1 for v in (0, 1))
+            assert sw or kmax > 1.5
+            continue
+        n_ok += 1
+        assert abs(r["x_scale"] * kmax - 1) < 1e-6
+        kap = np.linspace(1e-4, kmax, 257)
+        x = kap * r["x_scale"]
+        for v in (0, 1):
+            Kv = K[8 * v:8 * v + 8]
+            ca, cd = r["ca"][v], r["cd"][v]
+            for sgn in (1, -1):
+                # the reference's -kappa sample is the line of (-cos, sin): the negated line of plane -kappa
+                Ks = Kv.copy().astype(np.float64)
+                Ks[0:3] *= sgn
+                xa, yd, fold = _exact_coords(Ks, kap, B, B, range_t)
+                assert np.all(fold == (r["fold"][v] if sgn == 1 else not r["fold"][v]))
+                c0 = ca[0] + (ca[11] if sgn == 1 else ca[12])
+                pa = np.polyval(np.concatenate([ca[10:0:-1], [c0]]), sgn * x)
+                pd = np.polyval(np.concatenate([cd[10:0:-1], [cd[0] + cd[11]]]), sgn * x)
+                worst = max(worst, np.abs(pa - xa).max(), np.abs(pd - yd).max())
+    assert n_ok > 0.8 * n_pairs
+    assert worst < 2e-5, worst
