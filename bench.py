@@ -202,7 +202,7 @@ def main():
                    "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "pairs_kernel<true>", "kernel_ms": pair_ms,
+                     "kernel": "pairs_kernel<true, false>", "kernel_ms": pair_ms,
                      "algorithmic_bytes_per_launch": launch_bytes},
         "ms_per_radon_intermediate": ms_per_radon,
         "ms_per_preprocess": ms_per_preprocess,

@@ -2,13 +2,14 @@
 //
 // Two stream-ordered launches do what the reference needs two kernels, two device-wide syncs and N_kappa
 // float atomics per pair for (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cu):
-//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> k01_kernel, one thread per pair, 96-byte records that the
-//                                                    pair kernel reads with scalar loads (no sync in between);
+//   kernelEpipolarConsistencyComputeK01 (:13-67)  -> k01_kernel: pair geometry plus, per view of the pair, the
+//                                                    sample coordinates as polynomials in kappa (EccPairRecord,
+//                                                    312 bytes), read by the pair kernel with scalar loads;
 //   kernelEpipolarCosistency<deriv,false> (:152-276) -> pairs_kernel: one wave64 per pair, kappa samples strided
 //                                                    over the lanes, shuffle reduction, ONE plain store.
 // Sampling replaces tex2D on a normalised, clamped, bilinear texture (ref: RadonIntermediate.cpp:192)
-// by the exact fp32 rule of SURVEY.md 8c on the padded, distance-fast slab of ecc_layout.h: two
-// 8-byte loads per sample (taps (i,j),(i,j+1) are adjacent), no index clamps.
+// by the exact fp32 rule of SURVEY.md 8c on a row-paired copy of the padded, distance-fast slab of
+// ecc_layout.h: ONE 16-byte load per sample (the 2x2 footprint is contiguous), no index clamps.
 // The per-pair sum is carried in binary64 (the reference's atomicAdd order is arbitrary; the oracle
 // does the same), so results do not depend on the reduction tree.
 #include <hip/hip_runtime.h>
@@ -74,20 +75,21 @@ __device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0
 }
 
 // =================================================================================================
-// The pair kernel.  Same algorithm as the reference, restructured for the CDNA4 vector ALU -- it is
-// bound by VALU issue (4 x (sqrt + atan2 + 2 divisions + bilinear) per kappa sample), not by memory:
+// The pair kernel.  Same algorithm as the reference, restructured for CDNA4:
 //   * one WAVE per pair (4 pairs per 256-thread workgroup, no barrier, no LDS): 64 lanes x 23
-//     iterations cover N_kappa = 1448 with 98 % lane utilisation; K01 comes from k01_kernel's record by
+//     iterations cover N_kappa = 1448 with 98 % lane utilisation; the pair's record comes from k01_kernel by
 //     scalar loads and lives in SGPRs;
-//   * +kappa and -kappa share the six products K[:,0]*cos, K[:,1]*sin (x(-kappa) = (-cos, sin));
-//   * the (alpha+pi, -t) periodicity fold is a sign-bit operation on the line instead of the
-//     reference's atan2 range tests: a line with l1 < 0 is negated (same point set), which maps
-//     a -> a-1, d -> 1-d, and the sample gets the sign bit back (derivative filter only);
-//   * 1/len by v_rsq_f32, the angle by one v_rcp_f32 + a degree-8 minimax polynomial of
-//     atan(q)/(pi q) in q^2 on [0,1] (max error 6.7e-8 in a, i.e. below the fp32 libm path of the
-//     oracle measured against float64), sin/cos(kappa) by the classic pi/4-reduced kernels
-//     (< 0.9 ulp); no IEEE division sequences in the loop;
-//   * two 8-byte loads per bilinear sample (taps (i,j),(i,j+1) are adjacent in the slab).
+//   * FAST PATH (record.poly_ok, the normal case): the four sample positions of a kappa step come from the
+//     record's polynomials (kappa_loop_poly / poly_pm), then one 16-byte load and the bilinear rule each;
+//   * EXACT PATH (kappa_loop / sample_line), for pairs whose fit was rejected: per sample
+//       - +kappa and -kappa share the six products K[:,0]*cos, K[:,1]*sin (x(-kappa) = (-cos, sin));
+//       - the (alpha+pi, -t) periodicity fold is a sign-bit operation on the line instead of the
+//         reference's atan2 range tests: a line with l1 < 0 is negated (same point set), which maps
+//         a -> a-1, d -> 1-d, and the sample gets the sign bit back (derivative filter only);
+//       - 1/len by v_rsq_f32, the angle by one v_rcp_f32 + a minimax polynomial of atan(q)/(pi q) in q^2
+//         (degree 8 on [0,1]: max error 6.7e-8 in a, below the fp32 libm path of the oracle measured against
+//         float64; degree 3 when the whole wave is near-horizontal), sin/cos(kappa) by pi/4-reduced kernels
+//         (< 0.9 ulp); no IEEE division sequences in the loop.
 // Differences to the oracle are at the ulp level of the sample coordinates; tests hold the mean
 // to 1e-5 and pair values to 2e-4 (fp32 noise floor, tests/test_oracle_properties.py).
 // =================================================================================================
