@@ -268,12 +268,16 @@ __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_
                                         float& plus, float& minus)
 {
     static_assert(ECC_POLY_DEG % 2 == 0, "even degree");
+#if defined(PK_EXP_CHEAP_POLY)  // timing experiment: degree-2 coordinates (wrong results; sample_at clamps them)
+    float E = c[2], O = c[1];
+#else
     float E = c[ECC_POLY_DEG], O = c[ECC_POLY_DEG - 1];
 #pragma unroll
     for (int k = ECC_POLY_DEG - 2; k >= 2; k -= 2) {
         E = fmaf(E, z, c[k]);
         O = fmaf(O, z, c[k - 1]);
     }
+#endif
     const float Ep = fmaf(E, z, lo_plus);
     const float Em = same_lo ? Ep : fmaf(E, z, lo_minus);
     const float xo = x * O;
@@ -286,6 +290,9 @@ template <bool DERIV, int PITCH4>
 __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f)
 {
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
+#if defined(PK_EXP_CHEAP_POLY)
+    xa = __builtin_amdgcn_fmed3f(xa, 1.f, n_t_f);  // square bin grids only
+#endif
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
     const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 8.0f);
 #if defined(PK_EXP_NO_LOAD)   // timing experiment: no memory traffic at all (wrong results)
@@ -299,7 +306,12 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ fold) : v;
 }
 
-// The kappa loop of one pair on the polynomial path (see fit_sample_polynomials).
+// The kappa loop of one pair on the polynomial path (see fit_view_polynomials).
+// Measured and dropped: two kappa steps (k, k + 64) per trip with eight gathers in flight per wave -- 0.409 ms against
+// 0.400 ms, so the kernel is not short of memory-level parallelism at 8 waves per SIMD; a two-stage software pipeline
+// across trips cannot be expressed: the compiler's wait-count insertion drains all loads at the loop header
+// (vmcnt(0) before the next stage's loads), and with the gathers in inline assembly it copies their destination
+// registers before the explicit wait.
 template <bool DERIV, bool CORR, int PITCH4>
 __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
                                                 float kappa_max, float w06, const SlabView sv0, const SlabView sv1,
@@ -633,13 +645,18 @@ template <bool DERIV, bool CORR>
 __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // XCD-aware mapping at workgroup granularity: a workgroup owns 4 consecutive pairs (they share
-    // view i, so its slab lines are reused out of this CU's L1); workgroups b and b+8 share an XCD.
+    // Workgroup -> pairs.  XCD-aware: workgroups b and b+8 share an XCD, and an XCD walks a contiguous part of the
+    // pair order (consecutive pairs share view i and have neighbouring partners j: their dtr bands are re-used out
+    // of that XCD's L2).  The four waves of a workgroup, however, take pairs a quarter of the range apart: with four
+    // CONSECUTIVE pairs per workgroup the waves run in lockstep through nearly the same lines of view i, and the L1
+    // serialises hits on lines whose fill is still in flight (TCP_PENDING_STALL_CYCLES: a quarter of its busy time)
+    // -- 0.400 -> 0.335 ms for 79 800 pairs; spreading further (other strides, 2-D tiles of views that halve the HBM
+    // traffic) was slower, see DESIGN.md 4.2.
     const long long nblk = (p.count + 3) / 4;
     const long long per_xcd = (nblk + 7) / 8;
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (blk >= nblk) return;
-    long long local = blk * 4 + wave;
+    long long local = (long long)wave * nblk + blk;
     if (local >= p.count) return;  // no barriers below: waves leave independently
     // wave-uniform record -> SGPRs (readfirstlane makes the address provably uniform: scalar loads)
     local = ((long long)__builtin_amdgcn_readfirstlane((int)(local >> 32)) << 32) |
@@ -651,7 +668,11 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
         K0[i] = uniformf(rec->K0[i]);
         K1[i] = uniformf(rec->K1[i]);
     }
+#if defined(PK_EXP_SAME_VIEWS)  // timing experiment: every pair samples dtrs 0 and 1 (L2-resident; wrong results)
+    const int iD0 = 0, iD1 = 1;
+#else
     const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
+#endif
     const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
 
     const unsigned pitch4 = (unsigned)p.pitch * 8u;  // row pitch of the paired copies in bytes
