@@ -261,6 +261,11 @@ int ensure_poly_tables(ecc_ctx* ctx)
     t.nodes[H] = 0.0;  // exactly
     invert_vandermonde(H + 1, t.Ae);
     invert_vandermonde(H, t.Ao);
+    for (int k = 0; k <= ECC_TRIG_STEPS; ++k) {
+        const double a = 3.14159265358979323846 * k / (2.0 * ECC_TRIG_STEPS);
+        t.sc[k][0] = k == 0 ? 0.0 : k == ECC_TRIG_STEPS ? 1.0 : std::sin(a);
+        t.sc[k][1] = k == 0 ? 1.0 : k == ECC_TRIG_STEPS ? 0.0 : std::cos(a);
+    }
     HIP_TRY(hipMalloc((void**)&ctx->poly_d, sizeof(EccPolyTables)));
     HIP_TRY(hipMemcpyAsync(ctx->poly_d, &t, sizeof(t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // t goes out of scope

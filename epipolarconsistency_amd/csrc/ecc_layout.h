@@ -83,11 +83,13 @@ struct EccPairRecord {
 // (x[N-1-j] = -x[j], x[H] = 0, N = DEG+1, H = DEG/2), so the fit splits into an even part E(z) of degree H in
 // z = x^2 through the H+1 values (f[j] + f[N-1-j])/2 (j <= H) and an odd part x O(z), O of degree H-1 through the H
 // values (f[j] - f[N-1-j])/(2 x[j]) (j < H):  e_k = sum_j Ae[k][j] fe[j],  o_k = sum_j Ao[k][j] fo[j].
+#define ECC_TRIG_STEPS 32
 struct EccPolyTables {
     double nodes[ECC_POLY_DEG + 1];
     double checks[ECC_POLY_CHECKS];
     double Ae[(ECC_POLY_DEG / 2 + 1) * (ECC_POLY_DEG / 2 + 1)];
     double Ao[(ECC_POLY_DEG / 2) * (ECC_POLY_DEG / 2)];
+    double sc[ECC_TRIG_STEPS + 1][2];  // {sin, cos}(k pi / (2 ECC_TRIG_STEPS)), k = 0 .. ECC_TRIG_STEPS: the fit's float64 trigonometry
 };
 
 struct EccPairParams {

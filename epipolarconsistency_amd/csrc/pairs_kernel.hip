@@ -31,11 +31,11 @@ __device__ __forceinline__ void shift_origin_and_normalize(float x, float y, flo
     for (int i = 0; i < 6; i++) Ki[i] /= s0;
 }
 
-// ref: EpipolarConsistencyCommon.hxx:93-149 (computeK01), same expressions in fp32.
-__device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0, const float* __restrict__ C1,
-                            const float* __restrict__ P0invT, const float* __restrict__ P1invT,
-                            float object_radius_mm, float num_samples, float dkappa, bool want_view_angle,
-                            float* K0, float* K1)
+// ref: EpipolarConsistencyCommon.hxx:93-149 (computeK01), same expressions in fp32, in three parts so that a thread
+// that needs one view's half computes only that (k01_kernel); compute_K01 below is the whole function.
+// Part 1 (:115-129): Pluecker baseline B = C0 ^ C1, its norms and the pencil K = [E0, E90] of epipolar planes.
+__device__ __forceinline__ void baseline_pencil(const float* __restrict__ C0, const float* __restrict__ C1, float* K, float& s2,
+                                                float& s3)
 {
     float B01 = C0[0] * C1[1] - C0[1] * C1[0];
     float B02 = C0[0] * C1[2] - C0[2] * C1[0];
@@ -43,35 +43,55 @@ __device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0
     float B12 = C0[1] * C1[2] - C0[2] * C1[1];
     float B13 = C0[1] * C1[3] - C0[3] * C1[1];
     float B23 = C0[2] * C1[3] - C0[3] * C1[2];
-    const float s2 = sqrtf(B12 * B12 + B02 * B02 + B01 * B01);
-    const float s3 = sqrtf(B03 * B03 + B13 * B13 + B23 * B23);
-    float K[8] = {+B12 / s2, -B02 / s2, +B01 / s2, 0,
-                  (-B01 * B13 - B02 * B23) / (s2 * s3), (+B01 * B03 - B12 * B23) / (s2 * s3),
-                  (+B02 * B03 + B12 * B13) / (s2 * s3), -s2 / s3};
+    s2 = sqrtf(B12 * B12 + B02 * B02 + B01 * B01);
+    s3 = sqrtf(B03 * B03 + B13 * B13 + B23 * B23);
+    K[0] = +B12 / s2; K[1] = -B02 / s2; K[2] = +B01 / s2; K[3] = 0;
+    K[4] = (-B01 * B13 - B02 * B23) / (s2 * s3);
+    K[5] = (+B01 * B03 - B12 * B23) / (s2 * s3);
+    K[6] = (+B02 * B03 + B12 * B13) / (s2 * s3);
+    K[7] = -s2 / s3;
+}
+
+// Part 2 (:131-135): one view's 3x2 map kappa -> epipolar line, origin at the image centre, unit normal at kappa = 0.
+__device__ __forceinline__ void project_pencil(const float* __restrict__ PinvT, const float* K, float n_x2, float n_y2, float* Kv)
+{
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            float s0 = 0, s1 = 0;
+            float sum = 0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                s0 += P0invT[s * 3 + i] * K[j * 4 + s];
-                s1 += P1invT[s * 3 + i] * K[j * 4 + s];
-            }
-            K0[j * 3 + i] = s0;
-            K1[j * 3 + i] = s1;
+            for (int s = 0; s < 4; s++) sum += PinvT[s * 3 + i] * K[j * 4 + s];
+            Kv[j * 3 + i] = sum;
         }
-    shift_origin_and_normalize(n_x2, n_y2, K0);
-    shift_origin_and_normalize(n_x2, n_y2, K1);
-    K0[6] = s2 / s3;
+    shift_origin_and_normalize(n_x2, n_y2, Kv);
+}
+
+// Part 3 (:137-148): baseline distance, view angle, kappa range and step.
+__device__ __forceinline__ void pencil_range(float s2, float s3, float object_radius_mm, float num_samples, float dkappa,
+                                             bool want_view_angle, float& K06, float& K07, float& K16, float& K17)
+{
+    K06 = s2 / s3;
     // Elementary functions correctly rounded (binary64, rounded once), like the oracle; they run once
     // per pair.  K0[7] (angle between the views) is not used by the metric: debug output only.
-    K0[7] = want_view_angle ? -2.0f * (float)atan2((double)(-0.5f * s3), (double)(s2 / s3)) : 0.f;
+    K07 = want_view_angle ? -2.0f * (float)atan2((double)(-0.5f * s3), (double)(s2 / s3)) : 0.f;
     const float Pi = 3.14159265359f;
-    if (K0[6] <= object_radius_mm) K1[7] = 0.5f * Pi;
-    else K1[7] = (float)asin((double)(object_radius_mm / K0[6]));
-    if (dkappa <= 0.f) K1[6] = 2.f * K1[7] / num_samples;
-    else K1[6] = dkappa;
+    if (K06 <= object_radius_mm) K17 = 0.5f * Pi;
+    else K17 = (float)asin((double)(object_radius_mm / K06));
+    if (dkappa <= 0.f) K16 = 2.f * K17 / num_samples;
+    else K16 = dkappa;
+}
+
+__device__ void compute_K01(float n_x2, float n_y2, const float* __restrict__ C0, const float* __restrict__ C1,
+                            const float* __restrict__ P0invT, const float* __restrict__ P1invT,
+                            float object_radius_mm, float num_samples, float dkappa, bool want_view_angle,
+                            float* K0, float* K1)
+{
+    float K[8], s2, s3;
+    baseline_pencil(C0, C1, K, s2, s3);
+    project_pencil(P0invT, K, n_x2, n_y2, K0);
+    project_pencil(P1invT, K, n_x2, n_y2, K1);
+    pencil_range(s2, s3, object_radius_mm, num_samples, dkappa, want_view_angle, K0[6], K0[7], K1[6], K1[7]);
 }
 
 // =================================================================================================
@@ -394,36 +414,49 @@ struct CurvePoint {
     bool valid;
 };
 
-// sin and cos in float64 for |t| <= pi/2 by their Taylor series (t^24/24! < 1e-19 there): 25 multiply-adds, no
-// range reduction -- the fit needs them at a handful of node angles and inside one Newton step per point.
-__device__ __forceinline__ void sincos_taylor(double t, double& s, double& c)
+// The fit's float64 trigonometry.  No libm and no long series: a table of sin/cos at multiples of pi/64
+// (EccPolyTables::sc, correctly rounded on the host) brings every argument within pi/128 of a table angle, where
+// five series terms are exact to 1e-19.  (A float64 sincos by its 25-term Taylor series plus a float64 division per
+// evaluated point made k01_kernel three times as long.)
+#define ECC_TRIG_STEP (3.14159265358979323846 / (2.0 * ECC_TRIG_STEPS))
+
+// sin and cos of t in [0, pi/2 + 1e-6]
+__device__ __forceinline__ void sincos_table(const EccPolyTables& T, double t, double& s, double& c)
 {
-    const double z = t * t;
-    double pc = 1.0 / 620448401733239439360000.0;   // 1/24!
-    pc = pc * z - 1.0 / 1124000727777607680000.0;    // 1/22!
-    pc = pc * z + 1.0 / 2432902008176640000.0;       // 1/20!
-    pc = pc * z - 1.0 / 6402373705728000.0;          // 1/18!
-    pc = pc * z + 1.0 / 20922789888000.0;            // 1/16!
-    pc = pc * z - 1.0 / 87178291200.0;               // 1/14!
-    pc = pc * z + 1.0 / 479001600.0;                 // 1/12!
-    pc = pc * z - 1.0 / 3628800.0;                   // 1/10!
-    pc = pc * z + 1.0 / 40320.0;
-    pc = pc * z - 1.0 / 720.0;
-    pc = pc * z + 1.0 / 24.0;
-    pc = pc * z - 0.5;
-    c = pc * z + 1.0;
-    double ps = -1.0 / 25852016738884976640000.0;    // -1/23!
-    ps = ps * z + 1.0 / 51090942171709440000.0;      // 1/21!
-    ps = ps * z - 1.0 / 121645100408832000.0;        // 1/19!
-    ps = ps * z + 1.0 / 355687428096000.0;           // 1/17!
-    ps = ps * z - 1.0 / 1307674368000.0;             // 1/15!
-    ps = ps * z + 1.0 / 6227020800.0;                // 1/13!
-    ps = ps * z - 1.0 / 39916800.0;                  // 1/11!
-    ps = ps * z + 1.0 / 362880.0;
-    ps = ps * z - 1.0 / 5040.0;
-    ps = ps * z + 1.0 / 120.0;
-    ps = ps * z - 1.0 / 6.0;
-    s = ps * z * t + t;
+    int k = (int)(t * (1.0 / ECC_TRIG_STEP) + 0.5);
+    k = min(max(k, 0), ECC_TRIG_STEPS);  // (a NaN converts to 0)
+    const double d = fma((double)-k, ECC_TRIG_STEP, t), z = d * d;
+    const double sd = d * fma(z, fma(z, fma(z, fma(z, 1.0 / 362880.0, -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const double cd = fma(z, fma(z, fma(z, fma(z, 1.0 / 40320.0, -1.0 / 720.0), 1.0 / 24.0), -0.5), 1.0);
+    const double sk = T.sc[k][0], ck = T.sc[k][1];
+    s = fma(sk, cd, ck * sd);
+    c = fma(ck, cd, -(sk * sd));
+}
+
+// Angle of the vector (x, y) in (-pi, pi]: crude float estimate -> rotation back by
+// the nearest table angle -> atan of the small remainder by its series; the reciprocal by two Newton steps.
+__device__ __forceinline__ double angle_table(const EccPolyTables& T, double x, double y)
+{
+    const float ax = fabsf((float)x), ay = fabsf((float)y);
+    // angle of (|x|, |y|) in units of pi, [0, 1/2], good to 1.3e-3: atan(q) ~ q (pi/4 + 0.273 (1 - q)) on [0, 1] --
+    // only the nearest table entry is wanted, the series below absorbs a remainder of pi/128 + 4e-3 (t^11/11 ~ 1e-18)
+    const float lo = fminf(ax, ay), hi = fmaxf(ax, ay), q = lo * __builtin_amdgcn_rcpf(hi);
+    float a = q * fmaf(-0.0869f, q, 0.3369f);
+    if (ay > ax) a = 0.5f - a;
+    if (x < 0) a = 1.0f - a;  // angle of (x, |y|) in [0, 1]
+    int k = (int)(a * (2.0f * ECC_TRIG_STEPS) + 0.5f);
+    k = min(max(k, 0), 2 * ECC_TRIG_STEPS);
+    const int kk = k <= ECC_TRIG_STEPS ? k : 2 * ECC_TRIG_STEPS - k;
+    const double sk = T.sc[kk][0], ck = k <= ECC_TRIG_STEPS ? T.sc[kk][1] : -T.sc[kk][1];
+    const double yy = fabs(y);
+    const double u = fma(x, ck, yy * sk), w = fma(yy, ck, -(x * sk));  // (x, |y|) rotated by -k pi/64: u = length * cos(rest) > 0
+    double r = (double)__builtin_amdgcn_rcpf((float)u);
+    r = r * fma(-u, r, 2.0);
+    r = r * fma(-u, r, 2.0);
+    const double t = w * r, z = t * t;
+    const double d = t * fma(z, fma(z, fma(z, fma(z, 1.0 / 9.0, -1.0 / 7.0), 1.0 / 5.0), -1.0 / 3.0), 1.0);
+    const double ang = fma((double)k, ECC_TRIG_STEP, d);
+    return y < 0 ? -ang : ang;
 }
 
 // The reference's mapping line -> (angle, distance) texel coordinates for one point of a view's curve
@@ -431,114 +464,124 @@ __device__ __forceinline__ void sincos_taylor(double t, double& s, double& c)
 // the texel mapping of a normalised texture), in float64 with the reference's float constants, one coordinate
 // at a time.
 // The angle of (l0, l1) is taken RELATIVE to the curve's line at kappa = 0, whose normal (K[0], K[1]) is a unit
-// vector by construction (shiftOriginAndNormlaize): theta = theta_ref + D, D = angle of (dot, cross); D comes from
-// a float seed (the pair kernel's atan polynomial, 2e-7 rad) and ONE Newton step on the rotation in float64
-// (residual ~1e-20) -- a fraction of a float64 atan2.  1/len likewise: float rsqrt + two Newton steps.
-// Not valid (-> the pair takes the exact path) when the line turns by 90 degrees or more against kappa = 0.
-// The fold state is decided by the angle.
+// vector by construction (shiftOriginAndNormlaize): theta = theta_ref + D, D = angle of (dot, cross) by angle_table.
+// 1/len: float rsqrt + two Newton steps.  Not valid (-> the pair takes the exact path) when the line turns by 90
+// degrees or more against kappa = 0.  The fold state is decided by the angle.
 struct CurveGeom {
     double theta_ref, inv_range_t, n_alpha, n_t;
+    // l(kappa) = A cos + B sin with A = (K[0], K[1]), B = (K[3], K[4]): nn = A.A, alpha = A.B, beta = A x B, gamma = B.B
+    double nn, alpha, beta, gamma, k2, k5;
 };
 
-__device__ __forceinline__ double exact_angle_coord(const float* K, const CurveGeom& g, double c, double s, bool& fold, bool& valid)
+__device__ __forceinline__ void curve_geometry(const float* K, CurveGeom& g)
 {
-    const double pi = 3.14159265358979323846, Pi_f = (double)3.14159265359f;
-    const double l0 = (double)K[0] * c + (double)K[3] * s;
-    const double l1 = (double)K[1] * c + (double)K[4] * s;
-    const double dot = l0 * (double)K[0] + l1 * (double)K[1];
-    const double cross = l1 * (double)K[0] - l0 * (double)K[1];
+    const double a0 = K[0], a1 = K[1], b0 = K[3], b1 = K[4];
+    g.nn = fma(a0, a0, a1 * a1);
+    g.alpha = fma(a0, b0, a1 * b1);
+    g.beta = fma(a0, b1, -(a1 * b0));
+    g.gamma = fma(b0, b0, b1 * b1);
+    g.k2 = K[2];
+    g.k5 = K[5];
+}
+
+__device__ __forceinline__ double exact_angle_coord(const EccPolyTables& T, const CurveGeom& g, double c, double s, bool& fold,
+                                                    bool& valid)
+{
+    const double pi = 3.14159265358979323846, inv_Pi_f = 1.0 / (double)3.14159265359f;
+    const double dot = fma(g.nn, c, g.alpha * s);  // l . A
+    const double cross = g.beta * s;               // A x l
     valid = dot > 0.0 && fabs(cross) < 1e30 && dot < 1e30;
-    // seed: atan(cross/dot) to ~2e-7 rad from the float polynomial (|cross/dot| <= 1) or its complement
-    const float fd = (float)dot, fc = (float)cross;
-    float seed;
-    if (fabsf(fc) <= fd) seed = 3.14159265358979f * atan_over_pi(fc * __builtin_amdgcn_rcpf(fd));
-    else seed = copysignf(1.57079632679490f, fc) - 3.14159265358979f * atan_over_pi(fd * __builtin_amdgcn_rcpf(fc));
-    double s0, c0;
-    sincos_taylor((double)seed, s0, c0);
-    const double D = (double)seed + (cross * c0 - dot * s0) / (dot * c0 + cross * s0);
+    const double D = angle_table(T, dot, cross);
     double theta = g.theta_ref + D;     // in (-3pi/2, 3pi/2): bring back to atan2's range (-pi, pi]
     if (theta > pi) theta -= 2.0 * pi;
     else if (theta <= -pi) theta += 2.0 * pi;
-    double a = theta / Pi_f;
+    double a = theta * inv_Pi_f;
     if (a < 0) a += 2;
     fold = a > 1;
     if (fold) a -= 1;
-    return a * g.n_alpha + 0.5;  // texel position a*n_alpha - .5, +1 for the slab's border row
+    return fma(a, g.n_alpha, 0.5);  // texel position a*n_alpha - .5, +1 for the slab's border row
 }
 
-__device__ __forceinline__ double exact_distance_coord(const float* K, const CurveGeom& g, double c, double s, bool fold)
+__device__ __forceinline__ double exact_distance_coord(const CurveGeom& g, double c, double s, bool fold)
 {
-    const double l0 = (double)K[0] * c + (double)K[3] * s;
-    const double l1 = (double)K[1] * c + (double)K[4] * s;
-    const double l2 = (double)K[2] * c + (double)K[5] * s;
-    const double len2 = l0 * l0 + l1 * l1;
+    const double as = g.alpha * s;
+    const double len2 = fma(c, fma(g.nn, c, as + as), g.gamma * s * s);  // |A c + B s|^2
+    const double l2 = fma(g.k2, c, g.k5 * s), h = -0.5 * len2;
     double y = (double)__builtin_amdgcn_rsqf((float)len2);
-    y = y * (1.5 - 0.5 * len2 * y * y);
-    y = y * (1.5 - 0.5 * len2 * y * y);  // relative error ~1e-7 -> 1e-14 -> 1e-28
-    double d = -(l2 * y) * g.inv_range_t + 0.5;
+    y = y * fma(h * y, y, 1.5);
+    y = y * fma(h * y, y, 1.5);  // relative error ~1e-7 -> 1e-14 -> 1e-28
+    double d = fma(-(l2 * y), g.inv_range_t, 0.5);
     if (fold) d = 1 - d;
-    return d * g.n_t + 0.5;
-}
-
-// Monomial coefficients (float64) of one coordinate from its even/odd node combinations.
-__device__ __forceinline__ void solve_even_odd(const EccPolyTables& T, const double* fe, const double* fo, double* c)
-{
-    constexpr int H = ECC_POLY_DEG / 2;
-    for (int k = 0; k <= H; ++k) {
-        double e = 0;
-        for (int j = 0; j <= H; ++j) e += T.Ae[k * (H + 1) + j] * fe[j];
-        c[2 * k] = e;
-    }
-    for (int k = 0; k < H; ++k) {
-        double o = 0;
-        for (int j = 0; j < H; ++j) o += T.Ao[k * H + j] * fo[j];
-        c[2 * k + 1] = o;
-    }
+    return fma(d, g.n_t, 0.5);
 }
 
 // Fits the two polynomials of ONE view of one pair and checks them; ca_out: DEG+3 floats, cd_out: DEG+2 floats.
-__device__ bool fit_view_polynomials(const EccPolyTables& T, const float* K, const CurveGeom& g, double km, unsigned* fold_out,
+// The monomial coefficients are accumulated node by node (c_2k += Ae[k][j] fe_j, c_2k+1 += Ao[k][j] fo_j with the
+// even / odd combinations fe, fo of the values at +-x_j); the node loop stays rolled: unrolled, the kernel spilled
+// 150 scalar registers and spent a fifth of its instructions moving constants.
+__device__ bool fit_view_polynomials(const EccPolyTables& T, const CurveGeom& g, double km, unsigned* fold_out,
                                      float* ca_out, float* cd_out)
 {
     constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
     bool ok = true, fold0 = false;
-    double fe_a[H + 1], fo_a[H], fe_d[H + 1], fo_d[H];
-    for (int j = 0; j <= H; ++j) {
+    double ca[N], cd[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) ca[k] = cd[k] = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < H; ++j) {
+        const double xj = T.nodes[j];
         double sn, cs;
-        sincos_taylor(T.nodes[j] * km, sn, cs);
+        sincos_table(T, xj * km, sn, cs);
         bool f1 = false, f2 = false, v1 = true, v2 = true;
-        const double ap = exact_angle_coord(K, g, cs, sn, f1, v1);
+        const double ap = exact_angle_coord(T, g, cs, sn, f1, v1);
         if (j == 0) fold0 = f1;
-        // the mirrored node: cos(-t) = cos t, sin(-t) = -sin t
-        const double am = j < H ? exact_angle_coord(K, g, cs, -sn, f2, v2) : ap;
-        if (j == H) f2 = f1;
+        const double am = exact_angle_coord(T, g, cs, -sn, f2, v2);  // the mirrored node: cos(-t) = cos t, sin(-t) = -sin t
         ok = ok && v1 && v2 && f1 == fold0 && f2 == fold0;
-        const double dp = exact_distance_coord(K, g, cs, sn, fold0);
-        const double dm = j < H ? exact_distance_coord(K, g, cs, -sn, fold0) : dp;
-        fe_a[j] = 0.5 * (ap + am);
-        fe_d[j] = 0.5 * (dp + dm);
-        if (j < H) {
-            const double h = 0.5 / T.nodes[j];
-            fo_a[j] = (ap - am) * h;
-            fo_d[j] = (dp - dm) * h;
+        const double dp = exact_distance_coord(g, cs, sn, fold0);
+        const double dm = exact_distance_coord(g, cs, -sn, fold0);
+        const double h = 0.5 / xj;
+        const double ea = 0.5 * (ap + am), ed = 0.5 * (dp + dm), oa = (ap - am) * h, od = (dp - dm) * h;
+#pragma unroll
+        for (int k = 0; k <= H; ++k) {
+            const double w = T.Ae[k * (H + 1) + j];
+            ca[2 * k] = fma(w, ea, ca[2 * k]);
+            cd[2 * k] = fma(w, ed, cd[2 * k]);
+        }
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double w = T.Ao[k * H + j];
+            ca[2 * k + 1] = fma(w, oa, ca[2 * k + 1]);
+            cd[2 * k + 1] = fma(w, od, cd[2 * k + 1]);
         }
     }
-    double ca[N], cd[N];
-    solve_even_odd(T, fe_a, fo_a, ca);
-    solve_even_odd(T, fe_d, fo_d, cd);
+    {   // the centre node, kappa = 0
+        bool f1 = false, v1 = true;
+        const double a0 = exact_angle_coord(T, g, 1.0, 0.0, f1, v1);
+        const double d0 = exact_distance_coord(g, 1.0, 0.0, fold0);
+        ok = ok && v1 && f1 == fold0;
+#pragma unroll
+        for (int k = 0; k <= H; ++k) {
+            const double w = T.Ae[k * (H + 1) + H];
+            ca[2 * k] = fma(w, a0, ca[2 * k]);
+            cd[2 * k] = fma(w, d0, cd[2 * k]);
+        }
+    }
     // the check measures the interpolation error (float64 coefficients); the float rounding of the
     // coefficients is evaluation noise of the same kind as the exact path's own fp32 rounding
+#pragma unroll 1
     for (int j = 0; j < ECC_POLY_CHECKS; ++j) {
         const double x = T.checks[j];
         double sn, cs;
-        sincos_taylor(x * km, sn, cs);
+        sincos_table(T, fabs(x) * km, sn, cs);
+        if (x < 0) sn = -sn;
         bool f = false, v = true;
-        const double qa = exact_angle_coord(K, g, cs, sn, f, v);
-        const double qd = exact_distance_coord(K, g, cs, sn, fold0);
+        const double qa = exact_angle_coord(T, g, cs, sn, f, v);
+        const double qd = exact_distance_coord(g, cs, sn, fold0);
         double pa = ca[N - 1], pd = cd[N - 1];
+#pragma unroll
         for (int k = N - 2; k >= 0; --k) {
-            pa = pa * x + ca[k];
-            pd = pd * x + cd[k];
+            pa = fma(pa, x, ca[k]);
+            pd = fma(pd, x, cd[k]);
         }
         ok = ok && v && f == fold0 && fabs(pa - qa) <= 1e-5 && fabs(pd - qd) <= 1e-5;  // NaN fails
     }
@@ -559,14 +602,18 @@ __device__ bool fit_view_polynomials(const EccPolyTables& T, const float* K, con
     return ok;
 }
 
-// Pair geometry, ONE THREAD PER PAIR (ref: kernelEpipolarConsistencyComputeK01, ...RadonIntermediate.cu:13-67).
-// A wave of the pair kernel would spend ~900 vector instructions (float64 asin, ~25 IEEE divisions, get_ij) on
-// this per pair with all 64 lanes doing the same thing -- a sixth of its time; here 64 pairs share those
+// Pair geometry and polynomial fit, TWO THREADS PER PAIR (ref for the geometry: kernelEpipolarConsistencyComputeK01,
+// ...RadonIntermediate.cu:13-67).  A wave of the pair kernel would spend ~900 vector instructions (float64 asin, ~25
+// IEEE divisions, get_ij) on the geometry per pair with all 64 lanes doing the same thing; here 64 pairs share those
 // instructions and the pair kernel picks the result up with scalar loads.  Unlike the reference there is no
 // device-wide sync in between, the two kernels are just ordered on the stream.
+// The kernel is bound by float64 issue (4 cycles per wave instruction, PMC: the vector ALU is busy 3/4 of the
+// time), i.e. by its instruction count: four threads per pair (one per view and coordinate, one role per wave) repeat
+// the geometry and the node sin/cos and were slower (30 vs 25 us); what pays is fewer instructions per point
+// (sincos_table / angle_table, explicit fma: 35 -> 25 us for 79 800 pairs).
 __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 {
-    // two adjacent threads per pair: both compute K01 (cheap), thread v fits view v's polynomials
+    // two adjacent threads per pair: thread v handles view v
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long local = tid >> 1;
     const int v = (int)(tid & 1);
@@ -582,15 +629,18 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
             iP1 = iD1 = cj;
         }
     }
-    float K0[8], K1[8];
-    if (!live || iP0 == iP1) {
-        for (int i = 0; i < 8; i++) K0[i] = K1[i] = 0.f;
-    } else {
-        compute_K01(p.n_x2, p.n_y2, p.Cs + 4 * iP0, p.Cs + 4 * iP1, p.PinvTs + 12 * iP0, p.PinvTs + 12 * iP1,
-                    p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, K0, K1);
+    // thread v computes its own view's half of K01: Kv[0..5] the line map, Kv[6..7] = (baseline distance, view angle)
+    // for view 0, (dkappa, kappa_max) for view 1 -- the layout of the reference's K01 array
+    float Kv[8], kappa_max = 0.f, dkappa = 0.f;
+    for (int i = 0; i < 8; i++) Kv[i] = 0.f;
+    if (live && iP0 != iP1) {
+        float Kp[8], s2, s3, K06, K07;
+        baseline_pencil(p.Cs + 4 * iP0, p.Cs + 4 * iP1, Kp, s2, s3);
+        project_pencil(p.PinvTs + 12 * (v ? iP1 : iP0), Kp, p.n_x2, p.n_y2, Kv);
+        pencil_range(s2, s3, p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, K06, K07, dkappa, kappa_max);
+        Kv[6] = v ? dkappa : K06;
+        Kv[7] = v ? kappa_max : K07;
     }
-    const float kappa_max = K1[7], dkappa = K1[6];
-    const float* K = v ? K1 : K0;
     unsigned fold = 0u;
     float ca[ECC_POLY_DEG + 3], cd[ECC_POLY_DEG + 2];
     for (int k = 0; k < ECC_POLY_DEG + 3; ++k) ca[k] = 0.f;
@@ -598,11 +648,12 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     int ok = 0;
     if (live && p.poly && kappa_max > 0.f && dkappa > 0.f) {
         CurveGeom g;
-        g.theta_ref = atan2((double)K[1], (double)K[0]);
+        g.theta_ref = angle_table(*p.poly, (double)Kv[0], (double)Kv[1]);
         g.inv_range_t = 1.0 / (double)p.range_t;
         g.n_alpha = (double)p.n_alpha;
         g.n_t = (double)p.n_t;
-        ok = fit_view_polynomials(*p.poly, K, g, (double)kappa_max, &fold, ca, cd) ? 1 : 0;
+        curve_geometry(Kv, g);
+        ok = fit_view_polynomials(*p.poly, g, (double)kappa_max, &fold, ca, cd) ? 1 : 0;
     }
     ok &= __shfl_xor(ok, 1);  // both views of the pair (adjacent lanes; dead lanes carry 0 and have no live partner)
     // The records are assembled in LDS and leave the workgroup as one contiguous, coalesced block: written straight
@@ -613,22 +664,17 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     r->fold[v] = fold;
     for (int k = 0; k < ECC_POLY_DEG + 3; ++k) r->ca[v][k] = ca[k];
     for (int k = 0; k < ECC_POLY_DEG + 2; ++k) r->cd[v][k] = cd[k];
+    float* Kdst = v ? r->K1 : r->K0;
+    for (int i = 0; i < 8; i++) Kdst[i] = Kv[i];
+    if (live && p.K01_out)
+        for (int i = 0; i < 8; i++) p.K01_out[16 * local + 8 * v + i] = Kv[i];
     if (v == 0) {
-        for (int i = 0; i < 8; i++) {
-            r->K0[i] = K0[i];
-            r->K1[i] = K1[i];
-        }
         r->iD0 = iD0;
         r->iD1 = iD1;
         r->ci = ci;
         r->cj = cj;
         r->poly_ok = ok;
         r->x_scale = ok ? (float)(1.0 / (double)kappa_max) : 0.f;
-        if (live && p.K01_out)
-            for (int i = 0; i < 8; i++) {
-                p.K01_out[16 * local + i] = K0[i];
-                p.K01_out[16 * local + 8 + i] = K1[i];
-            }
     }
     __syncthreads();
     const long long first_pair = (long long)blockIdx.x * 128;
@@ -740,7 +786,22 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const long long n4 = count >> 2;
     const float4* __restrict__ v4 = reinterpret_cast<const float4*>(vals);
-    for (long long k = threadIdx.x; k < n4; k += 1024) {
+    // eight loads in flight per thread: the kernel is one workgroup reading what other XCDs have just written
+    // (HBM latency each time), issued one at a time it took 10 us for 79 800 values
+    long long k = threadIdx.x;
+    for (; k + 7 * 1024 < n4; k += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = v4[k + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 += (double)v[u].x;
+            a1 += (double)v[u].y;
+            a2 += (double)v[u].z;
+            a3 += (double)v[u].w;
+        }
+    }
+    for (; k < n4; k += 1024) {
         const float4 v = v4[k];
         a0 += (double)v.x;
         a1 += (double)v.y;
