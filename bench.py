@@ -8,9 +8,10 @@ all n(n-1)/2 pairs, the float64 reduction and the scalar back on the host.  Rado
 resident in HBM when the timed region starts (they are computed once per data set, before it, and
 that cost is reported separately as ms_per_radon_intermediate).
 
-N GPUs: one process per GPU (torchrun), dtr stack produced data-parallel + all-gathered once,
-contiguous shards of the pair range per rank, one 8-byte RCCL all-reduce per evaluation.  The total
-work per evaluation is fixed, so scaling is "strong".
+N GPUs: one process per GPU (torchrun), dtr stack produced data-parallel + all-gathered once (RCCL),
+contiguous shards of the pair range per rank, and per evaluation the 8-byte partial sums -- already
+on the host -- are added through the library's shared-memory exchange (--exchange collective: an
+all-reduce of a device scalar instead).  The total work per evaluation is fixed, so scaling is "strong".
 
 Prints ONE JSON line on rank 0.
 """
@@ -38,6 +39,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
+    ap.add_argument("--exchange", default="shm", choices=["shm", "collective"],
+                    help="N > 1: per-evaluation sum of the partial results through the library's shared-memory "
+                         "exchange (default; falls back to the collective if /dev/shm is unusable) or an all-reduce")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
@@ -144,10 +148,30 @@ def main():
         Pk[moving] = (P_moving @ T).T.reshape(12)
         poses.append(Pk)
 
+    # N > 1: the per-evaluation exchange of the 8-byte partial sums
+    exchange = None
+    if world > 1 and args.exchange == "shm":
+        ok = True
+        try:
+            exchange = sharding.open_exchange(rank, world, dist.barrier)
+        except Exception as e:  # no usable /dev/shm
+            sys.stderr.write("rank %d: shared-memory exchange unavailable (%s)\n" % (rank, e))
+            exchange, ok = None, False
+            if rank == 0:
+                dist.barrier()  # the one open_exchange did not reach
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0:
+            exchange = None  # all ranks take the collective
+        elif abs(exchange.sum(float(rank + 1)) - world * (world + 1) / 2.0) > 1e-12:
+            raise SystemExit("shared-memory exchange returned a wrong sum")
+
     def step(k):
         metric.setProjectionMatrices(poses[k % len(poses)])
         if world == 1:
             return metric.evaluate()
+        if exchange is not None:
+            return sharding.exchanged_evaluate(metric, n, exchange)
         return sharding.distributed_evaluate(metric, n, sum_t, rank, world)
 
     def fence():
@@ -199,7 +223,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%d-projection %dx%d circular short scan, %dx%d Radon bins, all %d pairs"
                                % (n, S, S, B, B, n_pairs),
-                   "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d" % world},
+                   "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d" % world,
+                   "sum_exchange": "none" if world == 1 else ("host shared memory" if exchange is not None
+                                                               else "all-reduce (%s)" % args.backend)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "pairs_kernel<true, false>", "kernel_ms": pair_ms,
@@ -258,6 +284,9 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
+        if exchange is not None:
+            exchange.close()
         dist.destroy_process_group()
 
 

@@ -343,6 +343,9 @@ int check_radon_args(ecc_ctx* ctx, const float* image, int n, int n_u, int n_v, 
 
 // ---- misc ------------------------------------------------------------------------------------
 ECC_EXPORT const char* ecc_last_error(void) { return g_last_error.c_str(); }
+
+// for the other translation units of the library (ecc_exchange.hip)
+int ecc_set_error(int code, const char* msg) { return fail(code, msg); }
 ECC_EXPORT int ecc_version(void) { return ECC_HIP_VERSION; }
 ECC_EXPORT int ecc_device_count(void)
 {
@@ -867,7 +870,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
     if (rc) return rc;
     if (pair_values && count > 0)
         HIP_TRY(hipMemcpyAsync(pair_values, m->pair_values_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(wait_stream_spin(ctx->stream));
     *partial_sum = *m->sum_h;
     return ECC_OK;
 }

@@ -3,8 +3,12 @@
 Pairs are independent; the only cross-pair operation of the path is the final sum
 (ref: EpipolarConsistencyRadonIntermediate.cpp:216-224).  Every rank holds the whole (replicated)
 dtr stack, evaluates a contiguous, equal-count chunk of the get_ij order and the ranks exchange one
-float64 partial sum per evaluation (RCCL all-reduce on GPUs; gloo in the CPU tests).
+float64 partial sum per evaluation: through the library's host-side exchange (ScalarExchange -- the partial sums
+are on the host already, a shared-memory cache line per rank costs ~1 us) or, with --exchange rccl, an RCCL
+all-reduce of a device scalar (gloo in the CPU tests).  Bulk data (the dtr stack) always moves with RCCL.
 """
+import ctypes as C
+import os
 
 
 def pair_range(rank, world, n_pairs):
@@ -41,3 +45,60 @@ def distributed_evaluate(metric, n_views, sum_tensor, rank, world, group=None):
     first, count = pair_range(rank, world, n_pairs)
     metric.evaluate_range_async(first, count, sum_tensor)
     return allreduce_mean(sum_tensor, n_pairs, group)
+
+
+class ScalarExchange:
+    """Sum of one float64 per rank between the processes of one node (ecc_exchange_* of the C ABI).
+    Rank 0 creates the shared-memory segment, the others wait for it; every rank gets the same bits back
+    (fixed summation order).  `name` must be the same on all ranks and unique per job."""
+
+    def __init__(self, rank, world, name=None):
+        from . import _lib
+        from .api import check
+        if name is None:
+            name = default_exchange_name()
+        self._h = C.c_void_p()
+        self.rank, self.world, self.name = rank, world, name
+        check(_lib.lib().ecc_exchange_open(name.encode(), int(rank), int(world), C.byref(self._h)))
+
+    def sum(self, partial):
+        from . import _lib
+        from .api import check
+        out = C.c_double()
+        check(_lib.lib().ecc_exchange_sum(self._h, float(partial), C.byref(out)))
+        return out.value
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.lib().ecc_exchange_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def open_exchange(rank, world, barrier, name=None):
+    """Opens the exchange on all ranks: rank 0 first (it removes a stale segment of the same name and creates a
+    fresh one), then -- after `barrier()` -- the others, so that nobody can attach to a leftover of a crashed job."""
+    ex = ScalarExchange(rank, world, name) if rank == 0 else None
+    barrier()
+    if rank != 0:
+        ex = ScalarExchange(rank, world, name)
+    return ex
+
+
+def default_exchange_name():
+    """One name per torchrun job: the rendezvous port (same on all ranks) and the user id."""
+    return "/ecc_hip_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
+
+
+def exchanged_evaluate(metric, n_views, exchange):
+    """One all-pairs evaluation sharded over the ranks of `exchange`: this rank's shard through the synchronous
+    range call (partial sum lands in pinned host memory), then the host-side sum; returns the mean."""
+    n_pairs = n_views * (n_views - 1) // 2
+    first, count = pair_range(exchange.rank, exchange.world, n_pairs)
+    return exchange.sum(metric.evaluate_range(first, count)) / n_pairs

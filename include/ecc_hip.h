@@ -271,6 +271,21 @@ double ecc_host_angular_step(const double* P0, const double* P1, int n_u, int n_
  * O receives 4 doubles (w = 1). */
 void ecc_host_iso_center(const double* Ps, int n_views, double* O);
 
+/* ---- multi-process sum of the partial results (one process per GPU, one node) ------------------ */
+/* The path's only exchange step is the final sum over pairs (ref: ...RadonIntermediate.cpp:216-224; SURVEY.md 8e:
+ * "one all-reduce of 2 doubles per evaluation -- latency-bound").  ecc_metric_evaluate_range leaves each rank's
+ * partial sum on the host; ecc_exchange_sum adds the partial sums of all ranks through a POSIX shared-memory segment
+ * (a cache line per rank, polled; ~1 us) in rank order, so every rank returns the same bits.  No device is
+ * involved.  All ranks call ecc_exchange_sum the same number of times.
+ * name: shm name starting with '/', the same on all ranks and unique per job; rank 0 creates the segment, the other
+ * ranks wait for it.  A rank that does not show up makes the others fail with ECC_ERR_UNSUPPORTED after
+ * ECC_EXCHANGE_TIMEOUT_S seconds (environment, default 60) instead of hanging. */
+#define ECC_EXCHANGE_MAX_RANKS 64
+typedef struct ecc_exchange ecc_exchange;
+int ecc_exchange_open(const char* name, int rank, int world, ecc_exchange** out);
+int ecc_exchange_sum(ecc_exchange* ex, double partial, double* total);
+int ecc_exchange_close(ecc_exchange* ex);
+
 /* Last kernel timings measured with HIP events on the context's stream (ms), for bench.py:
  * which = 0 pair kernel of the last evaluate, 1 Radon kernel of the last radon_compute[_batch],
  * 2 pre-processing kernel of the last ecc_preprocess.
