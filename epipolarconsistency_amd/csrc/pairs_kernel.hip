@@ -515,56 +515,48 @@ __device__ __forceinline__ double exact_distance_coord(const CurveGeom& g, doubl
     return fma(d, g.n_t, 0.5);
 }
 
-// Fits the two polynomials of ONE view of one pair and checks them; ca_out: DEG+3 floats, cd_out: DEG+2 floats.
-// The monomial coefficients are accumulated node by node (c_2k += Ae[k][j] fe_j, c_2k+1 += Ao[k][j] fo_j with the
-// even / odd combinations fe, fo of the values at +-x_j); the node loop stays rolled: unrolled, the kernel spilled
-// 150 scalar registers and spent a fifth of its instructions moving constants.
-__device__ bool fit_view_polynomials(const EccPolyTables& T, const CurveGeom& g, double km, unsigned* fold_out,
-                                     float* ca_out, float* cd_out)
+// Fits ONE coordinate (ANGLE: the angle coordinate xa, else the distance coordinate yd) of one view of one pair and
+// checks it; c: DEG+1 float64 monomial coefficients in x = kappa / kappa_max.  The distance coordinate is fitted in
+// the direct (unfolded) state: the fold is the reflection yd -> n_t + 1 - yd, applied by the caller once the thread
+// that fits the angle has decided it.
+// The coefficients are accumulated node by node (c_2k += Ae[k][j] fe_j, c_2k+1 += Ao[k][j] fo_j with the even / odd
+// combinations fe, fo of the values at +-x_j); the node loop stays rolled: unrolled, the kernel spilled 150 scalar
+// registers and spent a fifth of its instructions moving constants.
+template <bool ANGLE>
+__device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, double km, bool& fold0, double* c)
 {
     constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
-    bool ok = true, fold0 = false;
-    double ca[N], cd[N];
+    bool ok = true;
+    fold0 = false;
 #pragma unroll
-    for (int k = 0; k < N; ++k) ca[k] = cd[k] = 0.0;
+    for (int k = 0; k < N; ++k) c[k] = 0.0;
 #pragma unroll 1
     for (int j = 0; j < H; ++j) {
         const double xj = T.nodes[j];
-        double sn, cs;
+        double sn, cs, fp, fm;
         sincos_table(T, xj * km, sn, cs);
-        bool f1 = false, f2 = false, v1 = true, v2 = true;
-        const double ap = exact_angle_coord(T, g, cs, sn, f1, v1);
-        if (j == 0) fold0 = f1;
-        const double am = exact_angle_coord(T, g, cs, -sn, f2, v2);  // the mirrored node: cos(-t) = cos t, sin(-t) = -sin t
-        ok = ok && v1 && v2 && f1 == fold0 && f2 == fold0;
-        const double dp = exact_distance_coord(g, cs, sn, fold0);
-        const double dm = exact_distance_coord(g, cs, -sn, fold0);
-        const double h = 0.5 / xj;
-        const double ea = 0.5 * (ap + am), ed = 0.5 * (dp + dm), oa = (ap - am) * h, od = (dp - dm) * h;
-#pragma unroll
-        for (int k = 0; k <= H; ++k) {
-            const double w = T.Ae[k * (H + 1) + j];
-            ca[2 * k] = fma(w, ea, ca[2 * k]);
-            cd[2 * k] = fma(w, ed, cd[2 * k]);
+        if (ANGLE) {
+            bool f1 = false, f2 = false, v1 = true, v2 = true;
+            fp = exact_angle_coord(T, g, cs, sn, f1, v1);
+            if (j == 0) fold0 = f1;
+            fm = exact_angle_coord(T, g, cs, -sn, f2, v2);  // the mirrored node: cos(-t) = cos t, sin(-t) = -sin t
+            ok = ok && v1 && v2 && f1 == fold0 && f2 == fold0;
+        } else {
+            fp = exact_distance_coord(g, cs, sn, false);
+            fm = exact_distance_coord(g, cs, -sn, false);
         }
+        const double fe = 0.5 * (fp + fm), fo = (fp - fm) * (0.5 / xj);
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const double w = T.Ao[k * H + j];
-            ca[2 * k + 1] = fma(w, oa, ca[2 * k + 1]);
-            cd[2 * k + 1] = fma(w, od, cd[2 * k + 1]);
-        }
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + j], fe, c[2 * k]);
+#pragma unroll
+        for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.Ao[k * H + j], fo, c[2 * k + 1]);
     }
     {   // the centre node, kappa = 0
         bool f1 = false, v1 = true;
-        const double a0 = exact_angle_coord(T, g, 1.0, 0.0, f1, v1);
-        const double d0 = exact_distance_coord(g, 1.0, 0.0, fold0);
-        ok = ok && v1 && f1 == fold0;
+        const double f0 = ANGLE ? exact_angle_coord(T, g, 1.0, 0.0, f1, v1) : exact_distance_coord(g, 1.0, 0.0, false);
+        if (ANGLE) ok = ok && v1 && f1 == fold0;
 #pragma unroll
-        for (int k = 0; k <= H; ++k) {
-            const double w = T.Ae[k * (H + 1) + H];
-            ca[2 * k] = fma(w, a0, ca[2 * k]);
-            cd[2 * k] = fma(w, d0, cd[2 * k]);
-        }
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + H], f0, c[2 * k]);
     }
     // the check measures the interpolation error (float64 coefficients); the float rounding of the
     // coefficients is evaluation noise of the same kind as the exact path's own fp32 rounding
@@ -574,49 +566,36 @@ __device__ bool fit_view_polynomials(const EccPolyTables& T, const CurveGeom& g,
         double sn, cs;
         sincos_table(T, fabs(x) * km, sn, cs);
         if (x < 0) sn = -sn;
-        bool f = false, v = true;
-        const double qa = exact_angle_coord(T, g, cs, sn, f, v);
-        const double qd = exact_distance_coord(g, cs, sn, fold0);
-        double pa = ca[N - 1], pd = cd[N - 1];
+        bool f = fold0, v = true;
+        const double q = ANGLE ? exact_angle_coord(T, g, cs, sn, f, v) : exact_distance_coord(g, cs, sn, false);
+        double pq = c[N - 1];
 #pragma unroll
-        for (int k = N - 2; k >= 0; --k) {
-            pa = fma(pa, x, ca[k]);
-            pd = fma(pd, x, cd[k]);
-        }
-        ok = ok && v && f == fold0 && fabs(pa - qa) <= 1e-5 && fabs(pd - qd) <= 1e-5;  // NaN fails
+        for (int k = N - 2; k >= 0; --k) pq = fma(pq, x, c[k]);
+        ok = ok && v && f == fold0 && fabs(pq - q) <= 1e-5;  // NaN fails
     }
-    *fold_out = fold0 ? 0x80000000u : 0u;
-    for (int k = 0; k < N; ++k) {
-        ca_out[k] = (float)ca[k];
-        cd_out[k] = (float)cd[k];
-    }
-    ca_out[N] = (float)(ca[0] - (double)ca_out[0]);
-    cd_out[N] = (float)(cd[0] - (double)cd_out[0]);
-    // The negated line of the -kappa sample is in the OTHER fold state.  With the reference's float Pi
-    // (= pi (1 + 2.78e-8), EpipolarConsistencyCommon.hxx:155,159) the direct branch gives a = r (1 - e) and the
-    // folded one a = r (1 - e) + e for the same geometric line, e = 1 - pi / Pi: a constant offset of
-    // e * n_alpha bins between the two states (2.1e-5 bins at 768 -- the systematic shift DESIGN.md 2 is about).
-    const double Pi_f = (double)3.14159265359f, e = 1.0 - 3.14159265358979323846 / Pi_f;
-    const double delta = (fold0 ? -e : e) * g.n_alpha;
-    ca_out[N + 1] = (float)(ca[0] + delta - (double)ca_out[0]);
     return ok;
 }
 
-// Pair geometry and polynomial fit, TWO THREADS PER PAIR (ref for the geometry: kernelEpipolarConsistencyComputeK01,
+// Pair geometry and polynomial fit (ref for the geometry: kernelEpipolarConsistencyComputeK01,
 // ...RadonIntermediate.cu:13-67).  A wave of the pair kernel would spend ~900 vector instructions (float64 asin, ~25
 // IEEE divisions, get_ij) on the geometry per pair with all 64 lanes doing the same thing; here 64 pairs share those
 // instructions and the pair kernel picks the result up with scalar loads.  Unlike the reference there is no
 // device-wide sync in between, the two kernels are just ordered on the stream.
-// The kernel is bound by float64 issue (4 cycles per wave instruction, PMC: the vector ALU is busy 3/4 of the
-// time), i.e. by its instruction count: four threads per pair (one per view and coordinate, one role per wave) repeat
-// the geometry and the node sin/cos and were slower (30 vs 25 us); what pays is fewer instructions per point
-// (sincos_table / angle_table, explicit fma: 35 -> 25 us for 79 800 pairs).
+// FOUR threads per pair, one per (view, coordinate), arranged so that a wave has ONE role (no divergence between the
+// angle and the distance code): workgroup = 64 pairs; wave 0 / 1 = angle coordinate of view 0 / 1, wave 2 / 3 =
+// distance coordinate of view 0 / 1.  Every thread computes its view's half of K01 itself (cheaper than passing it
+// on).  A thread is a chain of dependent float64 operations, and a shard of the pair range at 8 GPUs is less than one
+// wave per SIMD -- the chain length is the kernel time there.  Measured: 79 800 pairs 35 us with float64 libm-style
+// series and divisions, 22 us with sincos_table / angle_table and explicit fma (both two threads per pair), 23 us
+// with four; a 9 975-pair shard (8 GPUs) 13 us with two threads per pair, 11 us with four.
+constexpr int K01_PAIRS = 64;
+
 __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 {
-    // two adjacent threads per pair: thread v handles view v
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long local = tid >> 1;
-    const int v = (int)(tid & 1);
+    constexpr int N = ECC_POLY_DEG + 1;
+    const int role = threadIdx.x >> 6, v = role & 1, slot = threadIdx.x & 63;
+    const bool angle_role = role < 2;
+    const long long local = (long long)blockIdx.x * K01_PAIRS + slot;
     const bool live = local < p.count;
     int iP0 = 0, iP1 = 0, iD0 = 0, iD1 = 0, ci = 0, cj = 0;
     if (live) {
@@ -629,56 +608,85 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
             iP1 = iD1 = cj;
         }
     }
-    // thread v computes its own view's half of K01: Kv[0..5] the line map, Kv[6..7] = (baseline distance, view angle)
-    // for view 0, (dkappa, kappa_max) for view 1 -- the layout of the reference's K01 array
+    // the thread's view's half of K01: Kv[0..5] the line map, Kv[6..7] = (baseline distance, view angle) for view 0,
+    // (dkappa, kappa_max) for view 1 -- the layout of the reference's K01 array
     float Kv[8], kappa_max = 0.f, dkappa = 0.f;
     for (int i = 0; i < 8; i++) Kv[i] = 0.f;
     if (live && iP0 != iP1) {
         float Kp[8], s2, s3, K06, K07;
         baseline_pencil(p.Cs + 4 * iP0, p.Cs + 4 * iP1, Kp, s2, s3);
         project_pencil(p.PinvTs + 12 * (v ? iP1 : iP0), Kp, p.n_x2, p.n_y2, Kv);
-        pencil_range(s2, s3, p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr, K06, K07, dkappa, kappa_max);
+        pencil_range(s2, s3, p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr && angle_role, K06, K07,
+                     dkappa, kappa_max);
         Kv[6] = v ? dkappa : K06;
         Kv[7] = v ? kappa_max : K07;
     }
-    unsigned fold = 0u;
-    float ca[ECC_POLY_DEG + 3], cd[ECC_POLY_DEG + 2];
-    for (int k = 0; k < ECC_POLY_DEG + 3; ++k) ca[k] = 0.f;
-    for (int k = 0; k < ECC_POLY_DEG + 2; ++k) cd[k] = 0.f;
+
+    // The records are assembled in LDS and leave the workgroup as one contiguous, coalesced block: written straight
+    // from the threads every store instruction would scatter its 64 lanes over 64 records 312 bytes apart.
+    __shared__ EccPairRecord recs[K01_PAIRS];
+    __shared__ int ok_flags[4][K01_PAIRS];
+    static_assert(sizeof(EccPairRecord) % 8 == 0, "record copied as 8-byte words");
+    EccPairRecord* r = &recs[slot];
+
+    double c[N];
+    bool fold0 = false;
     int ok = 0;
     if (live && p.poly && kappa_max > 0.f && dkappa > 0.f) {
         CurveGeom g;
-        g.theta_ref = angle_table(*p.poly, (double)Kv[0], (double)Kv[1]);
+        g.theta_ref = angle_role ? angle_table(*p.poly, (double)Kv[0], (double)Kv[1]) : 0.0;
         g.inv_range_t = 1.0 / (double)p.range_t;
         g.n_alpha = (double)p.n_alpha;
         g.n_t = (double)p.n_t;
         curve_geometry(Kv, g);
-        ok = fit_view_polynomials(*p.poly, g, (double)kappa_max, &fold, ca, cd) ? 1 : 0;
+        if (angle_role) ok = fit_coordinate<true>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;  // wave-uniform branch
+        else ok = fit_coordinate<false>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) c[k] = 0.0;
     }
-    ok &= __shfl_xor(ok, 1);  // both views of the pair (adjacent lanes; dead lanes carry 0 and have no live partner)
-    // The records are assembled in LDS and leave the workgroup as one contiguous, coalesced block: written straight
-    // from the threads every store instruction would scatter its 64 lanes over 32 records 312 bytes apart.
-    __shared__ EccPairRecord recs[128];
-    static_assert(sizeof(EccPairRecord) % 8 == 0, "record copied as 8-byte words");
-    EccPairRecord* r = &recs[threadIdx.x >> 1];
-    r->fold[v] = fold;
-    for (int k = 0; k < ECC_POLY_DEG + 3; ++k) r->ca[v][k] = ca[k];
-    for (int k = 0; k < ECC_POLY_DEG + 2; ++k) r->cd[v][k] = cd[k];
-    float* Kdst = v ? r->K1 : r->K0;
-    for (int i = 0; i < 8; i++) Kdst[i] = Kv[i];
-    if (live && p.K01_out)
-        for (int i = 0; i < 8; i++) p.K01_out[16 * local + 8 * v + i] = Kv[i];
-    if (v == 0) {
+    ok_flags[role][slot] = ok;
+    if (angle_role) {
+        r->fold[v] = fold0 ? 0x80000000u : 0u;
+#pragma unroll
+        for (int k = 0; k < N; ++k) r->ca[v][k] = (float)c[k];
+        const float c0 = (float)c[0];
+        r->ca[v][N] = (float)(c[0] - (double)c0);  // low part of the constant term
+        // The negated line of the -kappa sample is in the OTHER fold state.  With the reference's float Pi
+        // (= pi (1 + 2.78e-8), EpipolarConsistencyCommon.hxx:155,159) the direct branch gives a = r (1 - e) and the
+        // folded one a = r (1 - e) + e for the same geometric line, e = 1 - pi / Pi: a constant offset of
+        // e * n_alpha bins between the two states (2.1e-5 bins at 768 -- the systematic shift DESIGN.md 2 is about).
+        const double Pi_f = (double)3.14159265359f, e = 1.0 - 3.14159265358979323846 / Pi_f;
+        const double delta = (fold0 ? -e : e) * (double)p.n_alpha;
+        r->ca[v][N + 1] = (float)(c[0] + delta - (double)c0);
+        float* Kdst = v ? r->K1 : r->K0;
+        for (int i = 0; i < 8; i++) Kdst[i] = Kv[i];
+        if (live && p.K01_out)
+            for (int i = 0; i < 8; i++) p.K01_out[16 * local + 8 * v + i] = Kv[i];
+    }
+    __syncthreads();
+    if (!angle_role) {
+        if (r->fold[v]) {  // this view's fold, decided by the angle's thread: yd -> n_t + 1 - yd
+            c[0] = (double)p.n_t + 1.0 - c[0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) c[k] = -c[k];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) r->cd[v][k] = (float)c[k];
+        r->cd[v][N] = (float)(c[0] - (double)(float)c[0]);
+    }
+    if (role == 0) {
         r->iD0 = iD0;
         r->iD1 = iD1;
         r->ci = ci;
         r->cj = cj;
-        r->poly_ok = ok;
-        r->x_scale = ok ? (float)(1.0 / (double)kappa_max) : 0.f;
+        const int all_ok = ok_flags[0][slot] & ok_flags[1][slot] & ok_flags[2][slot] & ok_flags[3][slot];
+        r->poly_ok = all_ok;
+        r->x_scale = all_ok ? (float)(1.0 / (double)kappa_max) : 0.f;
     }
     __syncthreads();
-    const long long first_pair = (long long)blockIdx.x * 128;
-    const long long n_here = min((long long)128, p.count - first_pair);
+    const long long first_pair = (long long)blockIdx.x * K01_PAIRS;
+    const long long n_here = min((long long)K01_PAIRS, p.count - first_pair);
     if (n_here > 0) {
         const int words = (int)(n_here * (sizeof(EccPairRecord) / 8));
         const double* src = reinterpret_cast<const double*>(recs);
@@ -958,7 +966,7 @@ extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, f
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k01_kernel, dim3((unsigned)((2 * p->count + 255) / 256)), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(k01_kernel, dim3((unsigned)((p->count + K01_PAIRS - 1) / K01_PAIRS)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 
