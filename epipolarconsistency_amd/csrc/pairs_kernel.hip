@@ -284,16 +284,17 @@ __device__ __forceinline__ bool kappa_step(int k, const float (&K0)[8], const fl
 // Both coordinates' values at +x and -x from one polynomial each: even part E(z) and odd part O(z), z = x^2,
 // p(+x) = E + x O, p(-x) = E - x O.  The constant term goes in last, low part first: one rounding at the
 // coordinate's own magnitude, as on the exact path.
+template <int DEG>
 __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_minus, bool same_lo, float x, float z,
                                         float& plus, float& minus)
 {
-    static_assert(ECC_POLY_DEG % 2 == 0, "even degree");
+    static_assert(DEG % 2 == 0 && DEG >= 4 && DEG <= ECC_POLY_DEG, "even degree");
 #if defined(PK_EXP_CHEAP_POLY)  // timing experiment: degree-2 coordinates (wrong results; sample_at clamps them)
     float E = c[2], O = c[1];
 #else
-    float E = c[ECC_POLY_DEG], O = c[ECC_POLY_DEG - 1];
+    float E = c[DEG], O = c[DEG - 1];
 #pragma unroll
-    for (int k = ECC_POLY_DEG - 2; k >= 2; k -= 2) {
+    for (int k = DEG - 2; k >= 2; k -= 2) {
         E = fmaf(E, z, c[k]);
         O = fmaf(O, z, c[k - 1]);
     }
@@ -332,7 +333,9 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
 // across trips cannot be expressed: the compiler's wait-count insertion drains all loads at the loop header
 // (vmcnt(0) before the next stage's loads), and with the gathers in inline assembly it copies their destination
 // registers before the explicit wait.
-template <bool DERIV, bool CORR, int PITCH4>
+// DEG: the degree the record asks for -- the fit is of degree ECC_POLY_DEG, k01_kernel lowers it where Chebyshev
+// economisation costs less than 2e-8 bins (see economise).
+template <bool DERIV, bool CORR, int PITCH4, int DEG>
 __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
                                                 float kappa_max, float w06, const SlabView sv0, const SlabView sv1,
                                                 float n_t_f, float pitch4_f, double& acc, double& mom2, double& mom3,
@@ -345,6 +348,7 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         fold[v] = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->fold[v]);
 #pragma unroll
         for (int k = 0; k <= ECC_POLY_DEG + 1; ++k) {
+            if (k > DEG && k <= ECC_POLY_DEG) continue;  // dropped coefficients are not even loaded
             ca[v][k] = uniformf(rec->ca[v][k]);
             cd[v][k] = uniformf(rec->cd[v][k]);
         }
@@ -356,10 +360,10 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         if (kappa >= kappa_max) break;
         const float x = kappa * xs, z = x * x;
         float xa0p, xa0m, yd0p, yd0m, xa1p, xa1m, yd1p, yd1m;
-        poly_pm(ca[0], ca[0][ECC_POLY_DEG + 1], ca[0][ECC_POLY_DEG + 2], false, x, z, xa0p, xa0m);
-        poly_pm(cd[0], cd[0][ECC_POLY_DEG + 1], 0.f, true, x, z, yd0p, yd0m);
-        poly_pm(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa1p, xa1m);
-        poly_pm(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd1p, yd1m);
+        poly_pm<DEG>(ca[0], ca[0][ECC_POLY_DEG + 1], ca[0][ECC_POLY_DEG + 2], false, x, z, xa0p, xa0m);
+        poly_pm<DEG>(cd[0], cd[0][ECC_POLY_DEG + 1], 0.f, true, x, z, yd0p, yd0m);
+        poly_pm<DEG>(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa1p, xa1m);
+        poly_pm<DEG>(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd1p, yd1m);
         const float v0p = sample_at<DERIV, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f);
         const float v1p = sample_at<DERIV, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f);
         const float v0m = sample_at<DERIV, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f);
@@ -576,6 +580,41 @@ __device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, doubl
     return ok;
 }
 
+// Chebyshev economisation of the fitted polynomial: x^n = (T_n(x) + lower powers) / 2^(n-1) on [-1, 1], so the two top
+// monomials can be folded into the lower ones at an error of at most |c_n| / 2^(n-1) + |c_(n-1)| / 2^(n-2) -- two to
+// three orders of magnitude less than dropping them.  Lowers the degree two at a time while the accumulated bound
+// stays below 2e-8 bins and returns the degree the pair kernel has to evaluate (10, 8, 6 or 4); c is updated.
+__device__ __forceinline__ int economise(double* c)
+{
+    static_assert(ECC_POLY_DEG == 10, "degree classes 4 / 6 / 8 / 10");
+    const double tol = 2e-8;
+    double err = fabs(c[10]) * (1.0 / 512.0) + fabs(c[9]) * (1.0 / 256.0);
+    if (!(err <= tol)) return 10;
+    {   // T10 = 512x^10 - 1280x^8 + 1120x^6 - 400x^4 + 50x^2 - 1,  T9 = 256x^9 - 576x^7 + 432x^5 - 120x^3 + 9x
+        const double a = c[10] * (1.0 / 512.0), b = c[9] * (1.0 / 256.0);
+        c[8] = fma(a, 1280.0, c[8]); c[6] = fma(a, -1120.0, c[6]); c[4] = fma(a, 400.0, c[4]); c[2] = fma(a, -50.0, c[2]); c[0] += a;
+        c[7] = fma(b, 576.0, c[7]); c[5] = fma(b, -432.0, c[5]); c[3] = fma(b, 120.0, c[3]); c[1] = fma(b, -9.0, c[1]);
+        c[10] = c[9] = 0.0;
+    }
+    err += fabs(c[8]) * (1.0 / 128.0) + fabs(c[7]) * (1.0 / 64.0);
+    if (!(err <= tol)) return 8;
+    {   // T8 = 128x^8 - 256x^6 + 160x^4 - 32x^2 + 1,  T7 = 64x^7 - 112x^5 + 56x^3 - 7x
+        const double a = c[8] * (1.0 / 128.0), b = c[7] * (1.0 / 64.0);
+        c[6] = fma(a, 256.0, c[6]); c[4] = fma(a, -160.0, c[4]); c[2] = fma(a, 32.0, c[2]); c[0] -= a;
+        c[5] = fma(b, 112.0, c[5]); c[3] = fma(b, -56.0, c[3]); c[1] = fma(b, 7.0, c[1]);
+        c[8] = c[7] = 0.0;
+    }
+    err += fabs(c[6]) * (1.0 / 32.0) + fabs(c[5]) * (1.0 / 16.0);
+    if (!(err <= tol)) return 6;
+    {   // T6 = 32x^6 - 48x^4 + 18x^2 - 1,  T5 = 16x^5 - 20x^3 + 5x
+        const double a = c[6] * (1.0 / 32.0), b = c[5] * (1.0 / 16.0);
+        c[4] = fma(a, 48.0, c[4]); c[2] = fma(a, -18.0, c[2]); c[0] += a;
+        c[3] = fma(b, 20.0, c[3]); c[1] = fma(b, -5.0, c[1]);
+        c[6] = c[5] = 0.0;
+    }
+    return 4;
+}
+
 // Pair geometry and polynomial fit (ref for the geometry: kernelEpipolarConsistencyComputeK01,
 // ...RadonIntermediate.cu:13-67).  A wave of the pair kernel would spend ~900 vector instructions (float64 asin, ~25
 // IEEE divisions, get_ij) on the geometry per pair with all 64 lanes doing the same thing; here 64 pairs share those
@@ -645,6 +684,11 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 #pragma unroll
         for (int k = 0; k < N; ++k) c[k] = 0.0;
     }
+#if defined(PK_EXP_NO_ECONOMISE)
+    if (ok) ok = ECC_POLY_DEG;
+#else
+    if (ok) ok = economise(c);
+#endif
     ok_flags[role][slot] = ok;
     if (angle_role) {
         r->fold[v] = fold0 ? 0x80000000u : 0u;
@@ -680,9 +724,10 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
         r->iD1 = iD1;
         r->ci = ci;
         r->cj = cj;
-        const int all_ok = ok_flags[0][slot] & ok_flags[1][slot] & ok_flags[2][slot] & ok_flags[3][slot];
-        r->poly_ok = all_ok;
-        r->x_scale = all_ok ? (float)(1.0 / (double)kappa_max) : 0.f;
+        const int d0 = ok_flags[0][slot], d1 = ok_flags[1][slot], d2 = ok_flags[2][slot], d3 = ok_flags[3][slot];
+        const int degree = (d0 && d1 && d2 && d3) ? max(max(d0, d1), max(d2, d3)) : 0;
+        r->poly_ok = degree;
+        r->x_scale = degree ? (float)(1.0 / (double)kappa_max) : 0.f;
     }
     __syncthreads();
     const long long first_pair = (long long)blockIdx.x * K01_PAIRS;
@@ -742,12 +787,18 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
     const int poly_ok = __builtin_amdgcn_readfirstlane(rec->poly_ok);
     if (poly_ok) {
-        if (pitch4 == 6400u)
-            kappa_loop_poly<DERIV, CORR, 6400>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc,
-                                               mom2, mom3, mom4);
-        else
-            kappa_loop_poly<DERIV, CORR, 0>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2,
-                                            mom3, mom4);
+#define ECC_POLY_LOOP(P4, DEG) \
+    kappa_loop_poly<DERIV, CORR, P4, DEG>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4)
+        if (pitch4 == 6400u) {
+            if (poly_ok <= 4) ECC_POLY_LOOP(6400, 4);
+            else if (poly_ok <= 6) ECC_POLY_LOOP(6400, 6);
+            else if (poly_ok <= 8) ECC_POLY_LOOP(6400, 8);
+            else ECC_POLY_LOOP(6400, ECC_POLY_DEG);
+        } else {
+            if (poly_ok <= 6) ECC_POLY_LOOP(0, 6);
+            else ECC_POLY_LOOP(0, ECC_POLY_DEG);
+        }
+#undef ECC_POLY_LOOP
     } else if (pitch4 == 6400u) {  // 768 distance bins, the reference's default (Gui/ComputeRadonIntermediate.hxx:43-44)
         if (reduce)
             kappa_loop<DERIV, CORR, true, 6400>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,

@@ -255,7 +255,10 @@ def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
         x = kap * r["x_scale"]
         for v in (0, 1):
             Kv = K[8 * v:8 * v + 8]
-            ca, cd = r["ca"][v], r["cd"][v]
+            ca, cd = r["ca"][v].copy(), r["cd"][v].copy()
+            assert r["degree"] in (4, 6, 8, 10)
+            # the pair kernel evaluates up to `degree`: the economised coefficients above it are zero
+            assert not ca[r["degree"] + 1:11].any() and not cd[r["degree"] + 1:11].any()
             for sgn in (1, -1):
                 # the reference's -kappa sample is the line of (-cos, sin): the negated line of plane -kappa
                 Ks = Kv.copy().astype(np.float64)
