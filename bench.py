@@ -89,6 +89,7 @@ def main():
     Ps = synthetic.short_scan(n, S, S, pixel_mm)
     phantom = synthetic.sphere_phantom()
 
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # a stream of our own, not the legacy default stream
     stream = torch.cuda.current_stream()
     ctx = E.Context(local_rank, stream=stream.cuda_stream)
     ctx.enable_timing(True)  # Radon / pre-processing kernel times below

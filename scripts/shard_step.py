@@ -13,6 +13,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 n, S, B = 400, 1024, 768
 Ps = synthetic.short_scan(n, S, S, 0.308)
 dev = torch.device("cuda", 0)
+torch.cuda.set_stream(torch.cuda.Stream(dev))
 ctx = E.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 slabs = torch.zeros((n, E.slab_floats(B, B)), dtype=torch.float32, device=dev)
 ph = synthetic.sphere_phantom()
