@@ -36,8 +36,11 @@ __device__ unsigned long long g_radon_stats[8];
 
 namespace {
 
-constexpr int RT_T = 16;                   // distance bins per workgroup (tid & 15)
-constexpr int RT_A = 16;                   // angle bins per workgroup    (tid >> 4)
+#ifndef RT_DIST_BINS
+#define RT_DIST_BINS 16
+#endif
+constexpr int RT_T = RT_DIST_BINS;         // distance bins per workgroup (tid % RT_T)
+constexpr int RT_A = 256 / RT_DIST_BINS;   // angle bins per workgroup    (tid / RT_T)
 constexpr int RT_THREADS = RT_T * RT_A;    // 256
 // Tile shape: 96 x 96 floats (37 KB, 4 workgroups per CU) measured best; -DRT_TILE_W/H only for experiments
 // (scripts/radon_variants.sh: 64x64 0.97 ms, 96x80 0.79 ms, 96x96 0.76 ms per 1024^2 image).
