@@ -751,6 +751,9 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     // serialises hits on lines whose fill is still in flight (TCP_PENDING_STALL_CYCLES: a quarter of its busy time)
     // -- 0.400 -> 0.335 ms for 79 800 pairs; spreading further (other strides, 2-D tiles of views that halve the HBM
     // traffic) was slower, see DESIGN.md 4.2.
+    // (Several waves per pair for small shards -- wave h takes the kappa iterations it % split == h, float64 partial
+    // sums combined by the sum kernel -- were measured and dropped: a 9 975-pair shard 80 us per step with whole-pair
+    // waves, 89 us with two, 106 us with four waves per pair.)
     const long long nblk = (p.count + 3) / 4;
     const long long per_xcd = (nblk + 7) / 8;
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
