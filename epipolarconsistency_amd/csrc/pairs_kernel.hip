@@ -754,6 +754,8 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     // (Several waves per pair for small shards -- wave h takes the kappa iterations it % split == h, float64 partial
     // sums combined by the sum kernel -- were measured and dropped: a 9 975-pair shard 80 us per step with whole-pair
     // waves, 89 us with two, 106 us with four waves per pair.)
+    // (Persistent waves -- a launch sized to be resident at once, every wave handling several pairs in turn -- were
+    // measured too: 79 800 pairs 0.38 / 0.43 ms with 5 / 10 pairs per wave against 0.33 ms, the shard 86 us with two.)
     const long long nblk = (p.count + 3) / 4;
     const long long per_xcd = (nblk + 7) / 8;
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
