@@ -1,0 +1,90 @@
+"""BASELINE.json's full configuration (400 views, 1024x1024, 768x768 bins, 79 800 pairs, N_kappa = 1448) through
+the C ABI: size-independent properties of the metric, plus a bounded oracle check on a random sample of pairs.
+The whole-problem comparison against the oracle is in test_gpu_parity.py (every 4th view) and in bench.py (all pairs,
+`parity_rel_err_vs_oracle_on_sample`)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, S, B = 400, 1024, 768
+
+
+@pytest.fixture(scope="module")
+def full_scan(gpu_ctx):
+    import torch
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    Ps = synthetic.short_scan(N, S, S, 0.308)
+    dev = torch.device("cuda", 0)
+    slabs = torch.zeros((N, E.slab_floats(B, B)), dtype=torch.float32, device=dev)
+    phantom = synthetic.sphere_phantom()
+    for a in range(0, N, 50):
+        imgs = synthetic.projections_torch(Ps[a:a + 50], S, S, phantom, dev)
+        torch.cuda.synchronize()
+        keep = E.RadonIntermediate.compute_into(gpu_ctx, imgs, slabs[a:a + 50], B, B)
+        gpu_ctx.synchronize()
+        del keep, imgs
+    dtrs = [E.RadonIntermediate.wrap_device(gpu_ctx, slabs[k], B, B, S, S) for k in range(N)]
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    yield dict(Ps=Ps, dtrs=dtrs, metric=m, slabs=slabs)
+    m.close()
+
+
+def test_shards_cost_image_and_determinism(full_scan):
+    """Sum of 8 range shards == all-pairs sum; the cost image holds the pair values at index i + j*n; a second
+    evaluation returns the same bits; perturbing one view and restoring it restores the value exactly."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import geometry, sharding
+    m, Ps = full_scan["metric"], full_scan["Ps"]
+    n_pairs = N * (N - 1) // 2
+    cost = np.full((N, N), -1.0, np.float32)
+    mean = m.evaluate(cost)
+    assert mean > 0 and np.isfinite(mean)
+    assert m.evaluate() == mean
+    total, vals = m.evaluate_range(0, n_pairs, want_pairs=True)
+    assert total / n_pairs == mean
+    parts = [m.evaluate_range(*sharding.pair_range(r, 8, n_pairs)) for r in range(8)]
+    assert abs(sum(parts) - total) <= 1e-12 * total
+    # cost image: entry [j, i] for i < j, everything else untouched (ref: ...RadonIntermediate.cu:250,269)
+    iu = np.triu_indices(N, 1)  # (i, j) with i < j in get_ij order
+    assert np.array_equal(cost[iu[1], iu[0]], vals)
+    assert np.all(cost[iu] == -1.0) and np.all(np.diag(cost) == -1.0)
+    assert E.get_ij(n_pairs - 1, N) == (N - 2, N - 1)
+    # one view moved: the value changes; moved back: the same bits again
+    moved = list(Ps)
+    moved[200] = Ps[200] @ geometry.rigid_transform(tx=2.0, rz=0.01)
+    m.setProjectionMatrices(moved)
+    assert abs(m.evaluate() - mean) > 1e-6 * mean
+    m.setProjectionMatrices(Ps)
+    assert m.evaluate() == mean
+
+
+def test_random_pairs_against_oracle(full_scan, oracle_mod):
+    """300 random pairs at full size: index-list evaluation vs the oracle on read-back dtrs (mean within 1e-5,
+    single pairs within the fp32 noise floor of this size), and the metric's symmetry under swapping the views."""
+    m, Ps, dtrs = full_scan["metric"], full_scan["Ps"], full_scan["dtrs"]
+    rng = np.random.default_rng(11)
+    pairs = np.array([sorted(rng.choice(N, 2, replace=False)) for _ in range(300)], np.int32)
+    idx = np.stack([pairs[:, 0], pairs[:, 1], pairs[:, 0], pairs[:, 1]], 1).astype(np.int32)
+    out = np.empty(len(idx), np.float32)
+    mean = m.evaluate(idx, out)
+    used = sorted(set(pairs.ravel().tolist()))
+    host = {v: dtrs[v].readback() for v in used}
+    remap = {v: k for k, v in enumerate(used)}
+    idx_o = np.array([[remap[a], remap[b], remap[a], remap[b]] for a, b in pairs], np.int32)
+    want = oracle_mod.evaluate_pairs([Ps[v] for v in used], [host[v] for v in used], S, S, idx_o)
+    assert abs(mean - want["mean"]) <= 1e-5 * want["mean"], (mean, want["mean"])
+    np.testing.assert_allclose(out, want["pairs"], rtol=2e-3)
+    # swapped views: the same pair with the roles of view 0 and view 1 exchanged
+    swapped = idx[:, [1, 0, 3, 2]].copy()
+    out_s = np.empty(len(idx), np.float32)
+    mean_s = m.evaluate(swapped, out_s)
+    assert abs(mean_s - mean) <= 1e-5 * mean
+    np.testing.assert_allclose(out_s, out, rtol=2e-3)
+    # subset semantics: all pairs among a set of views == the cost-image entries of those pairs
+    views = sorted(int(v) for v in rng.choice(N, 12, replace=False))
+    cost = np.zeros((N, N), np.float32)
+    m.evaluate(cost)
+    entries = [cost[b, a] for k, a in enumerate(views) for b in views[k + 1:]]
+    assert abs(m.evaluate(set(views)) - float(np.mean(np.asarray(entries, np.float64)))) <= 2e-6 * np.mean(entries)
