@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+ENGINE_CLOCK_GHZ = 2.4  # MI355X peak engine clock (same guide); the pair kernel runs at ~2.1 GHz
 
 
 def parse():
@@ -238,6 +239,13 @@ def main():
         "kappa_samples_per_s": n_pairs * n_kappa * args.steps / elapsed,
         "last_value": last,
     }
+
+    # The gather is served on chip (traffic << algorithmic bytes), so the bandwidth that actually bounds the kernel is
+    # the L1's: 64 B/clk/CU (scripts/micro/gather_rate.hip); every algorithmic byte passes through it exactly once.
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    l1_peak = 64.0 * n_cu * ENGINE_CLOCK_GHZ  # GB/s
+    out["roofline"]["l1"] = {"achieved": achieved, "peak": l1_peak, "unit": "GB/s", "frac": achieved / l1_peak,
+                             "note": "64 B/clk/CU x %d CUs x %.1f GHz peak engine clock" % (n_cu, ENGINE_CLOCK_GHZ)}
 
     # measured HBM traffic per launch (rocprofv3 PMC pass, committed under profiles/), if it matches
     tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
