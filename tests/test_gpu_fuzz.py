@@ -1,0 +1,19 @@
+"""Randomised parity sweep as a test: 60 random geometries / bin grids / parameters (scripts/fuzz_parity.py) through
+the C ABI against the oracle -- mean within 1e-5 (relaxed by 30/sqrt(n_pairs) for tiny problems, whose per-pair fp32
+noise does not average out), pair values within 2e-3."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_randomised_parity_sweep():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "60", "11"],
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 of 60 cases out of tolerance" in r.stdout
