@@ -346,7 +346,8 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
         else {
             result = (sum - sumo) * RADON_STEP;  // ref: RadonIntermediate.cu:125-140
             if (p.post_process == 1) result = result < 0 ? -sqrtf(-result) : sqrtf(result);
-            else if (p.post_process == 2) result = result < 0 ? -logf(-result + 1) : logf(result + 1);
+            // logarithm correctly rounded (binary64, rounded once) like the oracle's: once per bin
+            else if (p.post_process == 2) result = result < 0 ? -(float)log((double)(-result + 1)) : (float)log((double)(result + 1));
         }
         float* out = p.out + (int64_t)blockIdx.z * p.out_stride;
         out[(size_t)(ix + 1) * p.pitch + (iy + 1)] = result;

@@ -51,6 +51,7 @@ ECCOR_API void eccor_set_use_corr(int v) { g_use_corr = v; }
 static float or_sinf(float x) { return g_variant == 2 ? sinf(x) : (float)sin((double)x); }
 static float or_cosf(float x) { return g_variant == 2 ? cosf(x) : (float)cos((double)x); }
 static float or_atan2f(float y, float x) { return g_variant == 2 ? atan2f(y, x) : (float)atan2((double)y, (double)x); }
+static float or_logf(float x) { return g_variant == 2 ? logf(x) : (float)log((double)x); }
 static float or_asinf(float x) { return g_variant == 2 ? asinf(x) : (float)asin((double)x); }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -425,7 +426,7 @@ static float or_radon_bin(const float *img, int W, int H, int n_alpha, int n_t, 
         if (fetches) *fetches += nf;
         result = (sum - sumo) * step;
         if (post == 1) return result < 0 ? -sqrtf(-result) : sqrtf(result);
-        if (post == 2) return result < 0 ? -logf(-result + 1) : logf(result + 1);
+        if (post == 2) return result < 0 ? -or_logf(-result + 1) : or_logf(result + 1);  /* correctly rounded, like every elementary function here */
         return result;
     }
 }

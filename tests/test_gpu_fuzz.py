@@ -17,3 +17,12 @@ def test_randomised_parity_sweep():
                        capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "0 of 60 cases out of tolerance" in r.stdout
+
+
+@pytest.mark.timeout(600)
+def test_randomised_radon_sweep():
+    """60 random image sizes / bin grids / filters / post-processes / contents (scripts/fuzz_radon.py): bit-exact."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_radon.py"), "60", "9"],
+                       capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 of 60 cases differ" in r.stdout
