@@ -79,6 +79,43 @@ for c in range(cases):
             print("   pair (%d,%d): hip %.7g oracle %.7g  baseline distance %.4g mm, kappa_max %.5f, dkappa %.3g, degree %d"
                   % (i, j, got[q], ref[q], K01[np.flatnonzero(ok_pairs)[q]][6], K01[np.flatnonzero(ok_pairs)[q]][15],
                      K01[np.flatnonzero(ok_pairs)[q]][14], degs[np.flatnonzero(ok_pairs)[q]]))
+    # explicit index tuples with cross-assigned projection matrices / dtrs and reversed pairs (E3'), the cost image
+    # of evaluate(), and the correlation form (E6; 1 - cc cancels two numbers near 1: absolute tolerance)
+    if n >= 3:
+        k = int(rng.integers(1, 9))
+        idx = np.stack([rng.integers(0, n, k), rng.integers(0, n, k), rng.integers(0, n, k), rng.integers(0, n, k)], 1)
+        idx = idx[(idx[:, 0] != idx[:, 1])].astype(np.int32)
+        far = [np.linalg.norm(Cs[a] - Cs[b]) >= 1e-4 * np.linalg.norm(Cs[a]) for a, b in idx[:, :2]]
+        idx = idx[np.asarray(far, bool)] if len(idx) else idx
+        if len(idx):
+            out = np.zeros(len(idx), np.float32)
+            m.evaluate(idx, out)
+            w = oracle.evaluate_pairs(Ps, dtrs_h, n_u, n_v, idx, object_radius_mm=radius, dkappa=dkappa, is_derivative=derivative)
+            fin = np.isfinite(w["pairs"])
+            sc = np.maximum(np.abs(w["pairs"][fin]), 1e-3 * np.abs(ref).max() if ref.size else 1.0)
+            r_idx = float(np.max(np.abs(out[fin] - w["pairs"][fin]) / sc)) if fin.any() else 0.0
+            if r_idx > 2e-3:
+                bad += 1
+                flag += "  <-- INDEX LIST OUT OF TOLERANCE (%.2e)" % r_idx
+        cost = np.full((n, n), -7.0, np.float32)
+        m.evaluate(cost)
+        iu = np.triu_indices(n, 1)
+        if not (np.array_equal(cost[iu[1], iu[0]], vals, equal_nan=True) and np.all(cost[iu] == -7.0)):
+            bad += 1
+            flag += "  <-- COST IMAGE DIFFERS FROM THE PAIR VALUES"
+        if ok_pairs.all() and rng.integers(0, 3) == 0:
+            m.useCorrelation(True)
+            oracle.set_use_corr(1)
+            try:
+                wc = oracle.evaluate_all(Ps, dtrs_h, n_u, n_v, object_radius_mm=radius, dkappa=dkappa, is_derivative=derivative)
+            finally:
+                oracle.set_use_corr(0)
+            _, vc = m.evaluate_range(0, n_pairs, want_pairs=True)
+            m.useCorrelation(False)
+            d_cc = float(np.nanmax(np.abs(vc - wc["pairs"]) / np.maximum(np.abs(wc["pairs"]), 1e-2)))
+            if not d_cc < 2e-3:
+                bad += 1
+                flag += "  <-- CORRELATION FORM OFF BY %.2e" % d_cc
     worst_mean, worst_pair = max(worst_mean, rel_mean), max(worst_pair, rel_pair)
     print("case %2d: n=%2d %3dx%3d bins %3dx%3d kind %d span %3.0f deriv %d r=%5.1f dk=%.3f | mean %.2e pair %.2e | "
           "degrees %s%s" % (c, n, n_u, n_v, n_alpha, n_t, kind, span, derivative, radius, dkappa, rel_mean, rel_pair,
