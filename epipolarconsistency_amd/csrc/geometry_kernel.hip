@@ -12,26 +12,34 @@
 #include "ecc_host_geometry.h"
 
 namespace {
-__global__ __launch_bounds__(64) void e1_kernel(const double* __restrict__ Ps, int n, float* __restrict__ PinvTs,
-                                                float* __restrict__ Cs)
+// Two threads per view, one role per wave (no divergence): wave 0 of a workgroup computes (P^+)^T of 64 views, wave 1
+// their source positions -- the two float64 Householder chains are independent and the kernel is pure latency (400
+// views = a handful of waves), so splitting them shortens it (8 -> 6 us).
+__global__ __launch_bounds__(128) void e1_kernel(const double* __restrict__ Ps, int n, float* __restrict__ PinvTs,
+                                                 float* __restrict__ Cs)
 {
-    int v = blockIdx.x * blockDim.x + threadIdx.x;
+    const int role = threadIdx.x >> 6;
+    const int v = blockIdx.x * 64 + (threadIdx.x & 63);
     if (v >= n) return;
     double P[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = Ps[12 * (size_t)v + k];
-    float pinvT[12], C[4];
-    ecc_host::pinv_transpose(P, pinvT);
-    ecc_host::source_position(P, C);
+    if (role == 0) {
+        float pinvT[12];
+        ecc_host::pinv_transpose(P, pinvT);
 #pragma unroll
-    for (int k = 0; k < 12; ++k) PinvTs[12 * (size_t)v + k] = pinvT[k];
+        for (int k = 0; k < 12; ++k) PinvTs[12 * (size_t)v + k] = pinvT[k];
+    } else {
+        float C[4];
+        ecc_host::source_position(P, C);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Cs[4 * (size_t)v + k] = C[k];
+        for (int k = 0; k < 4; ++k) Cs[4 * (size_t)v + k] = C[k];
+    }
 }
 }  // namespace
 
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream)
 {
-    hipLaunchKernelGGL(e1_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, Ps_d, n, PinvTs_d, Cs_d);
+    hipLaunchKernelGGL(e1_kernel, dim3((n + 63) / 64), dim3(128), 0, stream, Ps_d, n, PinvTs_d, Cs_d);
     return hipGetLastError();
 }
