@@ -102,3 +102,33 @@ def exchanged_evaluate(metric, n_views, exchange):
     n_pairs = n_views * (n_views - 1) // 2
     first, count = pair_range(exchange.rank, exchange.world, n_pairs)
     return exchange.sum(metric.evaluate_range(first, count)) / n_pairs
+
+
+def gather_cost_image(pair_values, n_views, rank, world, group=None, cost=None):
+    """The n x n cost image of a sharded evaluation ("when the caller wants the cost image, a gather of
+    each rank's pair values"): every rank passes the float32 values of its pair_range shard (evaluate_range(...,
+    want_pairs=True)), every rank gets the image back -- entry [j, i] = index i + j*n for i < j, other entries of
+    `cost` untouched, like evaluate(cost) on one GPU.  Uses the process group (RCCL or gloo); not on the
+    per-evaluation critical path of an optimiser, which only needs the scalar."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    n_pairs = n_views * (n_views - 1) // 2
+    if cost is None:
+        cost = np.zeros((n_views, n_views), np.float32)
+    counts = [pair_range(r, world, n_pairs)[1] for r in range(world)]
+    mine = torch.zeros(max(counts), dtype=torch.float32)
+    mine[:counts[rank]] = torch.from_numpy(np.ascontiguousarray(pair_values, np.float32))
+    if world > 1 and dist.is_initialized():
+        on_gpu = dist.get_backend(group) == "nccl"
+        if on_gpu:
+            mine = mine.cuda()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        parts = [p.cpu() for p in parts]
+    else:
+        parts = [mine]
+    vals = np.concatenate([parts[r][:counts[r]].numpy() for r in range(len(parts))])
+    iu = np.triu_indices(n_views, 1)  # (i, j), i < j, in get_ij order
+    cost[iu[1], iu[0]] = vals
+    return cost

@@ -28,7 +28,8 @@ def _worker(rank, world, port, pairs, n_views, out_q):
     first, count = sharding.pair_range(rank, world, n_pairs)
     part = torch.tensor([float(np.sum(pairs[first:first + count].astype(np.float64)))], dtype=torch.float64)
     mean = sharding.allreduce_mean(part, n_pairs)
-    out_q.put((rank, first, count, mean))
+    cost = sharding.gather_cost_image(pairs[first:first + count], n_views, rank, world)
+    out_q.put((rank, first, count, mean, cost))
     dist.destroy_process_group()
 
 
@@ -55,13 +56,14 @@ def test_two_rank_allreduce_mean(oracle_mod, small_scan):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ref["pairs"], 8, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=100) for _ in procs)
+    res = sorted((q.get(timeout=100) for _ in procs), key=lambda r: r[0])
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
     assert res[0][1:3] == (0, 14) and res[1][1:3] == (14, 14)
-    for _, _, _, mean in res:
+    for _, _, _, mean, cost in res:
         assert abs(mean - ref["mean"]) <= 1e-12 * abs(ref["mean"])
+        assert np.array_equal(cost, ref["cost"])  # the gathered cost image of the shards == the single-process one
 
 
 # ---- host-side exchange of the partial sums (ecc_exchange_* of the C ABI; no device involved) --------------------
