@@ -39,9 +39,14 @@ namespace {
 #ifndef RT_DIST_BINS
 #define RT_DIST_BINS 16
 #endif
-constexpr int RT_T = RT_DIST_BINS;         // distance bins per workgroup (tid % RT_T)
-constexpr int RT_A = 256 / RT_DIST_BINS;   // angle bins per workgroup    (tid / RT_T)
-constexpr int RT_THREADS = RT_T * RT_A;    // 256
+#ifndef RT_WG_THREADS
+#define RT_WG_THREADS 256
+#endif
+constexpr int RT_T = RT_DIST_BINS;                  // distance bins per workgroup (tid % RT_T)
+constexpr int RT_A = RT_WG_THREADS / RT_DIST_BINS;  // angle bins per workgroup    (tid / RT_T)
+constexpr int RT_THREADS = RT_T * RT_A;             // 256 (512 only in experiments)
+constexpr int RT_WAVES = RT_THREADS / 64;
+constexpr int RT_STAGE_ROWS = RT_THREADS / 32;      // tile rows staged per pass (32 texels per row segment)
 // Tile shape: 96 x 96 floats (37 KB, 4 workgroups per CU) measured best; -DRT_TILE_W/H only for experiments
 // (scripts/radon_variants.sh: 64x64 0.97 ms, 96x80 0.79 ms, 96x96 0.76 ms per 1024^2 image).
 #ifndef RT_TILE_W
@@ -104,10 +109,10 @@ __device__ __forceinline__ float wave_max_f(float v)
 
 struct RadonShared {
     float tile[TILE_S_MAX * TILE_H];
-    int box[4][4];    // per wave: min x, min y, max x, max y
-    float u[4][2];    // per wave: min/max of the along-line coordinate
+    int box[RT_WAVES][4];    // per wave: min x, min y, max x, max y
+    float u[RT_WAVES][2];    // per wave: min/max of the along-line coordinate
     float geo[6];
-    int pend[4];
+    int pend[RT_WAVES];
 };
 
 // TILE_S is the LDS row stride.  A half-wave is 16 adjacent distance bins x 2 adjacent angles, i.e.
@@ -189,8 +194,12 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
         }
     }
     __syncthreads();
-    const float U0 = fminf(fminf(s_u[0][0], s_u[1][0]), fminf(s_u[2][0], s_u[3][0]));
-    const float U1 = fmaxf(fmaxf(s_u[0][1], s_u[1][1]), fmaxf(s_u[2][1], s_u[3][1]));
+    float U0 = s_u[0][0], U1 = s_u[0][1];
+#pragma unroll
+    for (int q = 1; q < RT_WAVES; ++q) {
+        U0 = fminf(U0, s_u[q][0]);
+        U1 = fmaxf(U1, s_u[q][1]);
+    }
     if (tid == 0) {
         // Geometry of this workgroup's band for the chunk-length rule below (uniform via LDS).
         const float Pi = 3.14159265359f;
@@ -266,10 +275,14 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
                 s_pend[wave] = pend != 0ull;
             }
             __syncthreads();  // (A) boxes visible; every thread has left the previous chunk's tile
-            bx0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
-            by0 = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
-            bx1 = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
-            by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+            bx0 = s_box[0][0], by0 = s_box[0][1], bx1 = s_box[0][2], by1 = s_box[0][3];
+#pragma unroll
+            for (int q = 1; q < RT_WAVES; ++q) {
+                bx0 = min(bx0, s_box[q][0]);
+                by0 = min(by0, s_box[q][1]);
+                bx1 = max(bx1, s_box[q][2]);
+                by1 = max(by1, s_box[q][3]);
+            }
             any = bx1 >= bx0;
             w = bx1 - bx0 + 1, h = by1 - by0 + 1;
             fits = any && w <= (TILE_S < TILE_W ? TILE_S : TILE_W) && h <= TILE_H;
@@ -277,17 +290,20 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
             L *= 0.5f;
             __syncthreads();  // everyone has read s_box before it is rewritten
         }
-        if (!(s_pend[0] | s_pend[1] | s_pend[2] | s_pend[3])) break;  // uniform: all lines done
+        int any_pending = 0;
+#pragma unroll
+        for (int q = 0; q < RT_WAVES; ++q) any_pending |= s_pend[q];
+        if (!any_pending) break;  // uniform: all lines done
         if (tid == 0) { RSTAT(0, 1); RSTAT(1, fits ? 1 : 0); RSTAT(2, any ? 1 : 0); RSTAT(5, w > 0 ? w : 0); RSTAT(6, h > 0 ? h : 0); }
         if (fits) {
             // Stage the footprint: all of a thread's (up to 36) global loads are issued before the first
             // LDS store so their latencies overlap (a load -> store loop serialises one L2 round trip per
             // element).  Rows by wave-quarter, 32 consecutive texels per half-wave = one 128-B segment.
             const int cx = tid & 31, ry = tid >> 5;
-            float stage[(TILE_H / 8) * (TILE_W / 32)];
+            float stage[(TILE_H / RT_STAGE_ROWS) * (TILE_W / 32)];
 #pragma unroll
-            for (int q = 0; q < TILE_H / 8; ++q) {
-                const int r = ry + 8 * q;
+            for (int q = 0; q < TILE_H / RT_STAGE_ROWS; ++q) {
+                const int r = ry + RT_STAGE_ROWS * q;
                 const int gy = min(max(by0 + r, 0), H - 1);
                 const float* __restrict__ row = img + (size_t)gy * W;
 #pragma unroll
@@ -298,8 +314,8 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
                 }
             }
 #pragma unroll
-            for (int q = 0; q < TILE_H / 8; ++q) {
-                const int r = ry + 8 * q;
+            for (int q = 0; q < TILE_H / RT_STAGE_ROWS; ++q) {
+                const int r = ry + RT_STAGE_ROWS * q;
 #pragma unroll
                 for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
                     const int c = cx + 32 * c3;
