@@ -10,6 +10,8 @@ container that has /root/reference):
                         values, mean, K01s and per-dtr checksums.
 
   example_pair_256_rows.npz  the rows of SURVEY.md 8(f) on the example pair (see widened_rows()).
+  variants_128.npz      SURVEY.md 8c (a) and (d): every Radon filter / post-process on one 128x96 image at 96x80
+                        bins; index-list, subset and user-parameter variants of the metric on the 8-view set.
 
 The reference has no golden vectors for this path: these pin the ORACLE against
 regressions and travel to the GPU box, where /root/reference does not exist.
@@ -100,8 +102,37 @@ def widened_rows():
     print("widened rows: e7 %.9g corr %.9g direct %.9g fbcc %.9g" % (e7["ecc"], corr, d["metric"], f["metric"]))
 
 
+def variants():
+    """variants_128.npz: SURVEY.md 8c fixtures (a) and (d): one 128x96 synthetic image and its dtr at 96x80 bins for
+    every filter / post-process the Radon kernel has, and the index-list / subset / user-parameter variants of the
+    metric on the 8-view set."""
+    from conftest import make_small_scan
+    Ps, imgs = make_small_scan()
+    img = np.ascontiguousarray(imgs[3][16:112, :], np.float32)  # 96 rows x 128 columns
+    rng = np.random.default_rng(5)
+    bins = rng.integers(0, 96 * 80, size=256).astype(np.int32)
+    radon = {}
+    for name, (f, post) in dict(deriv=(0, 0), deriv_sqrt=(0, 1), deriv_log=(0, 2), plain=(2, 0), ramp=(1, 0)).items():
+        d = oracle.radon(img, 96, 80, filter=f, post=post)
+        radon["radon_%s_checksum" % name] = checksum(d)
+        radon["radon_%s_samples" % name] = d.reshape(-1)[bins]
+    dtrs = [oracle.radon(im, 96, 96) for im in imgs]
+    idx = np.array([[0, 1, 0, 1], [2, 5, 2, 5], [7, 3, 7, 3], [1, 6, 4, 2], [4, 5, 5, 4], [6, 0, 6, 0]], np.int32)
+    r_idx = oracle.evaluate_pairs(Ps, dtrs, 128, 128, idx)
+    views = [1, 2, 4, 6, 7]
+    idx_sub = np.array([(a, b, a, b) for k, a in enumerate(views) for b in views[k + 1:]], np.int32)
+    r_sub = oracle.evaluate_pairs(Ps, dtrs, 128, 128, idx_sub)
+    r_par = oracle.evaluate_all(Ps, dtrs, 128, 128, object_radius_mm=25.0, dkappa=0.004)
+    np.savez_compressed(
+        os.path.join(HERE, "variants_128.npz"), image=img, bins=bins, idx=idx, idx_pairs=r_idx["pairs"],
+        idx_mean=r_idx["mean"], subset=np.array(views, np.int32), subset_mean=r_sub["mean"], param_pairs=r_par["pairs"],
+        param_mean=r_par["mean"], param_n_kappa=r_par["n_kappa"], **radon)
+    print("variants: idx mean %.9g subset mean %.9g param mean %.9g" % (r_idx["mean"], r_sub["mean"], r_par["mean"]))
+
+
 if __name__ == "__main__":
     if os.path.isdir(REF):
         example_pair()
     synthetic8()
     widened_rows()
+    variants()

@@ -117,3 +117,48 @@ def test_hip_matches_widened_rows_golden(gpu_ctx):
     assert len(sd["kappas"]) == int(r["direct_n"]) and abs(val - float(r["direct_metric"])) <= 1e-5 * float(r["direct_metric"])
     val, _ = d.setFanBeamConsistency(True).evaluateForImagePair(0, 1)
     assert abs(val - float(r["fbcc_metric"])) <= 1e-3 * float(r["fbcc_metric"])
+
+
+_RADON_VARIANTS = dict(deriv=(0, 0), deriv_sqrt=(0, 1), deriv_log=(0, 2), plain=(2, 0), ramp=(1, 0))
+
+
+def test_oracle_reproduces_variants(oracle_mod, small_scan):
+    g = np.load(os.path.join(G, "variants_128.npz"))
+    for name, (f, post) in _RADON_VARIANTS.items():
+        d = oracle_mod.radon(g["image"], 96, 80, filter=f, post=post)
+        assert np.array_equal(_checksum(d), g["radon_%s_checksum" % name]), name
+        assert np.array_equal(d.reshape(-1)[g["bins"]], g["radon_%s_samples" % name]), name
+    s = small_scan
+    r = oracle_mod.evaluate_pairs(s["Ps"], s["dtrs"], 128, 128, g["idx"])
+    assert np.array_equal(r["pairs"], g["idx_pairs"]) and r["mean"] == float(g["idx_mean"])
+    r = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], 128, 128, object_radius_mm=25.0, dkappa=0.004)
+    assert np.array_equal(r["pairs"], g["param_pairs"]) and r["n_kappa"] == int(g["param_n_kappa"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_variants_golden(gpu_ctx, small_scan):
+    """Every Radon filter / post-process bit-exact against the fixture (Ramp: 1e-6 of the maximum); index-list,
+    subset and user-parameter evaluations against the fixture's oracle values."""
+    import epipolarconsistency_amd as E
+    g = np.load(os.path.join(G, "variants_128.npz"))
+    for name, (f, post) in _RADON_VARIANTS.items():
+        got = E.RadonIntermediate.compute(gpu_ctx, g["image"], 96, 80, filter=f, post_process=post).readback()
+        if name == "ramp":
+            want = g["radon_ramp_samples"]
+            assert np.abs(got.reshape(-1)[g["bins"]] - want).max() <= 1e-6 * np.abs(want).max()
+        else:
+            assert np.array_equal(_checksum(got), g["radon_%s_checksum" % name]), name
+            assert np.array_equal(got.reshape(-1)[g["bins"]], g["radon_%s_samples" % name]), name
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, 128, 128) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    out = np.zeros(len(g["idx"]), np.float32)
+    mean = m.evaluate(g["idx"], out)
+    np.testing.assert_allclose(out, g["idx_pairs"], rtol=2e-4)
+    assert abs(mean - float(g["idx_mean"])) <= 5e-5 * float(g["idx_mean"])
+    assert abs(m.evaluate(set(int(v) for v in g["subset"])) - float(g["subset_mean"])) <= 5e-5 * float(g["subset_mean"])
+    m.setObjectRadius(25.0)
+    m.setEpipolarPlaneStep(0.004)
+    total, vals = m.evaluate_range(0, 28, want_pairs=True)
+    np.testing.assert_allclose(vals, g["param_pairs"], rtol=2e-4)
+    assert abs(total / 28 - float(g["param_mean"])) <= 1e-5 * float(g["param_mean"])
