@@ -83,6 +83,7 @@ SIGNATURES = {
     "ecc_host_angular_range": (None, [_vp, _vp, _d, _pd, _pd]),
     "ecc_host_angular_step": (_d, [_vp, _vp, _i, _i]),
     "ecc_host_iso_center": (None, [_vp, _i, _vp]),
+    "ecc_host_line_to_sample_dtr": (_i, [_vp, C.c_float]),
     "ecc_exchange_open": (_i, [C.c_char_p, _i, _i, C.POINTER(C.c_void_p)]),
     "ecc_exchange_sum": (_i, [_vp, _d, _pd]),
     "ecc_exchange_close": (_i, [_vp]),

@@ -243,7 +243,72 @@ class RadonIntermediate:
         a, t = self._info()[:2]
         out = np.empty((t, a), np.float32)
         check(_lib.lib().ecc_dtr_readback(self._h, C.c_void_p(out.ctypes.data)))
+        self._raw_cpu = out
         return out
+
+    def clearRawData(self):
+        """ref: clearRawData(): drop the host copy."""
+        self._raw_cpu = None
+
+    def data(self):
+        """ref: data(): the host copy made by the last readback() (None before)."""
+        return getattr(self, "_raw_cpu", None)
+
+    def replaceRadonIntermediateData(self, radon_intermediate_image):
+        """ref: replaceRadonIntermediateData(image) (RadonIntermediate.cpp:105-123): new dtr data from host memory,
+        (n_t, n_alpha) float32, alpha fastest; original image size and filter are kept, the bin sizes follow the new
+        shape.  Like in the reference a metric that already holds this object must be given the dtrs again
+        (setRadonIntermediates)."""
+        a = np.ascontiguousarray(radon_intermediate_image, np.float32)
+        assert a.ndim == 2
+        info = self._info()
+        fresh = RadonIntermediate.from_host(self.ctx, a, info[2], info[3], filter=info[4])
+        self.close()
+        self._h, fresh._h = fresh._h, C.c_void_p()
+        self._keep = None
+        self._raw_cpu = a.copy()
+
+    def tex2D(self, s, t):
+        """ref: tex2D(s, t) (RadonIntermediate.h:108): HOST sample of the read-back data in texture coordinates
+        [0, 1]^2 -- bilinear in binary64 on the (n - 1)-scaled grid with NRRD::ImageView's edge rule
+        (HeaderOnly/NRRD/nrrd_image_view.hxx:159-205).  Call readback() first."""
+        raw = self.data()
+        if raw is None:
+            raise ValueError("call readback() first")
+        n_t, n_alpha = raw.shape
+        x, y = (n_alpha - 1) * float(np.float32(s)), (n_t - 1) * float(np.float32(t))
+
+        def cell(v, n):
+            i = int(v)  # truncation, like the reference's (int)x
+            f = v - i
+            if i < 0:
+                i, f = 0, 0.0
+            if i > n - 2:
+                i, f = n - 2, 1.0
+            return i, f
+        ix, fx = cell(x, n_alpha)
+        iy, fy = cell(y, n_t)
+        if fx == 0 and fy == 0:
+            return float(np.float32(raw[iy, ix]))
+        r = ((1.0 - fy) * ((1.0 - fx) * float(raw[iy, ix]) + fx * float(raw[iy, ix + 1]))
+             + fy * ((1.0 - fx) * float(raw[iy + 1, ix]) + fx * float(raw[iy + 1, ix + 1])))
+        return float(np.float32(r))
+
+    def sample(self, line):
+        """ref: sample(line) (RadonIntermediate.h:86-105): HOST sample for a line (l0, l1, l2) relative to the image
+        centre; `line` (3 floats) is overwritten with the sample location like in the reference.  Returns the value,
+        negated on the folded branch of a derivative dtr -- the evident intent, as for evaluateForImagePair: the
+        reference's own flip test comes after lineToSampleDtr has already folded the angle and can never fire
+        (RadonIntermediate.h:91-100)."""
+        l = np.ascontiguousarray(line, np.float32).reshape(3).copy()
+        range_t = np.float32(self.getRadonBinSize(1)) * np.float32(self.getRadonBinNumber(1))
+        folded = _lib.lib().ecc_host_line_to_sample_dtr(C.c_void_p(l.ctypes.data), C.c_float(float(range_t)))
+        try:
+            line[:3] = l
+        except TypeError:
+            pass
+        v = self.tex2D(l[0], l[1])
+        return -v if (folded and self.isDerivative()) else v
 
     def device_view(self):
         base, pitch, rows = C.c_void_p(), C.c_int(), C.c_int()

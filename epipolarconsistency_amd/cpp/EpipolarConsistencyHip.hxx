@@ -130,6 +130,56 @@ public:
     const std::vector<float>& data() const { return m_raw_cpu; }
     void clearRawData() { std::vector<float>().swap(m_raw_cpu); }
 
+    /// ref: replaceRadonIntermediateData(image) (RadonIntermediate.cpp:105-123): new data from host memory, n_t rows x
+    /// n_alpha columns; original image size and filter are kept.  A metric that already holds this object must be
+    /// given the dtrs again (setRadonIntermediates), like in the reference.
+    void replaceRadonIntermediateData(const float* radon_intermediate_image, int n_alpha, int n_t, ecc_ctx* ctx = nullptr)
+    {
+        Info i = info();
+        ecc_dtr* fresh = nullptr;
+        detail::check(ecc_dtr_from_host(ctx ? ctx : detail::default_context(), radon_intermediate_image, n_alpha, n_t, i.n_u,
+                                        i.n_v, i.filter, &fresh));
+        ecc_dtr_destroy(m_h);
+        m_h = fresh;
+        m_raw_cpu.assign(radon_intermediate_image, radon_intermediate_image + (size_t)n_alpha * n_t);
+    }
+
+    /// ref: tex2D(s, t) (RadonIntermediate.h:108): host sample of the read-back data in texture coordinates [0,1]^2,
+    /// bilinear in binary64 on the (n - 1)-scaled grid with NRRD::ImageView's edge rule
+    /// (HeaderOnly/NRRD/nrrd_image_view.hxx:159-205).  readback() first.
+    float tex2D(float s, float t) const
+    {
+        Info i = info();
+        if (m_raw_cpu.size() != (size_t)i.n_alpha * i.n_t) throw std::runtime_error("RadonIntermediate::tex2D: call readback() first");
+        double x = (i.n_alpha - 1) * (double)s, y = (i.n_t - 1) * (double)t;
+        int ix = (int)x, iy = (int)y;
+        double fx = x - ix, fy = y - iy;
+        if (ix < 0) { ix = 0; fx = 0; }
+        if (ix > i.n_alpha - 2) { ix = i.n_alpha - 2; fx = 1.0; }
+        if (iy < 0) { iy = 0; fy = 0; }
+        if (iy > i.n_t - 2) { iy = i.n_t - 2; fy = 1.0; }
+        const float* I = m_raw_cpu.data();
+        const size_t w = (size_t)i.n_alpha;
+        if (fx == 0 && fy == 0) return I[ix + iy * w];
+        return (float)((1.0 - fy) * ((1.0 - fx) * I[ix + iy * w] + fx * I[ix + 1 + iy * w]) +
+                       fy * ((1.0 - fx) * I[ix + (iy + 1) * w] + fx * I[ix + 1 + (iy + 1) * w]));
+    }
+
+    /// ref: sample(line) (RadonIntermediate.h:86-105): host sample for a line (l0, l1, l2) relative to the image centre;
+    /// `line` is overwritten with the sample location.  Negated on the folded branch of a derivative dtr -- the evident
+    /// intent: the reference's own flip test comes after lineToSampleDtr has folded the angle and can never fire.
+    template <typename Line>
+    float sample(Line& line) const
+    {
+        float l[3] = {(float)line[0], (float)line[1], (float)line[2]};
+        const float range_t = (float)getRadonBinSize(1) * getRadonBinNumber(1);
+        const int folded = ecc_host_line_to_sample_dtr(l, range_t);
+        line[0] = l[0];
+        line[1] = l[1];
+        const float v = tex2D(l[0], l[1]);
+        return (folded && isDerivative()) ? -v : v;
+    }
+
     /// ref: writePropertiesToMeta (RadonIntermediate.cpp:95-103)
     void writePropertiesToMeta(std::map<std::string, std::string>& dict) const
     {

@@ -357,6 +357,22 @@ ECC_EXPORT int ecc_device_count(void)
     return n;
 }
 
+ECC_EXPORT int ecc_host_line_to_sample_dtr(float* line, float range_t)
+{
+    // ref: EpipolarConsistencyCommon.hxx:152-171, the reference's float expressions; atan2 through binary64, rounded once
+    const float Pi = 3.14159265359f;
+    const float length = std::sqrt(line[0] * line[0] + line[1] * line[1]);
+    line[0] = (float)std::atan2((double)line[1], (double)line[0]) / Pi;
+    if (line[0] < 0) line[0] += 2;
+    line[1] = -(line[2] / length) / range_t + 0.5f;
+    if (line[0] > 1) {
+        line[0] = line[0] - 1.f;
+        line[1] = 1.f - line[1];
+        return 1;
+    }
+    return 0;
+}
+
 ECC_EXPORT void ecc_get_ij(int64_t ij, int n, int* i, int* j)
 {
     // pairs before row r: r*n - r(r+1)/2   (ref: EpipolarConsistencyCommon.hxx:52-79 enumerates the same order)

@@ -261,6 +261,11 @@ void ecc_host_pinvT(const double* P, float* PinvT12);
 void ecc_host_source_position(const double* P, float* C4);
 double ecc_host_object_radius(const double* P, int n_u, int n_v);
 
+/* ref: lineToSampleDtr (EpipolarConsistencyCommon.hxx:152-171), host: line (l0, l1, l2) relative to the image
+ * centre -> line[0] = angle / Pi in [0, 1], line[1] = distance in [0, 1]; returns 1 when the (alpha + Pi, -t)
+ * periodicity was used (the sample's sign flips for a derivative dtr).  fp32, atan2 correctly rounded. */
+int ecc_host_line_to_sample_dtr(float* line3, float range_t);
+
 /* ref: estimateAngularRange(join_pluecker(C0, C1), radius) (EpipolarConsistency.cpp:49-59): the kappa interval
  * of epipolar planes through the baseline of P0, P1 that touch a sphere of object_radius_mm about the origin. */
 void ecc_host_angular_range(const double* P0, const double* P1, double object_radius_mm, double* kappa_first,

@@ -44,6 +44,12 @@ int main(int argc, char** argv)
         printf("dtr1 %zu %.9g bins %d %d size %d %d step %.17g\n", dtrs[1]->data().size(), dtrs[1]->data()[1234 % dtrs[1]->data().size()],
                dtrs[1]->getRadonBinNumber(0), dtrs[1]->getRadonBinNumber(1), dtrs[1]->getOriginalImageSize(0),
                dtrs[1]->getOriginalImageSize(1), dtrs[1]->getRadonBinSize(1));
+        {   // host sampling helpers of the dtr class (RadonIntermediate.h:86-108)
+            float line[3] = {0.6f, -0.8f, -30.0f};
+            const float tex = dtrs[1]->tex2D(0.25f, 0.75f);
+            const float smp = dtrs[1]->sample(line);
+            printf("hostsample %.9g %.9g %.9g %.9g\n", tex, smp, line[0], line[1]);
+        }
         std::vector<float> rs0, rs1, kappas;
         std::vector<std::pair<float, float> > loc0, loc1;
         const double pair_ecc = ecc.evaluateForImagePair(0, 2, &rs0, &rs1, &kappas, &loc0, &loc1);

@@ -92,3 +92,19 @@ def test_metric_helper_functions():
     rad = max(api.estimateObjectRadius(Ps[0], 256, 256), api.estimateObjectRadius(Ps[3], 256, 256))
     a, b = api.estimateAngularRange(Ps[0], Ps[3], rad)
     assert abs(api.estimateAngularStep(Ps[0], Ps[3], 256, 256) - 2 * (b - a) / np.sqrt(2 * 256 ** 2)) < 1e-15
+
+
+def test_host_line_to_sample_dtr_matches_oracle(oracle_mod):
+    """ecc_host_line_to_sample_dtr (ref: lineToSampleDtr, EpipolarConsistencyCommon.hxx:152-171) is bit-identical to the
+    oracle's restatement, which tests/test_oracle_pins.py pins against the reference header."""
+    import ctypes as C
+    from epipolarconsistency_amd import _lib
+    rng = np.random.default_rng(17)
+    L = _lib.lib()
+    for _ in range(400):
+        line = rng.normal(0, 1, 3).astype(np.float32) * np.float32(rng.choice([1.0, 300.0]))
+        range_t = float(np.float32(rng.uniform(50, 2000)))
+        want, folded = oracle_mod.line_to_sample_dtr(line, range_t)
+        got = line.copy()
+        f = L.ecc_host_line_to_sample_dtr(C.c_void_p(got.ctypes.data), C.c_float(range_t))
+        assert np.array_equal(got[:2], want[:2]) and bool(f) == folded

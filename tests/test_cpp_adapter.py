@@ -52,6 +52,17 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     f = val["dtr1"].split()
     assert int(f[0]) == s["n_alpha"] * s["n_t"] and float(f[1]) == float(dtrs[1].reshape(-1)[1234])
     assert f[3:5] == [str(s["n_alpha"]), str(s["n_t"])] and f[6:8] == [str(s["n_u"]), str(s["n_v"])]
+    # host tex2D / sample of the adapter's dtr class against the Python mirror of the same reference functions
+    import epipolarconsistency_amd as E
+    ctx = E.Context(0)
+    d1 = E.RadonIntermediate.from_host(ctx, dtrs[1], s["n_u"], s["n_v"])
+    d1.readback()
+    line = np.array([0.6, -0.8, -30.0], np.float32)
+    smp = d1.sample(line)
+    f = [np.float32(x) for x in val["hostsample"].split()]
+    assert f[0] == np.float32(d1.tex2D(0.25, 0.75)) and f[1] == np.float32(smp) and f[2] == line[0] and f[3] == line[1]
+    d1.close()
+    ctx.close()
     e7 = oracle_mod.evaluate_for_image_pair(Ps, dtrs, 0, 2, s["n_u"], s["n_v"])
     f = val["pair02"].split()
     assert abs(float(f[0]) - e7["ecc"]) < 1e-4 * e7["ecc"]

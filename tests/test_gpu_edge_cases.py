@@ -264,3 +264,37 @@ def test_evaluate_for_image_pair(gpu_ctx, oracle_mod, small_scan, dkappa):
     assert ecc_bad > 2 * ecc_ok
     with pytest.raises(E.EccError):
         m.evaluateForImagePair(0, 99)
+
+
+def test_host_sampling_helpers_and_replace(gpu_ctx, oracle_mod):
+    """RadonIntermediate::tex2D / sample (host, RadonIntermediate.h:86-108) and replaceRadonIntermediateData
+    (RadonIntermediate.cpp:105-123)."""
+    import epipolarconsistency_amd as E
+    rng = np.random.default_rng(2)
+    n_t, n_alpha, n_u, n_v = 40, 56, 128, 96
+    a = rng.standard_normal((n_t, n_alpha)).astype(np.float32)
+    d = E.RadonIntermediate.from_host(gpu_ctx, a, n_u, n_v)
+    with pytest.raises(ValueError):
+        d.tex2D(0.5, 0.5)
+    assert np.array_equal(d.readback(), a) and d.data() is not None
+    # grid points of the (n - 1)-scaled lattice return the texels themselves, the far corner is clamped
+    for (i, j) in ((0, 0), (7, 3), (n_alpha - 1, n_t - 1), (20, n_t - 1)):
+        assert d.tex2D(i / (n_alpha - 1), j / (n_t - 1)) == pytest.approx(float(a[j, i]), rel=1e-6, abs=1e-6)
+    mid = d.tex2D(0.5 / (n_alpha - 1), 0.0)
+    assert mid == pytest.approx(0.5 * (float(a[0, 0]) + float(a[0, 1])), rel=1e-6)
+    # sample(line): location from lineToSampleDtr, sign flipped on the folded branch of a derivative dtr
+    range_t = np.float32(d.getRadonBinSize(1)) * np.float32(n_t)
+    for line in ([0.6, 0.8, 12.0], [0.6, -0.8, -30.0], [-1.0, 0.1, 5.0]):
+        l = np.array(line, np.float32)
+        want_loc, folded = oracle_mod.line_to_sample_dtr(l, float(range_t))
+        got = d.sample(l)
+        assert np.array_equal(l[:2], want_loc[:2])
+        assert got == (-1.0 if folded else 1.0) * d.tex2D(want_loc[0], want_loc[1])
+    # new data: the handle is replaced, metadata kept, bin size follows the new shape
+    b = rng.standard_normal((64, 48)).astype(np.float32)
+    d.replaceRadonIntermediateData(b)
+    assert d.getRadonBinNumber(0) == 48 and d.getRadonBinNumber(1) == 64 and d.getOriginalImageSize(0) == n_u
+    assert d.isDerivative() and np.array_equal(d.readback(), b)
+    assert abs(d.getRadonBinSize(1) - np.sqrt(n_u ** 2 + n_v ** 2) / 64) < 1e-9
+    d.clearRawData()
+    assert d.data() is None
