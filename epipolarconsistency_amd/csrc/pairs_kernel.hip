@@ -338,6 +338,11 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
 // across trips cannot be expressed: the compiler's wait-count insertion drains all loads at the loop header
 // (vmcnt(0) before the next stage's loads), and with the gathers in inline assembly it copies their destination
 // registers before the explicit wait.
+// Later, with the loads and their wait in inline assembly inside ONE trip (gathers of step k issued first, the
+// coordinates of step k + 64 computed while they are in flight, explicit s_waitcnt; no loop-carried loaded registers, so
+// no early copies -- checked in the ISA, results identical): 0.3305 vs 0.3323 ms, nothing; adding one-byte prefetch
+// loads of the next step's four lines (the L2 misses cost 13 %: 0.289 ms with every line cache-resident) made it 0.51 ms,
+// two prefetches 0.41 ms -- a gather instruction costs the L1 the same whatever it fetches.
 // DEG: the degree the record asks for -- the fit is of degree ECC_POLY_DEG, k01_kernel lowers it where Chebyshev
 // economisation costs less than 2e-8 bins (see economise).
 template <bool DERIV, bool CORR, int PITCH4, int DEG>
