@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libecc_hip.so")
 ECC_OK = 0
 FILTER_DERIVATIVE, FILTER_RAMP, FILTER_NONE = 0, 1, 2
 POST_IDENTITY, POST_SQUARE_ROOT, POST_LOGARITHM = 0, 1, 2
+SAMPLING_AUTO, SAMPLING_POLYNOMIAL, SAMPLING_PER_SAMPLE, SAMPLING_REFERENCE = 0, 1, 2, 3
 
 
 class EccError(RuntimeError):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "ecc_metric_set_projections": (_i, [_vp, _vp, _i]),
     "ecc_metric_debug_geometry": (_i, [_vp, _vp, _vp]),
     "ecc_metric_set_params": (_i, [_vp, _d, _d, _i]),
+    "ecc_metric_set_sampling": (_i, [_vp, _i]),
     "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
     "ecc_metric_evaluate_range": (_i, [_vp, _i64, _i64, _vp, _pd]),

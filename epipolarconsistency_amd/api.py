@@ -336,6 +336,8 @@ class MetricRadonIntermediate:
         self._dtrs = []
         self._Ps = None
         self._params = [0.0, 0.0, 0]
+        d = type(self).default_sampling
+        self._sampling = 0 if d is None else (self._SAMPLING[d] if isinstance(d, str) else int(d))
         if dtrs is not None:
             self.setRadonIntermediates(dtrs)
         if Ps is not None:
@@ -349,6 +351,7 @@ class MetricRadonIntermediate:
         hs = (C.c_void_p * len(self._dtrs))(*[d._h for d in self._dtrs])
         check(_lib.lib().ecc_metric_create(self.ctx._h, len(self._dtrs), hs, C.byref(self._h)))
         check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
+        check(_lib.lib().ecc_metric_set_sampling(self._h, self._sampling))
         if self._Ps is not None:
             self.setProjectionMatrices(self._Ps)
         return self
@@ -398,6 +401,18 @@ class MetricRadonIntermediate:
     def useCorrelation(self, corr=True):
         self._params[2] = 1 if corr else 0
         self._push_params()
+        return self
+
+    # class-wide default for new objects: None = the library's default (ECC_SAMPLING_AUTO)
+    default_sampling = None
+    _SAMPLING = {"auto": 0, "polynomial": 1, "per_sample": 2, "reference": 3}
+
+    def setSampling(self, mode="auto"):
+        """Not in the reference (ecc_metric_set_sampling): "auto" (reference arithmetic for evaluations of at most
+        512 pairs, fitted polynomials above), "polynomial", "per_sample" or "reference"."""
+        self._sampling = self._SAMPLING[mode] if isinstance(mode, str) else int(mode)
+        if self._h:
+            check(_lib.lib().ecc_metric_set_sampling(self._h, self._sampling))
         return self
 
     # -- evaluation ----------------------------------------------------------------------------

@@ -10,8 +10,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -114,6 +120,7 @@ struct ecc_metric {
     // parameters
     double object_radius_mm = 0, dkappa = 0;
     int use_corr = 0;
+    int sampling = ECC_SAMPLING_AUTO;  // ecc_metric_set_sampling
     // projections
     int n_views = 0;
     std::vector<double> P_first;  // first projection matrix (object radius estimate)
@@ -136,22 +143,93 @@ struct ecc_metric {
     int64_t records_capacity = 0;
     double* sum_d = nullptr;
     double* Ps_d = nullptr;   // n x 12 float64 as handed over by the caller
-    // pinned host staging
-    double* Ps_h = nullptr;
-    double* sum_h = nullptr;
-    double* Ps_h_dev = nullptr;   // the same pinned buffers as the device sees them (zero-copy: the 38 KB of
-    double* sum_h_dev = nullptr;  // matrices and the 8-byte result cross PCIe inside the kernels, no copy commands)
+    // pinned host staging, mapped into the device's address space (zero-copy: the 38 KB of matrices and the 8-byte
+    // result cross PCIe inside the kernels, no copy commands).  Two matrix buffers, used alternately: an evaluate
+    // call returns only after the stream has executed everything up to its result, so the buffer of the call before
+    // the previous one is free without asking the stream (set_generation / done_generation below).
+    double* Ps_h[2] = {nullptr, nullptr};
+    double* Ps_h_dev[2] = {nullptr, nullptr};
+    uint64_t set_generation = 0;   // number of e1 launches so far; launch g reads Ps_h[g & 1]
+    uint64_t done_generation = 0;  // every e1 launch up to this one is known to have completed
+    double* sum_h = nullptr;       // 64-byte slot; [0] = the result, written by sum_pairs_kernel with a system-scope store
+    double* sum_h_dev = nullptr;
 };
 
 namespace {
 
 // Wait for the stream with a query spin: the evaluate calls sit on an optimiser's critical path and the result is
-// 8 bytes; hipStreamSynchronize's blocking wait costs several microseconds more per call than polling.
+// 8 bytes; hipStreamSynchronize's blocking wait costs several microseconds more per call than polling.  The spin is
+// bounded: after ECC_SPIN_SECONDS of polling (a hung kernel, a faulted queue) it falls back to the blocking wait, which
+// sleeps instead of burning a core and returns the queue's error when the driver gives up on it.
+constexpr double ECC_SPIN_SECONDS = 2.0;
+
+double now_seconds()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 hipError_t wait_stream_spin(hipStream_t stream)
 {
-    for (;;) {
+    double t0 = 0.0;
+    for (unsigned spins = 0;; ++spins) {
         const hipError_t e = hipStreamQuery(stream);
         if (e != hipErrorNotReady) return e;
+        if ((spins & 0x3ff) == 0x3ff) {
+            const double t = now_seconds();
+            if (t0 == 0.0) t0 = t;
+            else if (t - t0 > ECC_SPIN_SECONDS) return hipStreamSynchronize(stream);
+        }
+    }
+}
+
+// The result of an evaluation is one float64 that sum_pairs_kernel stores straight into pinned host memory.  The host
+// arms the slot with a bit pattern no sum can have (a NaN with a private payload), launches, and polls the slot itself:
+// the value is visible as soon as the store has crossed PCIe, a few microseconds before the runtime reports the stream
+// idle (end-of-kernel cache write-back, completion signal).  Bounded like wait_stream_spin; the stream's own status is
+// consulted when the value does not show up, so a failed launch surfaces as an error instead of a hang.
+constexpr uint64_t ECC_RESULT_PENDING = 0x7ff8ecc0dead0001ull;
+
+bool result_polling_enabled()
+{
+    static const bool on = [] {
+        const char* e = std::getenv("ECC_RESULT_WAIT");  // "stream": wait for the stream instead (A/B measurements)
+        return !(e && std::strcmp(e, "stream") == 0);
+    }();
+    return on;
+}
+
+void arm_result(ecc_metric* m)
+{
+    reinterpret_cast<volatile uint64_t*>(m->sum_h)[0] = ECC_RESULT_PENDING;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
+hipError_t wait_result(ecc_metric* m, hipStream_t stream, double* value)
+{
+    if (!result_polling_enabled()) {
+        const hipError_t e = wait_stream_spin(stream);
+        std::memcpy(value, m->sum_h, sizeof(double));
+        return e;
+    }
+    const volatile uint64_t* slot = reinterpret_cast<const volatile uint64_t*>(m->sum_h);
+    double t0 = 0.0;
+    for (unsigned spins = 0;; ++spins) {
+        const uint64_t bits = *slot;
+        if (bits != ECC_RESULT_PENDING) {
+            std::memcpy(value, &bits, sizeof(double));
+            return hipSuccess;
+        }
+        if ((spins & 0xfff) == 0xfff) {
+            const double t = now_seconds();
+            if (t0 == 0.0) t0 = t;
+            else if (t - t0 > ECC_SPIN_SECONDS) {
+                const hipError_t e = hipStreamSynchronize(stream);
+                const uint64_t b2 = *slot;
+                std::memcpy(value, &b2, sizeof(double));
+                if (e == hipSuccess && b2 == ECC_RESULT_PENDING) return hipErrorUnknown;  // the kernel ran and wrote nothing
+                return e;
+            }
+        }
     }
 }
 
@@ -683,7 +761,7 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
         e = hipMemcpyAsync(m->paired_table_d, ptable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
 
-    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, sizeof(double), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&m->sum_h_dev, m->sum_h, 0);
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->dtr_table_d, table.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
@@ -717,7 +795,8 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->records_d) (void)hipFree(m->records_d);
     if (m->sum_d) (void)hipFree(m->sum_d);
     if (m->Ps_d) (void)hipFree(m->Ps_d);
-    if (m->Ps_h) (void)hipHostFree(m->Ps_h);
+    for (double* b : m->Ps_h)
+        if (b) (void)hipHostFree(b);
     if (m->sum_h) (void)hipHostFree(m->sum_h);
     delete m;
     return ECC_OK;
@@ -730,27 +809,42 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
     ecc_ctx* ctx = m->ctx;
     int rc = set_device(ctx);
     if (rc) return rc;
-    // the pinned staging buffer may still be in flight from the previous call
-    HIP_TRY(wait_stream_spin(ctx->stream));
     if (n_views > m->geom_capacity) {
+        HIP_TRY(wait_stream_spin(ctx->stream));
+        m->done_generation = m->set_generation;
         if (m->Cs_d) HIP_TRY(hipFree(m->Cs_d));
         if (m->PinvTs_d) HIP_TRY(hipFree(m->PinvTs_d));
         if (m->Ps_d) HIP_TRY(hipFree(m->Ps_d));
-        if (m->Ps_h) HIP_TRY(hipHostFree(m->Ps_h));
+        for (double*& b : m->Ps_h) {
+            if (b) HIP_TRY(hipHostFree(b));
+            b = nullptr;
+        }
         m->Cs_d = m->PinvTs_d = nullptr;
-        m->Ps_d = m->Ps_h = nullptr;
+        m->Ps_d = nullptr;
         m->geom_capacity = 0;
         HIP_TRY(hipMalloc((void**)&m->Cs_d, sizeof(float) * 4 * n_views));
         HIP_TRY(hipMalloc((void**)&m->PinvTs_d, sizeof(float) * 12 * n_views));
         HIP_TRY(hipMalloc((void**)&m->Ps_d, sizeof(double) * 12 * n_views));
-        HIP_TRY(hipHostMalloc((void**)&m->Ps_h, sizeof(double) * 12 * n_views, hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&m->Ps_h_dev, m->Ps_h, 0));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipHostMalloc((void**)&m->Ps_h[b], sizeof(double) * 12 * n_views, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&m->Ps_h_dev[b], m->Ps_h[b], 0));
+        }
         m->geom_capacity = n_views;
     }
+    // The staging buffer of this call was last read by the e1 launch two calls ago.  In the optimiser pattern
+    // (setProjectionMatrices, evaluate, setProjectionMatrices, ...) that launch is known to be complete and nothing is
+    // waited for; only a caller that sets matrices repeatedly without a synchronous evaluate in between waits here.
+    const uint64_t g = m->set_generation + 1;
+    if (g > 2 && m->done_generation < g - 2) {
+        HIP_TRY(wait_stream_spin(ctx->stream));
+        m->done_generation = m->set_generation;
+    }
+    const int slot = (int)(g & 1);
     // E1 on the device: one thread per view reads its 12 doubles straight from the pinned staging buffer and
     // does the reference's binary64 Householder-QR arithmetic (geometry_kernel.hip); nothing else crosses PCIe.
-    std::memcpy(m->Ps_h, Ps, sizeof(double) * 12 * (size_t)n_views);
-    HIP_TRY(ecc_launch_e1(m->Ps_h_dev, n_views, m->PinvTs_d, m->Cs_d, ctx->stream));
+    std::memcpy(m->Ps_h[slot], Ps, sizeof(double) * 12 * (size_t)n_views);
+    HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], n_views, m->PinvTs_d, m->Cs_d, ctx->stream));
+    m->set_generation = g;
     m->n_views = n_views;
     m->P_first.assign(Ps, Ps + 12);
     return ECC_OK;
@@ -778,6 +872,14 @@ ECC_EXPORT int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, dou
     return ECC_OK;
 }
 
+ECC_EXPORT int ecc_metric_set_sampling(ecc_metric* m, int mode)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    if (mode < ECC_SAMPLING_AUTO || mode > ECC_SAMPLING_REFERENCE) return fail(ECC_ERR_INVALID_ARGUMENT, "unknown sampling mode");
+    m->sampling = mode;
+    return ECC_OK;
+}
+
 ECC_EXPORT int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm)
 {
     if (!m || !radius_mm) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
@@ -789,7 +891,14 @@ ECC_EXPORT int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_
 
 namespace {
 
-int fill_pair_params(ecc_metric* m, EccPairParams* p)
+// ECC_SAMPLING_AUTO -> the mode one evaluation of `count` pairs runs in (include/ecc_hip.h)
+int resolve_sampling(const ecc_metric* m, int64_t count)
+{
+    if (m->sampling != ECC_SAMPLING_AUTO) return m->sampling;
+    return count <= ECC_SAMPLING_AUTO_REFERENCE_PAIRS ? ECC_SAMPLING_REFERENCE : ECC_SAMPLING_POLYNOMIAL;
+}
+
+int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t count)
 {
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     double radius = 0;
@@ -817,7 +926,10 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p)
     p->use_corr = m->use_corr ? 1 : 0;
     int rc = ensure_poly_tables(m->ctx);
     if (rc) return rc;
-    p->poly = m->ctx->poly_d;
+    // without the tables k01_kernel fits nothing and marks every pair for the per-sample path
+    p->poly = resolve_sampling(m, count) == ECC_SAMPLING_POLYNOMIAL ? m->ctx->poly_d : nullptr;
+    p->slabs = m->dtr_table_d;  // ECC_SAMPLING_REFERENCE samples the dtrs themselves (clamped taps), not the paired copies
+    p->reference_arithmetic = resolve_sampling(m, count) == ECC_SAMPLING_REFERENCE ? 1 : 0;
     return ECC_OK;
 }
 
@@ -832,7 +944,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     if (first < 0 || count < 0 || first + count > n_pairs)
         return fail(ECC_ERR_INVALID_ARGUMENT, "pair range outside [0, n(n-1)/2)");
     EccPairParams p;
-    int rc = fill_pair_params(m, &p);
+    int rc = fill_pair_params(m, &p, count);
     if (rc) return rc;
     rc = ensure_capacity(&m->records_d, &m->records_capacity, count > 0 ? count : 1, ctx->stream);
     if (rc) return rc;
@@ -853,6 +965,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     }
     if (sum_d) {
         if (count > 0) HIP_TRY(ecc_launch_sum_pairs(pair_values_d, count, sum_d, ctx->stream));
+        else if (sum_d == m->sum_h_dev) std::memset(m->sum_h, 0, sizeof(double));  // empty shard: nothing is launched
         else HIP_TRY(hipMemsetAsync(sum_d, 0, sizeof(double), ctx->stream));
     }
     return ECC_OK;
@@ -884,12 +997,15 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
     if (rc) return rc;
     rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count > 0 ? count : 1, ctx->stream);
     if (rc) return rc;
+    arm_result(m);
     rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_h_dev);
     if (rc) return rc;
-    if (pair_values && count > 0)
+    if (pair_values && count > 0) {
         HIP_TRY(hipMemcpyAsync(pair_values, m->pair_values_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(wait_stream_spin(ctx->stream));
-    *partial_sum = *m->sum_h;
+        HIP_TRY(wait_stream_spin(ctx->stream));  // the copy has to land too
+    }
+    HIP_TRY(wait_result(m, ctx->stream, partial_sum));
+    m->done_generation = m->set_generation;
     return ECC_OK;
 }
 
@@ -919,11 +1035,17 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
         // upload the caller's image so that untouched entries survive, ref: ...RadonIntermediate.cpp:183
         HIP_TRY(hipMemcpyAsync(cost_d, cost_nxn, sizeof(float) * n * n, hipMemcpyHostToDevice, ctx->stream));
     }
+    arm_result(m);
     rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_h_dev);  // the sum lands in pinned host memory
     if (rc) return rc;
-    if (cost_nxn) HIP_TRY(hipMemcpyAsync(cost_nxn, cost_d, sizeof(float) * n * n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(wait_stream_spin(ctx->stream));
-    *mean = *m->sum_h / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
+    if (cost_nxn) {
+        HIP_TRY(hipMemcpyAsync(cost_nxn, cost_d, sizeof(float) * n * n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(wait_stream_spin(ctx->stream));
+    }
+    double sum = 0.0;
+    HIP_TRY(wait_result(m, ctx->stream, &sum));
+    m->done_generation = m->set_generation;
+    *mean = sum / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
     return ECC_OK;
 }
 
@@ -947,7 +1069,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(m->indices_d, idx4, sizeof(int32_t) * 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     EccPairParams p;
-    rc = fill_pair_params(m, &p);
+    rc = fill_pair_params(m, &p, n_pairs);
     if (rc) return rc;
     rc = ensure_capacity(&m->records_d, &m->records_capacity, n_pairs, ctx->stream);
     if (rc) return rc;
@@ -963,10 +1085,16 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;
     }
+    arm_result(m);
     HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, ctx->stream));
-    if (out) HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *mean = *m->sum_h / (double)n_pairs;
+    if (out) {
+        HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(wait_stream_spin(ctx->stream));
+    }
+    double sum = 0.0;
+    HIP_TRY(wait_result(m, ctx->stream, &sum));
+    m->done_generation = m->set_generation;
+    *mean = sum / (double)n_pairs;
     return ECC_OK;
 }
 

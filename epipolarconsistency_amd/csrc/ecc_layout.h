@@ -115,6 +115,8 @@ struct EccPairParams {
     int k_limit;               // launch bound on the kappa index (ref: ...RadonIntermediate.cu:348-358)
     int is_derivative;
     int use_corr;              // MetricRadonIntermediate::useCorrelation (ref: ...RadonIntermediate.cu:116-149)
+    const float* const* slabs; // device table of the dtrs' slabs (private layout); sampled by ECC_SAMPLING_REFERENCE
+    int reference_arithmetic;  // ECC_SAMPLING_REFERENCE: pairs_reference_kernel instead of pairs_kernel
 };
 
 // ---- projection pre-processing ------------------------------------------------

@@ -891,7 +891,10 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int w = 0; w < 1024 / 64; w++) tot += s[w];
-        *out = tot;
+        // `out` is usually pinned host memory that the host polls (ecc_capi.hip, wait_result): one 8-byte store at
+        // system scope, written through, visible to the host before the kernel's end-of-dispatch write-back
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(tot),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -990,6 +993,79 @@ __global__ __launch_bounds__(256) void pair_samples_kernel(EccPairSamplesParams 
     p.out[6 * (size_t)p.capacity + k] = d1;
 }
 
+// -------------------------------------------------------------------------------------------------
+// ECC_SAMPLING_REFERENCE: the pair loop in the CPU path's own arithmetic (oracle/ecc_oracle.c or_pair / or_redundancy,
+// i.e. ref: ...RadonIntermediate.cu:87-113,257-270 + EpipolarConsistencyCommon.hxx:152-171 as fp32 source
+// expressions, sin/cos/atan2 through binary64 and rounded once, exact fp32 bilinear rule with index clamps on the
+// dtr's own slab).  One wave per pair like pairs_kernel, kappa samples strided over the lanes, per-lane float64
+// partial sums (the only difference to a sequential CPU loop: the order of a float64 sum).  ~10x the instructions of
+// the polynomial path per sample -- meant for evaluations of few pairs, where a single pair's value has to agree with
+// the CPU path (include/ecc_hip.h, ecc_metric_set_sampling).
+// -------------------------------------------------------------------------------------------------
+template <bool CORR>
+__global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairParams p)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long local = (long long)blockIdx.x * 4 + wave;
+    if (local >= p.count) return;
+    local = ((long long)__builtin_amdgcn_readfirstlane((int)(local >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)local);
+    const EccPairRecord* __restrict__ rec = p.records + local;
+    float K0[8], K1[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        K0[i] = uniformf(rec->K0[i]);
+        K1[i] = uniformf(rec->K1[i]);
+    }
+    const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
+    const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
+    const float* __restrict__ d0 = p.slabs[iD0];
+    const float* __restrict__ d1 = p.slabs[iD1];
+    const float dkappa = K1[6], kappa_max = K1[7];
+    const bool deriv = p.is_derivative != 0;
+    double acc = 0.0, mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;
+    for (int k = lane; k < p.k_limit; k += 64) {
+        const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259
+        if (kappa >= kappa_max) break;
+        float x0 = (float)cos((double)kappa);
+        const float x1 = (float)sin((double)kappa);
+        float a, d;
+        const float v0p = sample_line_plain(K0, x0, x1, d0, p.pitch, p.n_alpha, p.n_t, p.range_t, deriv, &a, &d);
+        const float v1p = sample_line_plain(K1, x0, x1, d1, p.pitch, p.n_alpha, p.n_t, p.range_t, deriv, &a, &d);
+        x0 *= -1;  // ref: ...RadonIntermediate.cu:106
+        const float v0m = sample_line_plain(K0, x0, x1, d0, p.pitch, p.n_alpha, p.n_t, p.range_t, deriv, &a, &d);
+        const float v1m = sample_line_plain(K1, x0, x1, d1, p.pitch, p.n_alpha, p.n_t, p.range_t, deriv, &a, &d);
+        if (!CORR) {
+            const float vp = v0p - v1p, vm = v0m - v1m;
+            const float consistency = (vp * vp + vm * vm) * K0[6];  // ref: ...RadonIntermediate.cu:112
+            acc += (double)(consistency * dkappa);                  // ref: ...RadonIntermediate.cu:269
+        } else {
+            const float one_over_n = kappa_max / kappa;  // ref: ...RadonIntermediate.cu:211,274
+            mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
+            mom3 += (double)(one_over_n * (v1p * v1p + v1m * v1m));
+            mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
+        }
+    }
+    float val;
+    if (!CORR) {
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        val = (float)acc;
+    } else {
+        for (int off = 32; off > 0; off >>= 1) {
+            mom2 += __shfl_down(mom2, off);
+            mom3 += __shfl_down(mom3, off);
+            mom4 += __shfl_down(mom4, off);
+        }
+        const float xx = (float)mom2, yy = (float)mom3, xy = (float)mom4;
+        const float corr = (float)((double)xy / (sqrt((double)xx) * sqrt((double)yy)));
+        val = (1.0f - corr) * 1.0f;
+    }
+    if (lane == 0) {
+        if (p.pair_values) p.pair_values[local] = val;
+        if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
+    }
+}
+
 }  // namespace
 
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream)
@@ -1041,6 +1117,11 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
 {
     if (p->count <= 0) return hipSuccess;
     long long nblk = (p->count + 3) / 4;
+    if (p->reference_arithmetic) {
+        if (p->use_corr) hipLaunchKernelGGL((pairs_reference_kernel<true>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
+        else hipLaunchKernelGGL((pairs_reference_kernel<false>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
+        return hipGetLastError();
+    }
     long long per_xcd = (nblk + 7) / 8;
     dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
     if (p->use_corr) {

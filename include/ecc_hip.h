@@ -164,6 +164,26 @@ int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs);
  * reference's provisional per-sample weight kappa_max/kappa (ref: ...RadonIntermediate.cu:116-149,274;
  * .cpp:127-131); the reference has no test for it (parity unpinned). */
 int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa, int use_corr);
+/* How the pair kernel obtains the sample positions of a pair (not in the reference, which has one GPU path with
+ * hardware texture filtering and no CPU twin).  All modes implement the same formulas; they differ in
+ * fp32 rounding, which matters for a SINGLE pair: its value is a sum of squared, nearly cancelling differences and
+ * moves by ~2e-5 (median) when sample positions move by 1e-5 bins, while means over many pairs average that out.
+ *   ECC_SAMPLING_POLYNOMIAL  sample coordinates from per-pair polynomials in kappa fitted by the pair-geometry kernel
+ *                            (pairs whose fit is rejected take PER_SAMPLE by themselves).  Fastest;
+ *                            all-pairs means agree with the CPU path to < 1e-6, single pairs to ~1e-4.
+ *   ECC_SAMPLING_PER_SAMPLE  every pair evaluates line -> lineToSampleDtr per sample with device approximations
+ *                            (v_rsq, v_rcp + minimax atan); ~1.5x the kernel time, same accuracy class as POLYNOMIAL.
+ *   ECC_SAMPLING_REFERENCE   the CPU path's arithmetic operation for operation (ref: EpipolarConsistencyCommon.hxx:152-171,
+ *                            ...RadonIntermediate.cu:71-113 in fp32 source order, sin/cos/atan2 correctly rounded,
+ *                            exact fp32 bilinear rule with index clamps): single pair values agree with the CPU path
+ *                            to float rounding of the final sum.  ~10x the kernel time of POLYNOMIAL.
+ *   ECC_SAMPLING_AUTO        (default) REFERENCE when one evaluation covers at most
+ *                            ECC_SAMPLING_AUTO_REFERENCE_PAIRS pairs (the whole evaluation is one pair's latency either
+ *                            way: 2-view metric values, index lists as in tools/Registration/Registration3D3D.hxx:95,109),
+ *                            POLYNOMIAL above.  Callers that compare values ACROSS calls of different size fix the mode. */
+enum { ECC_SAMPLING_AUTO = 0, ECC_SAMPLING_POLYNOMIAL = 1, ECC_SAMPLING_PER_SAMPLE = 2, ECC_SAMPLING_REFERENCE = 3 };
+#define ECC_SAMPLING_AUTO_REFERENCE_PAIRS 512
+int ecc_metric_set_sampling(ecc_metric* m, int mode);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
 int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);

@@ -43,3 +43,15 @@ def gpu_ctx():
     ctx = E.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _fixed_sampling_mode():
+    """The library's default sampling mode (ECC_SAMPLING_AUTO) switches small evaluations (<= 512 pairs) to the CPU
+    path's own arithmetic.  Most GPU tests are small on purpose and are there to hold the THROUGHPUT path (fitted
+    polynomials, per-sample fallback) against the oracle, so new metrics default to "polynomial" here; tests of the
+    other modes select them with setSampling() (tests/test_configs.py, tests/test_gpu_sampling_modes.py)."""
+    import epipolarconsistency_amd as E
+    E.MetricRadonIntermediate.default_sampling = "polynomial"
+    yield
+    E.MetricRadonIntermediate.default_sampling = None

@@ -9,6 +9,11 @@ container that has /root/reference):
   synthetic8_128.npz    8-view 128x128 synthetic scan (tests/conftest.py:make_small_scan): oracle pair
                         values, mean, K01s and per-dtr checksums.
 
+  example_pair_native.npz  BASELINE config 1 at its native size: the same two data files as they
+                        are, 1024x760 float32 (stored losslessly; mostly zero outside the object, 1.8 MB compressed),
+                        their projection matrices, and the oracle's outputs at 768x768 bins: K01, pair value, N_kappa,
+                        object radius, dtr checksums and 512 sparse dtr samples per view.
+
   example_pair_256_rows.npz  the rows of SURVEY.md 8(f) on the example pair (see widened_rows()).
   variants_128.npz      SURVEY.md 8c (a) and (d): every Radon filter / post-process on one 128x96 image at 96x80
                         bins; index-list, subset and user-parameter variants of the metric on the 8-view set.
@@ -59,6 +64,27 @@ def example_pair():
         dtr_checksums=np.stack([checksum(d) for d in dtrs]), sample_bins=bins,
         dtr_samples=np.stack([d.reshape(-1)[bins] for d in dtrs]))
     print("example pair: value %.9g, n_kappa %d" % (res["pairs"][0], res["n_kappa"]))
+
+
+def example_pair_native():
+    imgs, Ps = [], []
+    for name in ("proj000.nrrd", "proj040.nrrd"):
+        img, _, meta = nrrd.read(os.path.join(REF, name))
+        imgs.append(np.ascontiguousarray(img, np.float32))
+        Ps.append(nrrd.parse_matrix(meta["Projection Matrix"]))
+    imgs = np.stack(imgs)
+    n_u, n_v, n_alpha, n_t = 1024, 760, 768, 768
+    dtrs = [oracle.radon(im, n_alpha, n_t) for im in imgs]
+    res = oracle.evaluate_all(Ps, dtrs, n_u, n_v, want_K01=True)
+    rng = np.random.default_rng(43)
+    bins = rng.integers(0, n_alpha * n_t, size=512).astype(np.int32)
+    np.savez_compressed(
+        os.path.join(HERE, "example_pair_native.npz"), images=imgs, Ps=np.stack(Ps), n_alpha=n_alpha, n_t=n_t,
+        K01=res["K01s"][0], pair_value=res["pairs"][0], mean=res["mean"], n_kappa=res["n_kappa"],
+        object_radius=oracle.object_radius(Ps[0], n_u, n_v),
+        dtr_checksums=np.stack([checksum(d) for d in dtrs]), sample_bins=bins,
+        dtr_samples=np.stack([d.reshape(-1)[bins] for d in dtrs]))
+    print("example pair (native 1024x760): value %.9g, n_kappa %d" % (res["pairs"][0], res["n_kappa"]))
 
 
 def synthetic8():
@@ -133,6 +159,7 @@ def variants():
 if __name__ == "__main__":
     if os.path.isdir(REF):
         example_pair()
+        example_pair_native()
     synthetic8()
     widened_rows()
     variants()

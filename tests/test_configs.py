@@ -1,0 +1,211 @@
+"""BASELINE.json's configs, each through the C ABI on the GPU (`-m gpu`) against the CPU oracle:
+
+  config 1  the reference's example pair (config/example_data/proj000.nrrd + proj040.nrrd) at its NATIVE size,
+            1024x760 -> 768x768 bins, one ECC value.  The two data files travel as the fixture
+            tests/golden/example_pair_native.npz (made by tests/golden/make_golden.py) together with the oracle's
+            outputs; the known-answer scalars of SURVEY.md 8c (reference headers compiled in the survey container)
+            are checked as well.  The box-averaged 256x190 form is in test_golden.py.
+  config 2  synthetic 64-projection 512x512 short scan, Radon intermediates + all 2016 pairs.
+  config 5  FDCTMotionCorrection-style inner loop: view n/2 of the 400-view 1024x1024 scan swept over the six
+            "3D Rigid" parameters, 100 steps each = 600 all-pairs evaluations
+            (ref: Gui/Visualization.h:78-98 plotCostFunction; Gui/SingleImageMotion.h:84-90 evaluate(P_input);
+            LibProjectiveGeometry/Models/ModelSimilarity3D.hxx:64-88).
+  (config 3 = test_gpu_full_size.py / bench.py; config 4 = the pair-range shards of test_gpu_full_size.py and the
+  group / gloo tests.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+REL_MEAN = 1e-5  # north_star: 1e-5 relative on the metric value
+
+
+def _checksum(a):
+    a = np.ascontiguousarray(a, np.float32)
+    return np.array([a.astype(np.float64).sum(), np.abs(a).astype(np.float64).sum(),
+                     float(np.bitwise_xor.reduce(a.view(np.uint32).reshape(-1)))])
+
+
+# computeK01 of the example pair from the reference's own headers (n_u = 1024, n_v = 760,
+# r_obj = 106.75 mm, num_samples = 2 * 1275.2).  Entries that are ~1e-7 by cancellation are compared absolutely.
+K0_KAT = [2.01281409e-07, -1, 3.99973106, 0.934329152, 2.15178986e-07, -1253.72327, 265.277008, 2.41274428]
+K1_KAT = [-5.31891615e-08, -1, 3.99973106, -0.934328914, 2.15181757e-07, -1264.65845, 3.24763969e-04, 0.414144218]
+
+
+def _check_K01_kat(K01):
+    np.testing.assert_allclose(K01[:8], K0_KAT, rtol=2e-6, atol=2e-9)
+    np.testing.assert_allclose(K01[8:], K1_KAT, rtol=2e-6, atol=2e-9)
+
+
+# ---- config 1 ------------------------------------------------------------------------------------------------
+def test_config1_native_oracle_reproduces_fixture(oracle_mod):
+    g = np.load(os.path.join(G, "example_pair_native.npz"))
+    imgs, Ps = g["images"], list(g["Ps"])
+    assert imgs.shape == (2, 760, 1024) and int(g["n_kappa"]) == 1275  # N_kappa = 1275
+    assert abs(float(g["object_radius"]) - 106.75) < 5e-3
+    _check_K01_kat(g["K01"])
+    dtrs = [oracle_mod.radon(im, 768, 768) for im in imgs]
+    for k, d in enumerate(dtrs):
+        assert np.array_equal(_checksum(d), g["dtr_checksums"][k])
+        assert np.array_equal(d.reshape(-1)[g["sample_bins"]], g["dtr_samples"][k])
+    res = oracle_mod.evaluate_all(Ps, dtrs, 1024, 760, want_K01=True)
+    assert res["pairs"][0] == g["pair_value"] and res["n_kappa"] == 1275
+    assert np.array_equal(res["K01s"][0], g["K01"])
+
+
+@pytest.mark.gpu
+def test_config1_native_hip(gpu_ctx):
+    """Radon intermediates of the two native images bit-exact (checksums over all 589 824 bins + 512 sampled
+    bins); K01 against the fixture and the reference-header KAT; the single ECC value within 1e-5."""
+    import epipolarconsistency_amd as E
+    g = np.load(os.path.join(G, "example_pair_native.npz"))
+    dtrs = E.RadonIntermediate.compute_batch(gpu_ctx, g["images"], 768, 768)
+    for k, d in enumerate(dtrs):
+        got = d.readback()
+        assert np.array_equal(got.reshape(-1)[g["sample_bins"]], g["dtr_samples"][k])
+        assert np.array_equal(_checksum(got), g["dtr_checksums"][k])
+    m = E.MetricRadonIntermediate(gpu_ctx, list(g["Ps"]), dtrs)
+    assert abs(m.getObjectRadius() - float(g["object_radius"])) < 1e-9
+    K01 = m.debug_K01(0, 1)[0]
+    np.testing.assert_allclose(K01, g["K01"], rtol=3e-6, atol=1e-9)
+    _check_K01_kat(K01)
+    want = float(g["pair_value"])
+    # the library default (ECC_SAMPLING_AUTO): an evaluation of one pair runs in the CPU path's own arithmetic
+    m.setSampling("auto")
+    cost = np.zeros((2, 2), np.float32)
+    mean = m.evaluate(cost)
+    assert abs(mean - want) <= 1e-6 * want, (mean, want)
+    assert abs(cost[1, 0] - want) <= 1e-6 * want and cost[0, 1] == 0 and cost[0, 0] == 0 and cost[1, 1] == 0
+    assert m.setSampling("reference").evaluate() == mean
+    # the throughput paths on this single pair: fp32 rounding of the sample positions moves one pair's value by
+    # ~1e-4; they are held to 1e-5 on means over many pairs (configs 2, 3, 5)
+    for mode in ("polynomial", "per_sample"):
+        got = m.setSampling(mode).evaluate()
+        assert abs(got - want) <= 3e-4 * want, (mode, got, want)
+    m.close()
+
+
+# ---- config 2 ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_config2_short_scan_64x512(gpu_ctx, oracle_mod):
+    """64 views, 512x512, pixel 0.616 mm, 768x768 bins: dtrs bit-exact on sampled views/bins, all 2016 pair values
+    and the mean against the oracle run on the read-back dtrs."""
+    import torch
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    n, S, B = 64, 512, 768
+    Ps = synthetic.short_scan(n, S, S, 0.616)
+    phantom = synthetic.sphere_phantom()
+    dev = torch.device("cuda", gpu_ctx.device)
+    imgs = synthetic.projections_torch(Ps, S, S, phantom, dev)
+    torch.cuda.synchronize()
+    slabs = torch.zeros((n, E.slab_floats(B, B)), dtype=torch.float32, device=dev)
+    dtrs = E.RadonIntermediate.compute_into(gpu_ctx, imgs, slabs, B, B)
+    gpu_ctx.synchronize()
+    host = [d.readback() for d in dtrs]
+    # Radon intermediates: 3 views x 4096 random bins bit-exact against the oracle on the same (device-made) images
+    rng = np.random.default_rng(2)
+    bins = np.sort(rng.integers(0, B * B, size=4096)).astype(np.int32)
+    for v in (0, 31, 63):
+        img = imgs[v].cpu().numpy()
+        want = oracle_mod.radon_bins(img, B, B, bins)
+        assert np.array_equal(host[v].reshape(-1)[bins], want), "view %d" % v
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("auto")  # 2016 pairs: the polynomial path
+    n_pairs = n * (n - 1) // 2
+    assert n_pairs == 2016
+    cost = np.zeros((n, n), np.float32)
+    mean = m.evaluate(cost)
+    total, vals = m.evaluate_range(0, n_pairs, want_pairs=True)
+    assert total / n_pairs == mean
+    ref = oracle_mod.evaluate_all(Ps, host, S, S)
+    assert ref["n_kappa"] == 724 * n_pairs  # N_kappa = round(D) = 724 per pair at 512x512
+    assert abs(mean - ref["mean"]) <= REL_MEAN * ref["mean"], (mean, ref["mean"])
+    # single pairs: sums of squared, nearly cancelling differences; fp32 noise floor of this size
+    np.testing.assert_allclose(vals, ref["pairs"], rtol=1e-3)
+    iu = np.triu_indices(n, 1)
+    assert np.array_equal(cost[iu[1], iu[0]], vals)
+    # the per-sample path: same bars
+    total_x, vals_x = m.setSampling("per_sample").evaluate_range(0, n_pairs, want_pairs=True)
+    assert abs(total_x / n_pairs - ref["mean"]) <= REL_MEAN * ref["mean"]
+    np.testing.assert_allclose(vals_x, ref["pairs"], rtol=1e-3)
+    # reference arithmetic: every single pair value
+    total_r, vals_r = m.setSampling("reference").evaluate_range(0, n_pairs, want_pairs=True)
+    np.testing.assert_allclose(vals_r, ref["pairs"], rtol=1e-6)
+    assert abs(total_r / n_pairs - ref["mean"]) <= 1e-7 * ref["mean"]
+    m.close()
+
+
+# ---- config 5 ------------------------------------------------------------------------------------------------
+SWEEP_NAMES = ["tx", "ty", "tz", "rx", "ry", "rz"]
+SWEEP_RANGES = [5.0, 5.0, 5.0] + [float(np.deg2rad(2.0))] * 3  # Gui/Visualization.h:78-98 as used by config 5
+
+
+def sweep_pose(P, p, k, steps=100):
+    from epipolarconsistency_amd import geometry
+    x = -SWEEP_RANGES[p] + 2 * SWEEP_RANGES[p] * k / (steps - 1.0)
+    return P @ geometry.rigid_transform(**{SWEEP_NAMES[p]: x})
+
+
+@pytest.mark.gpu
+def test_config5_six_dof_sweep(gpu_ctx, oracle_mod):
+    """600 all-pairs evaluations of the 400-view scan with view 200 perturbed (P' = P T), as the optimiser's inner
+    loop issues them: setProjectionMatrices(Ps) + evaluate().  Checked: 7 sweep points against the oracle at 1e-5
+    (the oracle evaluates all 79 800 pairs once at the unperturbed pose and, per sweep point, the 399 pairs that
+    contain the moved view -- the other pair values do not depend on it); every 1-D sweep has its minimum at the
+    unperturbed pose (+-3 grid steps: the 100-step grid has no point at 0); the unperturbed value comes back
+    bit-for-bit after the sweep."""
+    import torch
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    n, S, B = 400, 1024, 768
+    moving = n // 2
+    Ps = synthetic.short_scan(n, S, S, 0.308)
+    dev = torch.device("cuda", gpu_ctx.device)
+    slabs = torch.zeros((n, E.slab_floats(B, B)), dtype=torch.float32, device=dev)
+    phantom = synthetic.sphere_phantom()
+    for a in range(0, n, 50):
+        imgs = synthetic.projections_torch(Ps[a:a + 50], S, S, phantom, dev)
+        torch.cuda.synchronize()
+        keep = E.RadonIntermediate.compute_into(gpu_ctx, imgs, slabs[a:a + 50], B, B)
+        gpu_ctx.synchronize()
+        del keep, imgs
+    dtrs = [E.RadonIntermediate.wrap_device(gpu_ctx, slabs[k], B, B, S, S) for k in range(n)]
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("auto")
+    n_pairs = n * (n - 1) // 2
+    base = m.evaluate()
+    packed = E.pack_projection_matrices(Ps)
+    P0 = Ps[moving].copy()
+    values = np.zeros((6, 100))
+    for p in range(6):
+        for k in range(100):
+            packed[moving] = sweep_pose(P0, p, k).T.reshape(12)
+            m.setProjectionMatrices(packed)
+            values[p, k] = m.evaluate()
+    packed[moving] = P0.T.reshape(12)
+    m.setProjectionMatrices(packed)
+    assert m.evaluate() == base  # restored bit-for-bit
+    assert np.all(np.isfinite(values)) and np.all(values > 0)
+    for p in range(6):
+        kmin = int(np.argmin(values[p]))
+        assert 46 <= kmin <= 53, (SWEEP_NAMES[p], kmin)
+        assert values[p, 0] > values[p, kmin] and values[p, 99] > values[p, kmin]
+
+    # oracle: full evaluation once, then the 399 pairs of the moved view per sampled sweep point
+    host = [d.readback() for d in dtrs]
+    ref0 = oracle_mod.evaluate_all(Ps, host, S, S, native=True)
+    assert abs(base - ref0["mean"]) <= REL_MEAN * ref0["mean"], (base, ref0["mean"])
+    idx = np.array([(min(moving, v), max(moving, v)) * 2 for v in range(n) if v != moving], np.int32)
+    idx = np.ascontiguousarray(idx[:, [0, 1, 0, 1]])
+    pair_sum0 = float(ref0["pairs"].astype(np.float64).sum())
+    ij = {(i, j): q for q, (i, j) in enumerate(zip(*np.triu_indices(n, 1)))}
+    moved0 = float(sum(float(ref0["pairs"][ij[(a, b)]]) for a, b, _, _ in idx))
+    for p, k in ((0, 10), (1, 90), (2, 49), (3, 0), (4, 70), (5, 99), (0, 50)):
+        Pk = [q for q in Ps]
+        Pk[moving] = sweep_pose(P0, p, k)
+        r = oracle_mod.evaluate_pairs(Pk, host, S, S, idx, native=True)
+        want = (pair_sum0 - moved0 + float(r["pairs"].astype(np.float64).sum())) / n_pairs
+        assert abs(values[p, k] - want) <= REL_MEAN * want, (p, k, values[p, k], want)
+    m.close()

@@ -157,6 +157,13 @@ def test_hip_matches_variants_golden(gpu_ctx, small_scan):
     np.testing.assert_allclose(out, g["idx_pairs"], rtol=2e-4)
     assert abs(mean - float(g["idx_mean"])) <= 5e-5 * float(g["idx_mean"])
     assert abs(m.evaluate(set(int(v) for v in g["subset"])) - float(g["subset_mean"])) <= 5e-5 * float(g["subset_mean"])
+    # library default (ECC_SAMPLING_AUTO -> reference arithmetic for these few pairs): 1e-6 on every value
+    m.setSampling("auto")
+    mean = m.evaluate(g["idx"], out)
+    np.testing.assert_allclose(out, g["idx_pairs"], rtol=1e-6)
+    assert abs(mean - float(g["idx_mean"])) <= 1e-6 * float(g["idx_mean"])
+    assert abs(m.evaluate(set(int(v) for v in g["subset"])) - float(g["subset_mean"])) <= 1e-6 * float(g["subset_mean"])
+    m.setSampling("polynomial")
     m.setObjectRadius(25.0)
     m.setEpipolarPlaneStep(0.004)
     total, vals = m.evaluate_range(0, 28, want_pairs=True)

@@ -165,6 +165,13 @@ def test_index_list_and_subset(gpu_ctx, oracle_mod, small_scan):
     idx2 = np.array([(a, b, a, b) for k, a in enumerate(sub) for b in sub[k + 1:]], np.int32)
     want2 = oracle_mod.evaluate_pairs(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], idx2)
     assert _rel(m.evaluate(views), want2["mean"]) < 5e-5
+    # the same calls in the library's default mode (ECC_SAMPLING_AUTO: few pairs -> the CPU path's own arithmetic):
+    # every single pair and both means far inside north_star's 1e-5
+    m.setSampling("auto")
+    mean = m.evaluate(idx, out)
+    np.testing.assert_allclose(out, want["pairs"], rtol=1e-6)
+    assert _rel(mean, want["mean"]) < 1e-6 and _rel(m.evaluate(views), want2["mean"]) < 1e-6
+    m.setSampling("polynomial")
     # invalid indices are rejected (the reference only checks under _DEBUG)
     with pytest.raises(E.EccError):
         m.evaluate(np.array([[0, 99, 0, 1]], np.int32))
@@ -192,6 +199,7 @@ def test_user_dkappa_and_radius(gpu_ctx, oracle_mod, small_scan):
     m.setObjectRadius(60.0).setEpipolarPlaneStep(0.002)
     want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], object_radius_mm=60.0, dkappa=0.002)
     assert _rel(m.evaluate(), want["mean"]) < 5e-5
+    assert _rel(m.setSampling("auto").evaluate(), want["mean"]) < 1e-6  # 28 pairs: reference arithmetic
 
 
 def test_full_size_radon_spot_check(gpu_ctx, oracle_mod):

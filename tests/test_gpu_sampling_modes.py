@@ -1,0 +1,82 @@
+"""The four sampling modes of the pair kernel (include/ecc_hip.h, ecc_metric_set_sampling) against the oracle on the
+small synthetic scan: what each mode promises for single pair values and for the mean.
+
+  reference   the CPU path's arithmetic, operation for operation: every pair value to float rounding of its sum;
+  auto        = reference up to 512 pairs per evaluation, polynomial above;
+  polynomial / per_sample   the throughput paths: mean 1e-5, single pairs at the fp32 noise floor (2e-4 here).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _metric(gpu_ctx, s, filt=0):
+    import epipolarconsistency_amd as E
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"], filter=filt) for d in s["dtrs"]]
+    return E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs), dtrs
+
+
+def test_reference_mode_reproduces_every_pair(gpu_ctx, oracle_mod, small_scan):
+    s = small_scan
+    m, _ = _metric(gpu_ctx, s)
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], want_K01=True)
+    for mode in ("reference", "auto"):
+        m.setSampling(mode)
+        cost = np.full((8, 8), -2.0, np.float32)
+        mean = m.evaluate(cost)
+        total, vals = m.evaluate_range(0, 28, want_pairs=True)
+        np.testing.assert_allclose(vals, want["pairs"], rtol=1e-6)
+        assert np.mean(vals == want["pairs"]) > 0.8  # bit-identical for most pairs (float64 sum order aside)
+        assert abs(mean - want["mean"]) <= 1e-7 * want["mean"] and total / 28 == mean
+        iu = np.triu_indices(8, 1)
+        assert np.array_equal(cost[iu[1], iu[0]], vals) and np.all(cost[iu] == -2.0)
+    # K01 of the pair-geometry kernel: the oracle's expressions, bit for bit except the two angles that go through
+    # the device's float64 asin / atan2
+    K = m.debug_K01(0, 28)
+    np.testing.assert_allclose(K, want["K01s"], rtol=3e-7, atol=1e-12)
+    m.close()
+
+
+def test_modes_agree_on_the_mean(gpu_ctx, oracle_mod, small_scan):
+    s = small_scan
+    m, _ = _metric(gpu_ctx, s)
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+    for mode, pair_tol in (("polynomial", 2e-4), ("per_sample", 2e-4), ("reference", 1e-6)):
+        total, vals = m.setSampling(mode).evaluate_range(0, 28, want_pairs=True)
+        assert abs(total / 28 - want["mean"]) <= 1e-5 * want["mean"], mode
+        np.testing.assert_allclose(vals, want["pairs"], rtol=pair_tol, err_msg=mode)
+    with pytest.raises(Exception):
+        m.setSampling(7)
+    m.close()
+
+
+def test_reference_mode_variants(gpu_ctx, oracle_mod, small_scan):
+    """Plain (non-derivative) dtrs, user dkappa / radius, useCorrelation and swapped index tuples in reference mode."""
+    s = small_scan
+    m, _ = _metric(gpu_ctx, s, filt=2)  # Filter::None -> no sign flip on the folded branch
+    m.setSampling("reference")
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], is_derivative=False)
+    total, vals = m.evaluate_range(0, 28, want_pairs=True)
+    np.testing.assert_allclose(vals, want["pairs"], rtol=1e-6)
+    m.close()
+    m, _ = _metric(gpu_ctx, s)
+    m.setSampling("reference").setObjectRadius(25.0).setEpipolarPlaneStep(0.004)
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], object_radius_mm=25.0, dkappa=0.004)
+    total, vals = m.evaluate_range(0, 28, want_pairs=True)
+    np.testing.assert_allclose(vals, want["pairs"], rtol=1e-6)
+    m.setObjectRadius(0.0).setEpipolarPlaneStep(0.0)
+    idx = np.array([[5, 2, 5, 2], [1, 6, 4, 2], [3, 3, 3, 3]], np.int32)  # reversed, crossed, degenerate (same view)
+    want = oracle_mod.evaluate_pairs(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], idx)
+    out = np.zeros(3, np.float32)
+    m.evaluate(idx, out)
+    np.testing.assert_allclose(out, want["pairs"], rtol=1e-6, atol=0)
+    assert out[2] == 0.0
+    oracle_mod.set_use_corr(True)
+    try:
+        want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+    finally:
+        oracle_mod.set_use_corr(False)
+    total, vals = m.useCorrelation(True).evaluate_range(0, 28, want_pairs=True)
+    np.testing.assert_allclose(vals, want["pairs"], rtol=2e-5, atol=1e-7)  # 1 - cc: cancellation of a float near 1
+    m.close()
