@@ -9,9 +9,18 @@ resident in HBM when the timed region starts (they are computed once per data se
 that cost is reported separately as ms_per_radon_intermediate).
 
 N GPUs: one process per GPU (torchrun), dtr stack produced data-parallel + all-gathered once (RCCL),
-contiguous shards of the pair range per rank, and per evaluation the 8-byte partial sums -- already
-on the host -- are added through the library's shared-memory exchange (--exchange collective: an
-all-reduce of a device scalar instead).  The total work per evaluation is fixed, so scaling is "strong".
+contiguous shards of the pair range per rank, and per evaluation the 8-byte partial sums are added
+either through the library's shared-memory exchange (they are on the host already) or by an RCCL
+all-reduce of a device scalar.  BOTH are timed; `value` is the faster one, the other is reported next
+to it (config.sum_exchange says which).  The total work per evaluation is fixed: scaling is "strong".
+(The single-process form of the same partitioning -- ecc_group_* of the C ABI, what a C++ caller of the
+adapter uses -- is measured by scripts/bench_group.py.)
+
+Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by barrier + synchronize on both
+sides and reduced with MAX over ranks.  The first block is what a cold process gets (clocks still
+ramping, first touch of the pose arrays) and is reported as `cold`; `value` / `ms_per_step` are the
+MEDIAN block (all block times are listed), so a 20-step run reports the same steady-state number as a
+200-step one.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,8 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-ENGINE_CLOCK_GHZ = 2.4  # MI355X peak engine clock (same guide); the pair kernel runs at ~2.1 GHz
+# peaks from /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # HBM3E, spec (6.29 TB/s measured with a float4 copy)
+ENGINE_CLOCK_GHZ = 2.4      # peak engine clock; the pair kernel runs at ~2.1 GHz under load
+N_CU, SIMD_PER_CU = 256, 4
+L1_BYTES_PER_CLK_CU = 64.0  # a 16-byte-per-lane gather occupies the CU's vector L1 for 16 cycles (profiles/r01_gather_rate.txt)
+LDS_READ2_B32_BYTES_PER_CLK_CU = 128.0  # ds_read2_b32 / ds_read_b32: 128 B/clk/CU (the guide's LDS table)
+VALU_CYCLES_PER_WAVE_INSTR = 2.0        # wave64 fp32 instruction on a SIMD-32: 2 cycles (4 for cvt/fract/f64, not modelled)
 
 
 def parse():
@@ -40,14 +54,56 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
-    ap.add_argument("--exchange", default="shm", choices=["shm", "collective"],
+    ap.add_argument("--exchange", default="both", choices=["both", "shm", "collective"],
                     help="N > 1: per-evaluation sum of the partial results through the library's shared-memory "
-                         "exchange (default; falls back to the collective if /dev/shm is unusable) or an all-reduce")
+                         "exchange, an all-reduce of a device scalar, or (default) both, one after the other")
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="number of timed K-step blocks (0 = automatic: up to 9, about 1 s in total)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
                     help="CPU baseline evaluates all pairs among every k-th view")
     return ap.parse_args()
+
+
+def radon_fetches_per_image(n_u, n_v, n_alpha, n_t):
+    """Bilinear fetches of one derivative Radon intermediate: sum over bins of 2 * (#steps of `for t = t0; t <= t1;
+    t += 0.66f`), line clipping as in ref: RadonIntermediate.cu:44-99, evaluated in float32 numpy.  The step count is
+    taken as floor((t1 - t0) / 0.66) + 1 (the kernel's fp32 accumulation of t can differ by one step in rare bins;
+    checked against the oracle's exact count in tests/test_bench_helpers.py to 1e-3)."""
+    import numpy as np
+    f = np.float32
+    Pi = f(3.14159265359)
+    ix, iy = np.meshgrid(np.arange(n_alpha, dtype=np.float32), np.arange(n_t, dtype=np.float32))
+    alpha = (ix / f(n_alpha) - f(0.5)) * Pi
+    tau = (iy / f(n_t) - f(0.5)) * f(np.sqrt(f(n_u) * f(n_u) + f(n_v) * f(n_v)))
+    l0, l1 = -np.sin(alpha.astype(np.float64)).astype(np.float32), np.cos(alpha.astype(np.float64)).astype(np.float32)
+    l2 = -tau + (f(-0.5) * f(n_u) * l0 - f(0.5) * f(n_v) * l1)
+    o0, o1, d0, d1 = -l2 * l0, -l2 * l1, l1, -l0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ts = np.stack([(f(1) - o0) / d0, (f(n_u) - f(1) - o0) / d0, (f(1) - o1) / d1, (f(n_v) - f(1) - o1) / d1])
+    ax0, ax1 = d0 * d0 < f(1e-12), d1 * d1 < f(1e-12)
+    ts[0][ax0], ts[1][ax0], ts[2][ax1], ts[3][ax1] = -1e10, 1e10, -1e10, 1e10
+    ts = np.sort(ts, axis=0)
+    t0, t1 = ts[1], ts[2]
+    u, v = o0 + t0 * d0, o1 + t0 * d1
+    ok = (u <= n_u) & (v <= n_v) & (u >= 0) & (v >= 0) & (t1 > t0)
+    steps = np.where(ok, np.floor((t1 - t0).astype(np.float64) / float(f(0.66))) + 1, 0)
+    return int(2 * steps.sum())
+
+
+def load_pmc(kernel_prefix):
+    """Per-dispatch PMC averages of a kernel from profiles/pmc_current.json (made by scripts/pmc_summary_to_json.py
+    from separate rocprofv3 --pmc passes of this bench, see its `files`), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_current.json")
+    try:
+        d = json.load(open(path))
+        for name, c in d["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return dict(c, _tag=d.get("tag"), _files=d.get("files"))
+    except Exception:
+        pass
+    return None
 
 
 def n_kappa_auto(n_u, n_v, n_t):
@@ -152,7 +208,7 @@ def main():
 
     # N > 1: the per-evaluation exchange of the 8-byte partial sums
     exchange = None
-    if world > 1 and args.exchange == "shm":
+    if world > 1 and args.exchange in ("both", "shm"):
         ok = True
         try:
             exchange = sharding.open_exchange(rank, world, dist.barrier)
@@ -168,13 +224,15 @@ def main():
         elif abs(exchange.sum(float(rank + 1)) - world * (world + 1) / 2.0) > 1e-12:
             raise SystemExit("shared-memory exchange returned a wrong sum")
 
-    def step(k):
-        metric.setProjectionMatrices(poses[k % len(poses)])
-        if world == 1:
-            return metric.evaluate()
-        if exchange is not None:
-            return sharding.exchanged_evaluate(metric, n, exchange)
-        return sharding.distributed_evaluate(metric, n, sum_t, rank, world)
+    def make_step(mode):
+        def step(k):
+            metric.setProjectionMatrices(poses[k % len(poses)])
+            if world == 1:
+                return metric.evaluate()
+            if mode == "shm":
+                return sharding.exchanged_evaluate(metric, n, exchange)
+            return sharding.distributed_evaluate(metric, n, sum_t, rank, world)
+        return step
 
     def fence():
         torch.cuda.synchronize()
@@ -182,19 +240,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_block(step, k0):
+        """Exactly args.steps steps between two fences; seconds, MAX over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        last = None
+        for k in range(k0, k0 + args.steps):
+            last = step(k)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            e = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            el = e.item()
+        return el, last
+
+    def measure(mode):
+        """W warm-up steps, then blocks of K steps: the first is the cold number, the median the steady one."""
+        step = make_step(mode)
+        for k in range(args.warmup):
+            step(k)
+        blocks, last = [], None
+        el, last = timed_block(step, 0)
+        blocks.append(el)
+        n_blocks = args.blocks if args.blocks > 0 else int(min(9, max(3, 1.0 / max(el, 1e-6))))
+        if world > 1:  # every rank must run the same number of blocks
+            nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.broadcast(nb, 0)
+            n_blocks = int(nb.item())
+        for b in range(1, n_blocks):
+            el, last = timed_block(step, b * args.steps)
+            blocks.append(el)
+        steady = sorted(blocks)[len(blocks) // 2]
+        return dict(cold=blocks[0], steady=steady, blocks=blocks, last=last, step=step)
+
     ctx.enable_timing(False)  # no event records inside the timed region (they break back-to-back dispatch)
-    for k in range(args.warmup):
-        step(k)
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        last = step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        e = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        elapsed = e.item()
+    modes = ["single"] if world == 1 else (
+        [m for m in ("shm", "collective") if (m != "shm" or exchange is not None)] if args.exchange == "both"
+        else (["shm"] if args.exchange == "shm" and exchange is not None else ["collective"]))
+    results = {m: measure(m) for m in modes}
+    best = min(modes, key=lambda m: results[m]["steady"])
+    res = results[best]
+    elapsed, last, step = res["steady"], res["last"], res["step"]
     # pair-kernel duration: HIP events on the context's stream around the pair kernel alone, averaged over a
     # second, untimed pass over the same steps (at most 50)
     ctx.enable_timing(True)
@@ -204,11 +291,61 @@ def main():
         pair_ms += ctx.last_kernel_ms("pairs")
     fence()
     pair_ms /= n_timed
+    pair_s = pair_ms * 1e-3
 
     n_kappa = n_kappa_auto(S, S, B)
     bytes_per_pair = 64 * n_kappa + 68            # 2 views x 2 signs x 4 taps x 4 B + K01 + result
     launch_bytes = bytes_per_pair * count         # one launch = this rank's shard of pairs
-    achieved = launch_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+    achieved = launch_bytes / pair_s / 1e9 if pair_ms > 0 else 0.0
+    exch_name = {"single": "none", "shm": "host shared memory", "collective": "all-reduce (%s)" % args.backend}
+
+    # ---- which roof bounds the pair kernel -------------------------------------------------------------------
+    # The gather is served on chip (measured HBM traffic << algorithmic bytes), so the algorithmic bytes are priced
+    # against the roof they actually cross -- the CU's vector L1 -- and the kernel's instruction stream against the
+    # vector-ALU issue rate; `bound` is the roof with the larger fraction.  Instruction counts and HBM bytes per
+    # launch are PMC measurements (separate rocprofv3 --pmc passes of this bench, profiles/pmc_current.json); they
+    # are used only at N = 1 on the workload they were taken on.
+    l1_peak = L1_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ  # GB/s
+    roofs = {"l1": {"achieved": achieved, "peak": l1_peak, "unit": "GB/s", "frac": achieved / l1_peak,
+                    "note": "algorithmic gather bytes through the vector L1: %.0f B/clk/CU x %d CUs x %.1f GHz"
+                            % (L1_BYTES_PER_CLK_CU, N_CU, ENGINE_CLOCK_GHZ)}}
+    pmc = load_pmc("pairs_kernel<true, false>") if (world == 1 and (n, S, B) == (400, 1024, 768)) else None
+    traffic, traffic_src = None, None
+    if pmc and "SQ_INSTS_VALU" in pmc and pair_ms > 0:
+        valu_peak = N_CU * SIMD_PER_CU * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTR  # G wave-instructions/s
+        valu_ach = pmc["SQ_INSTS_VALU"] / pair_s / 1e9
+        roofs["valu"] = {"achieved": valu_ach, "peak": valu_peak, "unit": "G wave-instr/s", "frac": valu_ach / valu_peak,
+                         "note": "SQ_INSTS_VALU = %.4g per launch (PMC, %s) at %.0f cycles per wave64 instruction on %d SIMDs"
+                                 % (pmc["SQ_INSTS_VALU"], pmc["_tag"], VALU_CYCLES_PER_WAVE_INSTR, N_CU * SIMD_PER_CU)}
+    if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        traffic = int(2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024)
+        traffic_src = ("PMC, not this run: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 counts 128-B fabric reads as 64 B) "
+                       "from separate rocprofv3 --pmc passes of bench.py --steps 5, profiles/pmc_current.json (%s)" % pmc["_tag"])
+        roofs["hbm_measured"] = {"achieved": traffic / pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": traffic / pair_s / 1e9 / HBM_PEAK_GBS}
+    bound = max(roofs, key=lambda r: roofs[r]["frac"])
+    roofline = {"bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"],
+                "unit": roofs[bound]["unit"], "frac": roofs[bound]["frac"], "traffic": traffic,
+                "traffic_source": traffic_src, "kernel": "pairs_kernel<true, false>", "kernel_ms": pair_ms,
+                "algorithmic_bytes_per_launch": launch_bytes, "roofs": roofs,
+                # SURVEY.md 8(d)'s figure against HBM peak: > 1 means the gather's reuse is captured on chip
+                "hbm_algorithmic": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "reuse_factor_vs_hbm_peak": achieved / HBM_PEAK_GBS}}
+
+    # ---- second headline metric: ms per Radon intermediate ---------------------------------------------------
+    fetches = radon_fetches_per_image(S, S, B, B)
+    lds_peak = LDS_READ2_B32_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ
+    lds_ach = 16.0 * fetches / (ms_per_radon * 1e-3) / 1e9 if ms_per_radon > 0 else 0.0
+    roofline_radon = {"bound": "lds", "achieved": lds_ach, "peak": lds_peak, "unit": "GB/s", "frac": lds_ach / lds_peak,
+                      "kernel": "radon_kernel<true>", "kernel_ms_per_image": ms_per_radon,
+                      "algorithmic_bytes_per_image": 16 * fetches, "bilinear_fetches_per_image": fetches,
+                      "note": "16 B of LDS reads per bilinear fetch (2 x ds_read2_b32) against %.0f B/clk/CU x %d CUs x %.1f GHz; "
+                              "compulsory HBM bytes are 4 (n_u n_v + n_alpha n_t) = %.2f MB per image"
+                              % (LDS_READ2_B32_BYTES_PER_CLK_CU, N_CU, ENGINE_CLOCK_GHZ, 4e-6 * (S * S + B * B))}
+    rp = load_pmc("radon_kernel<true>") if (S, B) == (1024, 768) else None
+    if rp and rp.get("SQ_LDS_IDX_ACTIVE"):
+        roofline_radon["lds_bank_conflict_ratio"] = rp["SQ_LDS_BANK_CONFLICT"] / rp["SQ_LDS_IDX_ACTIVE"]
+        roofline_radon["pmc_source"] = "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/pmc_current.json (%s)" % rp["_tag"]
 
     out = {
         "metric": "ECC evaluations/sec (N=%d, %d^2 projections)" % (n, S),
@@ -226,36 +363,27 @@ def main():
         "config": {"workload": "%d-projection %dx%d circular short scan, %dx%d Radon bins, all %d pairs"
                                % (n, S, S, B, B, n_pairs),
                    "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d" % world,
-                   "sum_exchange": "none" if world == 1 else ("host shared memory" if exchange is not None
-                                                               else "all-reduce (%s)" % args.backend)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "pairs_kernel<true, false>", "kernel_ms": pair_ms,
-                     "algorithmic_bytes_per_launch": launch_bytes},
+                   "sum_exchange": exch_name[best]},
+        "timing": {"value_is": "median of %d blocks of %d steps" % (len(res["blocks"]), args.steps),
+                   "blocks_ms_per_step": [1e3 * b / args.steps for b in res["blocks"]],
+                   "cold": {"ms_per_step": 1e3 * res["cold"] / args.steps, "value": args.steps / res["cold"],
+                            "note": "first block after the %d warm-up steps" % args.warmup}},
+        "roofline": roofline,
+        "roofline_radon": roofline_radon,
         "ms_per_radon_intermediate": ms_per_radon,
         "ms_per_preprocess": ms_per_preprocess,
         "preprocess_hbm_GBs": 8.0 * S * S / (ms_per_preprocess * 1e-3) / 1e9 if ms_per_preprocess > 0 else 0.0,
         "pairs_per_s": n_pairs * args.steps / elapsed,
         "kappa_samples_per_s": n_pairs * n_kappa * args.steps / elapsed,
+        "non_pair_kernel_us_per_step": 1e3 * (1e3 * elapsed / args.steps - pair_ms),
         "last_value": last,
     }
-
-    # The gather is served on chip (traffic << algorithmic bytes), so the bandwidth that actually bounds the kernel is
-    # the L1's: 64 B/clk/CU (scripts/micro/gather_rate.hip); every algorithmic byte passes through it exactly once.
-    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    l1_peak = 64.0 * n_cu * ENGINE_CLOCK_GHZ  # GB/s
-    out["roofline"]["l1"] = {"achieved": achieved, "peak": l1_peak, "unit": "GB/s", "frac": achieved / l1_peak,
-                             "note": "64 B/clk/CU x %d CUs x %.1f GHz peak engine clock" % (n_cu, ENGINE_CLOCK_GHZ)}
-
-    # measured HBM traffic per launch (rocprofv3 PMC pass, committed under profiles/), if it matches
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            t = json.load(open(tfile))
-            if t.get("views") == n and t.get("size") == S and t.get("bins") == B and t.get("n_gpus", 1) == world:
-                out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+    for m in modes:
+        if m != best:
+            out["timing"]["other_exchange"] = {"sum_exchange": exch_name[m],
+                                               "ms_per_step": 1e3 * results[m]["steady"] / args.steps,
+                                               "value": args.steps / results[m]["steady"],
+                                               "cold_ms_per_step": 1e3 * results[m]["cold"] / args.steps}
 
     # ---- CPU baseline: the oracle timed on this box's host cores (rank 0, N = 1 only) -----------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

@@ -86,6 +86,20 @@ SIGNATURES = {
     "ecc_host_angular_step": (_d, [_vp, _vp, _i, _i]),
     "ecc_host_iso_center": (None, [_vp, _i, _vp]),
     "ecc_host_line_to_sample_dtr": (_i, [_vp, C.c_float]),
+    "ecc_group_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "ecc_group_destroy": (_i, [_vp]),
+    "ecc_group_size": (_i, [_vp]),
+    "ecc_group_ctx": (_i, [_vp, _i, C.POINTER(_vp)]),
+    "ecc_group_radon_compute_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_pair_shard": (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "ecc_group_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ecc_group_metric_destroy": (_i, [_vp]),
+    "ecc_group_metric_set_projections": (_i, [_vp, _vp, _i]),
+    "ecc_group_metric_set_params": (_i, [_vp, _d, _d, _i]),
+    "ecc_group_metric_set_sampling": (_i, [_vp, _i]),
+    "ecc_group_metric_get_object_radius": (_i, [_vp, _pd]),
+    "ecc_group_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
+    "ecc_group_metric_rank_metric": (_i, [_vp, _i, C.POINTER(_vp)]),
     "ecc_exchange_open": (_i, [C.c_char_p, _i, _i, C.POINTER(C.c_void_p)]),
     "ecc_exchange_sum": (_i, [_vp, _d, _pd]),
     "ecc_exchange_close": (_i, [_vp]),

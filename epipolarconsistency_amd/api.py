@@ -512,6 +512,149 @@ class MetricRadonIntermediate:
             pass
 
 
+class _BorrowedContext:
+    """A context owned by a Group (never destroyed from here)."""
+
+    def __init__(self, handle, device, group):
+        self._h, self.device, self._group = handle, device, group  # keeps the group (and so the context) alive
+
+    def synchronize(self):
+        check(_lib.lib().ecc_ctx_synchronize(self._h))
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+class Group:
+    """Single-process multi-GPU: one context, stream and host thread per device (ecc_group_* of the C ABI).
+    devices: list of HIP device indices (an index may repeat: rehearsal of the multi-rank path on one GPU)."""
+
+    def __init__(self, devices):
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        self._h = C.c_void_p()
+        check(_lib.lib().ecc_group_create(len(devices), arr, C.byref(self._h)))
+        self.devices = devices
+        self._ctxs = {}
+
+    def __len__(self):
+        return _lib.lib().ecc_group_size(self._h)
+
+    def context(self, rank):
+        if rank not in self._ctxs:
+            h = C.c_void_p()
+            check(_lib.lib().ecc_group_ctx(self._h, int(rank), C.byref(h)))
+            self._ctxs[rank] = _BorrowedContext(h, self.devices[rank], self)
+        return self._ctxs[rank]
+
+    def compute_batch(self, images, size_alpha, size_t, filter=FILTER_DERIVATIVE, post_process=POST_IDENTITY):
+        """Radon intermediates of host images (n, n_v, n_u), data-parallel over the group's devices."""
+        keep = np.ascontiguousarray(images, np.float32)
+        n, n_v, n_u = keep.shape
+        hs = (C.c_void_p * n)()
+        check(_lib.lib().ecc_group_radon_compute_batch(self._h, C.c_void_p(keep.ctypes.data), n, n_u, n_v, size_alpha,
+                                                       size_t, filter, post_process, hs))
+        chunk = (n + len(self.devices) - 1) // len(self.devices)
+        ctxs = [self.context(r) for r in range(len(self.devices))]
+        return [RadonIntermediate(ctxs[k // chunk], C.c_void_p(h)) for k, h in enumerate(hs)]
+
+    def close(self):
+        """Destroy group metrics and Radon intermediates made from the group's contexts first."""
+        if self._h:
+            for c in self._ctxs.values():
+                c.close()  # objects that still hold one of these contexts will not touch it any more
+            self._ctxs = {}
+            _lib.lib().ecc_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pair_shard(n_pairs, world, rank):
+    """ecc_pair_shard: (first, count) of `rank`'s contiguous chunk of the get_ij order."""
+    a, b = C.c_int64(), C.c_int64()
+    _lib.lib().ecc_pair_shard(int(n_pairs), int(world), int(rank), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class GroupMetricRadonIntermediate:
+    """MetricRadonIntermediate over a Group: the same setProjectionMatrices / evaluate calls, every device of the
+    group evaluating a contiguous shard of the pair range (ecc_group_metric_* of the C ABI)."""
+
+    def __init__(self, group, Ps=None, dtrs=None):
+        self.group = group
+        self._h = C.c_void_p()
+        self._dtrs = []
+        self._Ps = None
+        if dtrs is not None:
+            self.setRadonIntermediates(dtrs)
+        if Ps is not None:
+            self.setProjectionMatrices(Ps)
+
+    def setRadonIntermediates(self, dtrs):
+        self.close()
+        self._dtrs = list(dtrs)
+        hs = (C.c_void_p * len(self._dtrs))(*[d._h for d in self._dtrs])
+        check(_lib.lib().ecc_group_metric_create(self.group._h, len(self._dtrs), hs, C.byref(self._h)))
+        d = MetricRadonIntermediate.default_sampling
+        if d is not None:
+            self.setSampling(d)
+        if self._Ps is not None:
+            self.setProjectionMatrices(self._Ps)
+        return self
+
+    def setProjectionMatrices(self, Ps):
+        if isinstance(Ps, np.ndarray) and Ps.ndim == 2 and Ps.shape[1] == 12 and Ps.dtype == np.float64 \
+                and Ps.flags["C_CONTIGUOUS"]:
+            self._Ps = Ps
+        else:
+            self._Ps = _Ps_colmajor(Ps)
+        if self._h:
+            check(_lib.lib().ecc_group_metric_set_projections(self._h, C.c_void_p(self._Ps.ctypes.data), len(self._Ps)))
+        return self
+
+    def getNumberOfProjetions(self):  # sic
+        return 0 if self._Ps is None else len(self._Ps)
+
+    def setObjectRadius(self, radius_mm=0.0, dkappa=0.0, use_corr=False):
+        check(_lib.lib().ecc_group_metric_set_params(self._h, float(radius_mm), float(dkappa), 1 if use_corr else 0))
+        return self
+
+    def getObjectRadius(self):
+        r = C.c_double()
+        check(_lib.lib().ecc_group_metric_get_object_radius(self._h, C.byref(r)))
+        return r.value
+
+    def setSampling(self, mode="auto"):
+        mode = MetricRadonIntermediate._SAMPLING[mode] if isinstance(mode, str) else int(mode)
+        check(_lib.lib().ecc_group_metric_set_sampling(self._h, mode))
+        return self
+
+    def evaluate(self, cost=None):
+        mean = C.c_double()
+        if cost is not None:
+            n = self.getNumberOfProjetions()
+            assert cost.dtype == np.float32 and cost.flags["C_CONTIGUOUS"] and cost.shape == (n, n)
+        check(_lib.lib().ecc_group_metric_evaluate_all(self._h, C.c_void_p(cost.ctypes.data if cost is not None else 0),
+                                                       C.byref(mean)))
+        return mean.value
+
+    def close(self):
+        if self._h and self.group._h:
+            _lib.lib().ecc_group_metric_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MetricDirect:
     """ref: class MetricDirect : public Metric (EpipolarConsistencyDirect.h:28-60): epipolar consistency straight
     from the projection images.  images: (n, n_v, n_u) float32, numpy (uploaded, owned) or a torch tensor on ctx's

@@ -12,7 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libecc_hip.so")
-SOURCES = ["radon_kernel.hip", "ramp_kernel.hip", "preprocess_kernel.hip", "direct_kernel.hip", "pairs_kernel.hip", "geometry_kernel.hip", "ecc_capi.hip", "ecc_exchange.hip"]
+SOURCES = ["radon_kernel.hip", "ramp_kernel.hip", "preprocess_kernel.hip", "direct_kernel.hip", "pairs_kernel.hip", "geometry_kernel.hip", "ecc_capi.hip",
+           "ecc_exchange.cpp", "ecc_group.cpp"]  # .cpp: host-only code (no device code), still built by hipcc for the HIP headers
 HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", "ecc_sampling.h", os.path.join("..", "..", "include", "ecc_hip.h")]
 # radon_kernel.hip: the SLP vectoriser packs the two samples of the derivative pair into v_pk_*_f32 pairs, which
 # cost two issue slots each on gfx950 (no gain, scripts/micro/valu_rate.hip) plus ~12 v_mov per iteration to
@@ -36,13 +37,13 @@ def build_library(force=False, verbose=False, extra_flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for s in SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         cmd = [hipcc] + FLAGS + PER_SOURCE_FLAGS.get(s, []) + list(extra_flags) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lrt", "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-lrt", "-lpthread", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

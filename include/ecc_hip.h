@@ -296,6 +296,50 @@ double ecc_host_angular_step(const double* P0, const double* P1, int n_u, int n_
  * O receives 4 doubles (w = 1). */
 void ecc_host_iso_center(const double* Ps, int n_views, double* O);
 
+/* ---- single-process multi-GPU: a group of devices behind the same two calls ----------------------- */
+/* The reference's callers are one process, one optimiser thread: ecc->setProjectionMatrices(Ps); ecc->evaluate()
+ * (ref: Gui/SingleImageMotion.h:84-90, HeaderOnly/LibOpterix/WrapNLOpt.hxx:151-173).  A group gives such a caller
+ * every GPU of the node: one context, stream and host thread per device, the Radon-intermediate stack replicated on
+ * every device, the pair range cut into contiguous equal-count shards of the get_ij order (ecc_pair_shard), the
+ * partial sums (8 bytes per device, pinned host memory) added on the host in rank order -- the same bits on every
+ * call.  Nothing is exchanged between devices on the per-evaluation path.
+ * devices: n_dev HIP device indices (NULL = 0 .. n_dev-1).  An index may repeat: ranks on the same device get their
+ * own stream and thread and share the caller's slabs (rehearsal of the multi-rank path on one GPU). */
+typedef struct ecc_group ecc_group;
+typedef struct ecc_group_metric ecc_group_metric;
+int ecc_group_create(int n_dev, const int* devices, ecc_group** out);
+/* Destroy group metrics first, then dtrs made from the group's contexts, then the group. */
+int ecc_group_destroy(ecc_group* g);
+int ecc_group_size(const ecc_group* g);
+/* The context of one rank (borrowed): e.g. to produce Radon intermediates on that device yourself. */
+int ecc_group_ctx(ecc_group* g, int rank, ecc_ctx** ctx);
+/* Data-parallel form of ecc_radon_compute_batch for host images: rank r computes the contiguous chunk of views
+ * [r*ceil(n/G), ...) on its own device, all ranks concurrently.  out[k] lives on the device that computed it;
+ * ecc_group_metric_create replicates. */
+int ecc_group_radon_compute_batch(ecc_group* g, const float* images, int n, int n_u, int n_v, int n_alpha, int n_t,
+                                  int filter, int post_process, ecc_dtr** out);
+/* rank r of `world` evaluates pairs [first, first + count) of the get_ij order: first = r*n_pairs/world (integer). */
+void ecc_pair_shard(int64_t n_pairs, int world, int rank, int64_t* first, int64_t* count);
+
+/* ref: MetricRadonIntermediate(Ps, dtrs) (...RadonIntermediate.cpp:53-66,87-106) over a group.  dtrs may live on
+ * any devices; every rank gets a replica of the whole stack (device-to-device copies, peer access where available;
+ * a rank whose device already holds all of them borrows them instead) and its own ecc_metric.  Same borrowing
+ * contract as ecc_metric_create. */
+int ecc_group_metric_create(ecc_group* g, int n_dtrs, ecc_dtr* const* dtrs, ecc_group_metric** out);
+int ecc_group_metric_destroy(ecc_group_metric* gm);
+/* ref: setProjectionMatrices.  The matrices are copied and handed to the devices together with the next
+ * evaluation (one hand-off to the rank threads per optimiser step). */
+int ecc_group_metric_set_projections(ecc_group_metric* gm, const double* Ps, int n_views);
+int ecc_group_metric_set_params(ecc_group_metric* gm, double object_radius_mm, double dkappa, int use_corr);
+int ecc_group_metric_set_sampling(ecc_group_metric* gm, int mode);
+int ecc_group_metric_get_object_radius(ecc_group_metric* gm, double* radius_mm);
+/* ref: double MetricRadonIntermediate::evaluate(float* out): all pairs, sharded over the group; *mean = sum/n_pairs.
+ * cost_nxn (host, nullable): entry (i,j), i<j at index i + j*n is written, the rest preserved.  With one rank the
+ * result is bit-identical to ecc_metric_evaluate_all; with G ranks it is the rank-ordered float64 sum of G shard sums. */
+int ecc_group_metric_evaluate_all(ecc_group_metric* gm, float* cost_nxn, double* mean);
+/* The per-rank metric (borrowed; debugging and tests). */
+int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m);
+
 /* ---- multi-process sum of the partial results (one process per GPU, one node) ------------------ */
 /* The path's only exchange step is the final sum over pairs (ref: ...RadonIntermediate.cpp:216-224; SURVEY.md 8e:
  * "one all-reduce of 2 doubles per evaluation -- latency-bound").  ecc_metric_evaluate_range leaves each rank's

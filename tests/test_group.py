@@ -1,0 +1,96 @@
+"""Single-process multi-GPU group (ecc_group_* of the C ABI; BASELINE config 4's partitioning).
+
+CPU: the shard arithmetic.  GPU (one device on the test box): a 1-rank group equals ecc_metric_evaluate_all bit for
+bit; 2 and 3 ranks on the SAME device (own stream + host thread each) exercise the threaded multi-rank path: rank-order
+sum of the shard sums, cost image assembled from the shards, data-parallel Radon intermediates, errors from a worker
+thread reaching the caller."""
+import numpy as np
+import pytest
+
+
+def test_pair_shard_arithmetic():
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import sharding
+    for n_pairs in (0, 1, 7, 2016, 79800, 79801):
+        for world in (1, 2, 3, 8, 64):
+            nxt = 0
+            for r in range(world):
+                first, count = E.pair_shard(n_pairs, world, r)
+                assert (first, count) == sharding.pair_range(r, world, n_pairs)
+                assert first == nxt and count >= 0
+                nxt = first + count
+            assert nxt == n_pairs
+            counts = [E.pair_shard(n_pairs, world, r)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+    assert E.pair_shard(79800, 8, 3) == (29925, 9975)  # BASELINE config 4: 9 975 pairs per GPU
+
+
+@pytest.mark.gpu
+def test_one_rank_group_is_the_plain_metric(gpu_ctx, small_scan):
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    g = E.Group([0])
+    assert len(g) == 1
+    gm = E.GroupMetricRadonIntermediate(g, s["Ps"], dtrs)
+    cost_a, cost_b = np.full((8, 8), 3.0, np.float32), np.full((8, 8), 3.0, np.float32)
+    a, b = m.evaluate(cost_a), gm.evaluate(cost_b)
+    assert a == b and np.array_equal(cost_a, cost_b)
+    assert gm.getObjectRadius() == m.getObjectRadius()
+    moved = list(s["Ps"])
+    moved[3] = moved[3] @ E.geometry.rigid_transform(tx=1.0, ry=0.02)
+    assert gm.setProjectionMatrices(moved).evaluate() == m.setProjectionMatrices(moved).evaluate() != a
+    gm.close()
+    g.close()
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_multi_rank_group_on_one_device(gpu_ctx, oracle_mod, small_scan, ranks):
+    import epipolarconsistency_amd as E
+    s = small_scan
+    g = E.Group([0] * ranks)
+    # data-parallel Radon intermediates: bit-exact like the single-context path
+    dtrs = g.compute_batch(s["imgs"], s["n_alpha"], s["n_t"])
+    for k in (0, 2, 5, 7):
+        assert np.array_equal(dtrs[k].readback(), s["dtrs"][k])
+    gm = E.GroupMetricRadonIntermediate(g, s["Ps"], dtrs)
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"])
+                                                     for d in s["dtrs"]])
+    total, vals = m.evaluate_range(0, 28, want_pairs=True)
+    parts = [m.evaluate_range(*E.pair_shard(28, ranks, r)) for r in range(ranks)]
+    cost = np.full((8, 8), -1.0, np.float32)
+    mean = gm.evaluate(cost)
+    acc = 0.0
+    for p in parts:
+        acc += p
+    assert mean == acc / 28  # rank-order float64 sum of the shard sums
+    assert abs(mean - total / 28) <= 1e-13 * mean
+    iu = np.triu_indices(8, 1)
+    assert np.array_equal(cost[iu[1], iu[0]], vals) and np.all(cost[iu] == -1.0) and np.all(np.diag(cost) == -1.0)
+    want = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"])
+    assert abs(mean - want["mean"]) <= 1e-5 * want["mean"]
+    # repeated evaluations (the worker threads go to sleep in between and are woken again), same bits
+    import time
+    for pause in (0.0, 0.0, 0.05):
+        time.sleep(pause)
+        assert gm.evaluate() == mean
+    # parameters and sampling mode reach every rank
+    gm.setSampling("reference")
+    assert abs(gm.evaluate() - want["mean"]) <= 1e-7 * want["mean"]
+    gm.setSampling("polynomial").setObjectRadius(25.0, 0.004)
+    want2 = oracle_mod.evaluate_all(s["Ps"], s["dtrs"], s["n_u"], s["n_v"], object_radius_mm=25.0, dkappa=0.004)
+    assert abs(gm.evaluate() - want2["mean"]) <= 1e-5 * want2["mean"]
+    # an error raised on a worker thread reaches the caller with its message
+    with pytest.raises(E.EccError) as ei:
+        gm.setProjectionMatrices(s["Ps"] + s["Ps"]).evaluate()  # 16 matrices, 8 dtrs
+    assert "fewer Radon intermediates" in str(ei.value)
+    gm.setProjectionMatrices(s["Ps"])
+    gm.setObjectRadius(0.0, 0.0)
+    assert gm.evaluate() == mean
+    gm.close()
+    m.close()
+    del dtrs
+    g.close()
