@@ -12,8 +12,16 @@
 // LibUtilsCuda; nothing else changes.  With Eigen on the include path Geometry::ProjectionMatrix is
 // the reference's Eigen::Matrix<double,3,4>; without it a 12-double column-major stand-in with the
 // same .data() contract is used (that is what this repository's tests compile, Eigen is not
-// installed here).  Images are taken as (pointer, width, height); an overload for the reference's
-// NRRD::ImageView<float> is enabled when <NRRD/nrrd_image_view.hxx> is on the include path.
+// installed here).  Images are taken as (pointer, width, height); with the reference's header-only NRRD
+// library on the include path (-I<reference>/code/HeaderOnly) the reference's own NRRD-typed signatures are
+// there as well: RadonIntermediate(const NRRD::ImageView<float>&, ...), RadonIntermediate(const std::string path),
+// RadonIntermediate(const NRRD::ImageView<float>&), readPropertiesFromMeta, replaceRadonIntermediateData(view),
+// and data() returns NRRD::ImageView<float>& (ref: RadonIntermediate.h:31-41,47,53,80-83); compiled by
+// tests/test_cpp_adapter.py against the reference headers where they lie.
+//
+// Multi-GPU without touching the callers: a process-wide default group (setDefaultDevices(), or the environment
+// variable ECC_HIP_DEVICES = "0,1,2,3" / "all") makes every MetricRadonIntermediate shard its all-pairs evaluate()
+// over those devices (ecc_group_* of the C ABI); index-list / subset / single-pair calls stay on the first device.
 //
 // Error behaviour: the reference prints and exit()s on any CUDA error (LibUtilsCuda/UtilsCuda.hxx:14-28);
 // the adapter throws std::runtime_error with ecc_last_error() instead.
@@ -23,6 +31,8 @@
 #define ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
 
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <set>
 #include <stdexcept>
@@ -37,8 +47,8 @@
 #include <Eigen/Core>
 #define ECC_ADAPTER_HAVE_EIGEN 1
 #endif
-#if __has_include(<NRRD/nrrd_image_view.hxx>)
-#include <NRRD/nrrd_image_view.hxx>
+#if __has_include(<NRRD/nrrd_image.hxx>)
+#include <NRRD/nrrd_image.hxx>  // the reference's header-only NRRD library (ImageView, Image, load/save)
 #define ECC_ADAPTER_HAVE_NRRD 1
 #endif
 #endif
@@ -68,14 +78,57 @@ inline void check(int rc)
 {
     if (rc != ECC_OK) throw std::runtime_error(std::string("libecc_hip: ") + ecc_last_error());
 }
-/// One context per (device, stream); the reference uses the current device's default stream.
+/// Process-wide default group (null: single device).  Set by setDefaultDevices() or, on first use, from the
+/// environment variable ECC_HIP_DEVICES ("0,1,2,3" or "all").
+inline ecc_group*& default_group_slot()
+{
+    static ecc_group* g = nullptr;
+    return g;
+}
+inline ecc_group* default_group()
+{
+    static bool env_checked = false;
+    ecc_group*& g = default_group_slot();
+    if (!g && !env_checked) {
+        env_checked = true;
+        const char* e = std::getenv("ECC_HIP_DEVICES");
+        if (e && *e) {
+            std::vector<int> devs;
+            if (std::strcmp(e, "all") == 0) {
+                for (int d = 0; d < ecc_device_count(); ++d) devs.push_back(d);
+            } else {
+                for (const char* p = e; *p;) {
+                    devs.push_back(std::atoi(p));
+                    while (*p && *p != ',') ++p;
+                    if (*p == ',') ++p;
+                }
+            }
+            if (devs.size() > 1) check(ecc_group_create((int)devs.size(), devs.data(), &g));
+        }
+    }
+    return g;
+}
+/// One context per (device, stream); the reference uses the current device's default stream.  With a default group
+/// this is the group's first context, so that dtrs and the group's rank 0 share a device and a stream.
 inline ecc_ctx* default_context()
 {
     static ecc_ctx* ctx = nullptr;
-    if (!ctx) check(ecc_ctx_create(0, nullptr, &ctx));
+    if (!ctx) {
+        if (ecc_group* g = default_group()) check(ecc_group_ctx(g, 0, &ctx));
+        else check(ecc_ctx_create(0, nullptr, &ctx));
+    }
     return ctx;
 }
 }  // namespace detail
+
+/// Not in the reference: evaluate() of every MetricRadonIntermediate created afterwards is sharded over these HIP
+/// devices (one host thread per device inside the library).  Call before the first dtr / metric is created.
+inline void setDefaultDevices(const std::vector<int>& devices)
+{
+    ecc_group*& g = detail::default_group_slot();
+    if (g) throw std::runtime_error("setDefaultDevices: a default group exists already");
+    if (devices.size() > 1) detail::check(ecc_group_create((int)devices.size(), devices.data(), &g));
+}
 
 /// ref: class RadonIntermediate
 class RadonIntermediate {
@@ -92,11 +145,55 @@ public:
                                         size_t, (int)filter, (int)post_process, &m_h));
     }
 #ifdef ECC_ADAPTER_HAVE_NRRD
+    /// ref: RadonIntermediate(const NRRD::ImageView<float>& projectionData, size_alpha, size_t, filter, post_process)
+    /// (RadonIntermediate.h:31, .cpp:17-31)
     RadonIntermediate(const NRRD::ImageView<float>& projectionData, int size_alpha, int size_t, Filter filter,
                       PostProcess post_process)
         : RadonIntermediate((const float*)projectionData, projectionData.size(0), projectionData.size(1), size_alpha,
                             size_t, filter, post_process)
     {
+    }
+    /// ref: RadonIntermediate(const std::string path) (RadonIntermediate.h:37, .cpp:47-67): a dtr NRRD file written
+    /// by the reference's tools or by save(); size and filter come from its meta info (readPropertiesFromMeta).
+    /// Like the reference, a file that cannot be read leaves an invalid object (message on stderr).
+    explicit RadonIntermediate(const std::string path) : m_h(nullptr)
+    {
+        if (!m_raw_cpu.load(path) || !m_raw_cpu) {
+            std::cerr << "Failed to load " << path << std::endl;
+            return;
+        }
+        upload_raw_cpu(m_raw_cpu.meta_info);
+    }
+    /// ref: RadonIntermediate(const NRRD::ImageView<float>& radon_intermediate_image) (RadonIntermediate.h:40,
+    /// .cpp:69-80): existing dtr data in host memory, size(0) = angle bins (fast), size(1) = distance bins; original
+    /// image size and filter from its meta_info.
+    explicit RadonIntermediate(const NRRD::ImageView<float>& radon_intermediate_image) : m_h(nullptr)
+    {
+        replaceRadonIntermediateData(radon_intermediate_image);
+    }
+    /// ref: readPropertiesFromMeta (RadonIntermediate.h:47, .cpp:82-93).  The bin sizes are functions of the bin
+    /// counts and the original image size here (ecc_dtr_info), so only size and filter are taken from the dictionary;
+    /// the device copy is re-created with them.
+    void readPropertiesFromMeta(std::map<std::string, std::string> dict)
+    {
+        if (m_raw_cpu.size(0) < 1) readback();
+        upload_raw_cpu(dict);
+    }
+    /// ref: replaceRadonIntermediateData(const NRRD::ImageView<float>&) (RadonIntermediate.h:53, .cpp:105-123)
+    void replaceRadonIntermediateData(const NRRD::ImageView<float>& radon_intermediate_image)
+    {
+        m_raw_cpu.clone(radon_intermediate_image);
+        upload_raw_cpu(radon_intermediate_image.meta_info);
+    }
+    /// ref: data() (RadonIntermediate.h:80-83): the host copy made by readback() (may be an invalid image).
+    NRRD::ImageView<float>& data() { return m_raw_cpu; }
+    const NRRD::ImageView<float>& data() const { return m_raw_cpu; }
+    /// Save like the reference's tools do (Gui/ComputeRadonIntermediate.hxx:77-83): readback, meta info, NRRD file.
+    bool save(const std::string& path)
+    {
+        readback();
+        writePropertiesToMeta(m_raw_cpu.meta_info);
+        return m_raw_cpu.save(path);
     }
 #endif
     /// ref: RadonIntermediate(const NRRD::ImageView<float>& radon_intermediate_image): existing dtr data,
@@ -124,11 +221,13 @@ public:
     void readback(bool /*gpu_memory_only*/ = false)
     {
         Info i = info();
-        m_raw_cpu.resize((size_t)i.n_alpha * i.n_t);
-        detail::check(ecc_dtr_readback(m_h, m_raw_cpu.data()));
+        host_resize(i.n_alpha, i.n_t);
+        detail::check(ecc_dtr_readback(m_h, host_ptr()));
     }
+#ifndef ECC_ADAPTER_HAVE_NRRD
     const std::vector<float>& data() const { return m_raw_cpu; }
-    void clearRawData() { std::vector<float>().swap(m_raw_cpu); }
+#endif
+    void clearRawData() { host_resize(0, 0); }
 
     /// ref: replaceRadonIntermediateData(image) (RadonIntermediate.cpp:105-123): new data from host memory, n_t rows x
     /// n_alpha columns; original image size and filter are kept.  A metric that already holds this object must be
@@ -141,7 +240,8 @@ public:
                                         i.n_v, i.filter, &fresh));
         ecc_dtr_destroy(m_h);
         m_h = fresh;
-        m_raw_cpu.assign(radon_intermediate_image, radon_intermediate_image + (size_t)n_alpha * n_t);
+        host_resize(n_alpha, n_t);
+        std::memcpy(host_ptr(), radon_intermediate_image, sizeof(float) * (size_t)n_alpha * n_t);
     }
 
     /// ref: tex2D(s, t) (RadonIntermediate.h:108): host sample of the read-back data in texture coordinates [0,1]^2,
@@ -150,7 +250,10 @@ public:
     float tex2D(float s, float t) const
     {
         Info i = info();
-        if (m_raw_cpu.size() != (size_t)i.n_alpha * i.n_t) throw std::runtime_error("RadonIntermediate::tex2D: call readback() first");
+        if (host_length() != (size_t)i.n_alpha * i.n_t) throw std::runtime_error("RadonIntermediate::tex2D: call readback() first");
+#ifdef ECC_ADAPTER_HAVE_NRRD
+        return (float)m_raw_cpu((i.n_alpha - 1) * s, (i.n_t - 1) * t);  // the reference's expression (RadonIntermediate.h:108)
+#endif
         double x = (i.n_alpha - 1) * (double)s, y = (i.n_t - 1) * (double)t;
         int ix = (int)x, iy = (int)y;
         double fx = x - ix, fy = y - iy;
@@ -158,7 +261,7 @@ public:
         if (ix > i.n_alpha - 2) { ix = i.n_alpha - 2; fx = 1.0; }
         if (iy < 0) { iy = 0; fy = 0; }
         if (iy > i.n_t - 2) { iy = i.n_t - 2; fy = 1.0; }
-        const float* I = m_raw_cpu.data();
+        const float* I = host_ptr();
         const size_t w = (size_t)i.n_alpha;
         if (fx == 0 && fy == 0) return I[ix + iy * w];
         return (float)((1.0 - fy) * ((1.0 - fx) * I[ix + iy * w] + fx * I[ix + 1 + iy * w]) +
@@ -207,7 +310,32 @@ private:
         return i;
     }
     ecc_dtr* m_h;
+#ifdef ECC_ADAPTER_HAVE_NRRD
+    NRRD::Image<float> m_raw_cpu;  // ref: RadonIntermediate.h:111
+    void host_resize(int n_alpha, int n_t)
+    {
+        if (n_alpha < 1 || n_t < 1) m_raw_cpu.set(0, 0, 0);
+        else if (m_raw_cpu.size(0) != n_alpha || m_raw_cpu.size(1) != n_t) m_raw_cpu.set(n_alpha, n_t);
+    }
+    float* host_ptr() const { return (float*)m_raw_cpu; }
+    size_t host_length() const { return !m_raw_cpu ? 0 : (size_t)m_raw_cpu.length(); }
+    /// (re)creates the device copy from m_raw_cpu with size / filter taken from a meta dictionary
+    void upload_raw_cpu(std::map<std::string, std::string> dict)
+    {
+        const int n_x = stringTo<int>(dict["Original Image/Width"]), n_y = stringTo<int>(dict["Original Image/Height"]);
+        const Filter f = dict["Filter"] == "Ramp" ? Ramp : (dict["Filter"] == "Derivative" ? Derivative : None);
+        ecc_dtr* fresh = nullptr;
+        detail::check(ecc_dtr_from_host(detail::default_context(), host_ptr(), m_raw_cpu.size(0), m_raw_cpu.size(1), n_x, n_y,
+                                        (int)f, &fresh));
+        ecc_dtr_destroy(m_h);
+        m_h = fresh;
+    }
+#else
     std::vector<float> m_raw_cpu;
+    void host_resize(int n_alpha, int n_t) { std::vector<float>((size_t)(n_alpha > 0 ? n_alpha : 0) * (n_t > 0 ? n_t : 0)).swap(m_raw_cpu); }
+    float* host_ptr() const { return const_cast<float*>(m_raw_cpu.data()); }
+    size_t host_length() const { return m_raw_cpu.size(); }
+#endif
 };
 
 /// ref: class Metric (interface)
@@ -233,42 +361,83 @@ public:
 class MetricRadonIntermediate : public Metric {
     std::vector<RadonIntermediate*> dtrs;
     bool use_corr;
-    ecc_metric* m_h;
+    int sampling;
+    ecc_metric* m_h;          // single-device metric, or the group's rank-0 metric (borrowed) when m_gh is set
+    ecc_group_metric* m_gh;   // sharded over a group of devices (ecc_group_*), else null
     ecc_ctx* m_ctx;
+    ecc_group* m_group;
 
-    void push_params() { if (m_h) detail::check(ecc_metric_set_params(m_h, object_radius_mm, dkappa, use_corr ? 1 : 0)); }
+    void push_params()
+    {
+        if (m_gh) {
+            detail::check(ecc_group_metric_set_params(m_gh, object_radius_mm, dkappa, use_corr ? 1 : 0));
+            detail::check(ecc_group_metric_set_sampling(m_gh, sampling));
+        } else if (m_h) {
+            detail::check(ecc_metric_set_params(m_h, object_radius_mm, dkappa, use_corr ? 1 : 0));
+            detail::check(ecc_metric_set_sampling(m_h, sampling));
+        }
+    }
     void push_projections()
     {
-        if (!m_h || Ps.empty()) return;
+        if ((!m_h && !m_gh) || Ps.empty()) return;
         std::vector<double> flat(12 * Ps.size());
         for (size_t i = 0; i < Ps.size(); ++i)
             for (int k = 0; k < 12; ++k) flat[12 * i + k] = Ps[i].data()[k];
-        detail::check(ecc_metric_set_projections(m_h, flat.data(), (int)Ps.size()));
+        if (m_gh) detail::check(ecc_group_metric_set_projections(m_gh, flat.data(), (int)Ps.size()));
+        else detail::check(ecc_metric_set_projections(m_h, flat.data(), (int)Ps.size()));
+    }
+    /// the metric that serves the few-pair calls: with a group, rank 0's (the call also hands over pending matrices)
+    ecc_metric* single()
+    {
+        if (m_gh) detail::check(ecc_group_metric_rank_metric(m_gh, 0, &m_h));
+        return m_h;
+    }
+    void destroy()
+    {
+        if (m_gh) ecc_group_metric_destroy(m_gh);
+        else ecc_metric_destroy(m_h);
+        m_gh = nullptr;
+        m_h = nullptr;
     }
 
 public:
-    explicit MetricRadonIntermediate(ecc_ctx* ctx = nullptr) : use_corr(false), m_h(nullptr), m_ctx(ctx) {}
+    explicit MetricRadonIntermediate(ecc_ctx* ctx = nullptr)
+        : use_corr(false), sampling(ECC_SAMPLING_AUTO), m_h(nullptr), m_gh(nullptr), m_ctx(ctx), m_group(nullptr)
+    {
+    }
+    /// ref: MetricRadonIntermediate(Ps, dtrs) (.h:31).  ctx: a context other than the process-wide default one.
     MetricRadonIntermediate(const std::vector<ProjectionMatrix>& _Ps, const std::vector<RadonIntermediate*>& _dtrs,
                             ecc_ctx* ctx = nullptr)
-        : use_corr(false), m_h(nullptr), m_ctx(ctx)
+        : use_corr(false), sampling(ECC_SAMPLING_AUTO), m_h(nullptr), m_gh(nullptr), m_ctx(ctx), m_group(nullptr)
     {
         setProjectionMatrices(_Ps);
         setRadonIntermediates(_dtrs);
     }
-    ~MetricRadonIntermediate() { ecc_metric_destroy(m_h); }
+    /// Same over an explicit group of devices (not in the reference): evaluate() is sharded over the group.
+    MetricRadonIntermediate(const std::vector<ProjectionMatrix>& _Ps, const std::vector<RadonIntermediate*>& _dtrs,
+                            ecc_group* group)
+        : use_corr(false), sampling(ECC_SAMPLING_AUTO), m_h(nullptr), m_gh(nullptr), m_ctx(nullptr), m_group(group)
+    {
+        setProjectionMatrices(_Ps);
+        setRadonIntermediates(_dtrs);
+    }
+    ~MetricRadonIntermediate() { destroy(); }
 
     MetricRadonIntermediate& setdKappa(float _dkappa) { dkappa = _dkappa; push_params(); return *this; }
     MetricRadonIntermediate& useCorrelation(bool corr = true) { use_corr = corr; push_params(); return *this; }
+    /// Not in the reference: ECC_SAMPLING_* of the C ABI (default ECC_SAMPLING_AUTO).
+    MetricRadonIntermediate& setSampling(int mode) { sampling = mode; push_params(); return *this; }
 
     /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
     MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)
     {
         dtrs = _dtrs;
-        ecc_metric_destroy(m_h);
-        m_h = nullptr;
+        destroy();
         std::vector<ecc_dtr*> hs(dtrs.size());
         for (size_t i = 0; i < dtrs.size(); ++i) hs[i] = dtrs[i]->handle();
-        detail::check(ecc_metric_create(m_ctx ? m_ctx : detail::default_context(), (int)hs.size(), hs.data(), &m_h));
+        ecc_group* group = m_group ? m_group : (m_ctx ? nullptr : detail::default_group());
+        if (group) detail::check(ecc_group_metric_create(group, (int)hs.size(), hs.data(), &m_gh));
+        else detail::check(ecc_metric_create(m_ctx ? m_ctx : detail::default_context(), (int)hs.size(), hs.data(), &m_h));
         push_params();
         push_projections();
         return *this;
@@ -280,7 +449,8 @@ public:
     virtual double getObjectRadius() const
     {
         double r = 0;
-        if (m_h) detail::check(ecc_metric_get_object_radius(m_h, &r));
+        if (m_gh) detail::check(ecc_group_metric_get_object_radius(m_gh, &r));
+        else if (m_h) detail::check(ecc_metric_get_object_radius(m_h, &r));
         return r;
     }
 
@@ -297,7 +467,8 @@ public:
     virtual double evaluate(float* out = 0x0)
     {
         double mean = 0;
-        detail::check(ecc_metric_evaluate_all(m_h, out, &mean));
+        if (m_gh) detail::check(ecc_group_metric_evaluate_all(m_gh, out, &mean));
+        else detail::check(ecc_metric_evaluate_all(m_h, out, &mean));
         return mean;
     }
 
@@ -328,7 +499,7 @@ public:
     double evaluate_indices(const int32_t* idx4, int n_pairs, float* _out)
     {
         double mean = 0;
-        detail::check(ecc_metric_evaluate_pairs(m_h, idx4, n_pairs, _out, &mean));
+        detail::check(ecc_metric_evaluate_pairs(single(), idx4, n_pairs, _out, &mean));
         return mean;
     }
 
@@ -346,7 +517,7 @@ public:
                                 std::vector<std::pair<float, float> >* radon_samples1)
     {
         int cap = 0, n = 0;
-        detail::check(ecc_metric_pair_samples_bound(m_h, &cap));
+        detail::check(ecc_metric_pair_samples_bound(single(), &cap));
         std::vector<float> s0(cap), s1(cap), kp(cap), r0(2 * (size_t)cap), r1(2 * (size_t)cap);
         double ecc = 0;
         detail::check(ecc_metric_evaluate_for_image_pair(m_h, i, j, cap, &n, s0.data(), s1.data(), kp.data(), r0.data(),

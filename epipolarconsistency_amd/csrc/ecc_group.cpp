@@ -383,13 +383,6 @@ ECC_EXPORT int ecc_group_metric_create(ecc_group* g, int n_dtrs, ecc_dtr* const*
     return ECC_OK;
 }
 
-ECC_EXPORT int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m)
-{
-    if (!gm || !m || rank < 0 || rank >= gm->g->size()) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "bad group metric / rank");
-    *m = gm->metrics[rank];
-    return ECC_OK;
-}
-
 ECC_EXPORT int ecc_group_metric_set_params(ecc_group_metric* gm, double object_radius_mm, double dkappa, int use_corr)
 {
     if (!gm) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "group metric is null");
@@ -422,6 +415,15 @@ int flush_projections(ecc_group_metric* gm)
     return rc;
 }
 }  // namespace
+
+ECC_EXPORT int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m)
+{
+    if (!gm || !m || rank < 0 || rank >= gm->g->size()) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "bad group metric / rank");
+    const int rc = flush_projections(gm);  // the rank's metric is about to be used directly: hand over pending matrices
+    if (rc != ECC_OK) return rc;
+    *m = gm->metrics[rank];
+    return ECC_OK;
+}
 
 ECC_EXPORT int ecc_group_metric_get_object_radius(ecc_group_metric* gm, double* radius_mm)
 {

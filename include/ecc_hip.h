@@ -337,7 +337,8 @@ int ecc_group_metric_get_object_radius(ecc_group_metric* gm, double* radius_mm);
  * cost_nxn (host, nullable): entry (i,j), i<j at index i + j*n is written, the rest preserved.  With one rank the
  * result is bit-identical to ecc_metric_evaluate_all; with G ranks it is the rank-ordered float64 sum of G shard sums. */
 int ecc_group_metric_evaluate_all(ecc_group_metric* gm, float* cost_nxn, double* mean);
-/* The per-rank metric (borrowed; debugging and tests). */
+/* The per-rank metric (borrowed): few-pair calls (index lists, evaluateForImagePair) go to rank 0's metric.  Pending
+ * projection matrices are handed to the devices first. */
 int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m);
 
 /* ---- multi-process sum of the partial results (one process per GPU, one node) ------------------ */

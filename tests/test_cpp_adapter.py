@@ -27,6 +27,72 @@ def test_adapter_compiles_and_links(tmp_path):
     assert subprocess.run([exe]).returncode == 2
 
 
+REF_HEADERS = "/root/reference/code/HeaderOnly"
+NRRD_EXE = os.path.join(ROOT, "oracle", "_ref", "test_adapter_nrrd")
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_HEADERS), reason="reference tree not present (GPU box): compile-time check only")
+def test_adapter_nrrd_signatures_compile_against_reference_headers():
+    """ECC_ADAPTER_HAVE_NRRD: the reference's own NRRD-typed signatures (ref: RadonIntermediate.h:31-41,47,53,80-83)
+    compile and link against the reference's header-only NRRD library where it lies (nothing copied); -Werror on the
+    adapter itself is held by the non-NRRD build above (the reference headers have warnings of their own)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "adapter_nrrd"], check=True)
+    assert os.path.exists(NRRD_EXE)
+    assert subprocess.run([NRRD_EXE]).returncode == 2  # usage: touches no device
+    # the two adapter flavours are both syntactically valid with all warnings on for OUR header
+    src = '#include "EpipolarConsistencyHip.hxx"\nint main() { return 0; }\n'
+    for inc in ([], ["-isystem", REF_HEADERS]):
+        r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                            "-I" + os.path.join(PKG, "cpp")] + inc + ["-x", "c++", "-"], input=src, text=True,
+                           capture_output=True)
+        assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_nrrd_paths(tmp_path, oracle_mod, small_scan):
+    """The NRRD-typed adapter calls on the GPU: the binary was built where the reference headers are
+    (oracle/Makefile adapter_nrrd -> oracle/_ref/, travels like the other built artefacts)."""
+    if not os.path.exists(NRRD_EXE):
+        pytest.skip("oracle/_ref/test_adapter_nrrd was not built (needs the reference tree at build time)")
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import nrrd
+    s = small_scan
+    img = np.ascontiguousarray(s["imgs"][2], np.float32)
+    ipath, ppath = os.path.join(tmp_path, "img.nrrd"), os.path.join(tmp_path, "py_dtr.nrrd")
+    nrrd.write(ipath, img)
+    plain = oracle_mod.radon(img, 64, 48, filter=2)
+    nrrd.write_dtr(ppath, plain, s["n_u"], s["n_v"], E.FILTER_NONE)
+    out = subprocess.run([NRRD_EXE, ipath, str(s["n_alpha"]), str(s["n_t"]), ppath, str(tmp_path)], check=True,
+                         capture_output=True, text=True).stdout
+    val = {k: v.split() for k, v in re.findall(r"^(\w+) (.*)$", out, flags=re.M)}
+    want = s["dtrs"][2]
+    flat = want.reshape(-1)
+    assert [int(v) for v in val["computed"][:4]] == [s["n_alpha"], s["n_t"], s["n_u"], s["n_v"]]
+    assert np.float32(val["computed"][4]) == flat[1234 % flat.size]
+    assert [int(v) for v in val["reloaded"][:5]] == [s["n_alpha"], s["n_t"], s["n_u"], s["n_v"], 0]
+    assert np.float32(val["reloaded"][5]) == flat[1234 % flat.size]
+    assert [int(v) for v in val["python"][:5]] == [64, 48, s["n_u"], s["n_v"], 2] and np.float32(val["python"][5]) == plain.reshape(-1)[77]
+    # the file the adapter wrote reads back through the Python NRRD reader with the reference's meta keys
+    data, info = nrrd.read_dtr(os.path.join(tmp_path, "adapter_saved.nrrd"))
+    assert np.array_equal(data, want) and info["n_u"] == s["n_u"] and info["filter"] == E.FILTER_DERIVATIVE
+    # host sampling through NRRD::ImageView's own operator() equals the Python mirror of it
+    ctx = E.Context(0)
+    d = E.RadonIntermediate.from_host(ctx, want, s["n_u"], s["n_v"])
+    d.readback()
+    line = np.array([0.6, -0.8, -30.0], np.float32)
+    smp = d.sample(line)
+    v = val["view"]
+    assert [int(x) for x in v[:3]] == [s["n_alpha"], s["n_t"], 1]
+    assert np.float32(v[3]) == np.float32(d.tex2D(0.25, 0.75)) and np.float32(v[4]) == np.float32(smp)
+    assert np.float32(v[5]) == line[0] and np.float32(v[6]) == line[1]
+    assert np.float32(val["replaced"][0]) == np.float32(2) * flat[1234 % flat.size]
+    assert np.float32(val["replaced"][1]) == np.float32(2.0 * d.tex2D(0.25, 0.75)) or \
+        abs(float(val["replaced"][1]) - 2.0 * d.tex2D(0.25, 0.75)) <= 1e-6 * abs(d.tex2D(0.25, 0.75))
+    assert [int(x) for x in val["remeta"]] == [2, 0]
+    d.close()
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     s = small_scan
