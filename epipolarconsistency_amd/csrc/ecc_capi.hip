@@ -746,11 +746,12 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
         }
         table[k] = dtrs[k]->base;
     }
-    // one fp32 conversion forms the byte offset inside a paired copy: it has to stay below 2^24
+    // (the pair kernel forms byte offsets inside a paired copy in fp32 while the copy stays below 2^24 bytes and in
+    // integer arithmetic above -- fill_pair_params; offsets have to fit 32 bits: 16384 x 16384 bins is 2.1 GB)
     const int64_t paired_floats = (int64_t)(m->n_alpha + 1) * m->pitch * 2;
-    if (paired_floats * 4 >= (int64_t)1 << 24) {
+    if (paired_floats * 4 >= (int64_t)1 << 32) {
         delete m;
-        return fail(ECC_ERR_UNSUPPORTED, "Radon intermediates above ~2 M bins (e.g. 1448 x 1448) are not supported by the pair kernel");
+        return fail(ECC_ERR_UNSUPPORTED, "Radon intermediates above 4 GB per row-paired copy are not supported");
     }
     std::vector<const float*> ptable(n_dtrs);
     hipError_t e = hipMalloc((void**)&m->dtr_table_d, sizeof(float*) * n_dtrs);
@@ -930,6 +931,7 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t count)
     p->poly = resolve_sampling(m, count) == ECC_SAMPLING_POLYNOMIAL ? m->ctx->poly_d : nullptr;
     p->slabs = m->dtr_table_d;  // ECC_SAMPLING_REFERENCE samples the dtrs themselves (clamped taps), not the paired copies
     p->reference_arithmetic = resolve_sampling(m, count) == ECC_SAMPLING_REFERENCE ? 1 : 0;
+    p->wide_offsets = ((int64_t)(m->n_alpha + 1) * m->pitch * 8 >= (int64_t)1 << 24) ? 1 : 0;
     return ECC_OK;
 }
 

@@ -117,6 +117,7 @@ struct EccPairParams {
     int use_corr;              // MetricRadonIntermediate::useCorrelation (ref: ...RadonIntermediate.cu:116-149)
     const float* const* slabs; // device table of the dtrs' slabs (private layout); sampled by ECC_SAMPLING_REFERENCE
     int reference_arithmetic;  // ECC_SAMPLING_REFERENCE: pairs_reference_kernel instead of pairs_kernel
+    int wide_offsets;          // a row-paired copy is 2^24 bytes or more: integer instead of fp32 offset arithmetic
 };
 
 // ---- projection pre-processing ------------------------------------------------

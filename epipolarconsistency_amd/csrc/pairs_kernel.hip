@@ -178,6 +178,18 @@ __device__ __forceinline__ float atan_over_pi_small(float t)
     return pz * t;
 }
 
+// Byte offset of the footprint (row = floor(xa), bin = floor(yd), both already integral floats) in a row-paired copy.
+// PITCH4 >= 0: formed exactly in fp32 -- one fma, one conversion -- which needs the copy to stay below 2^24 bytes
+// (768 x 768 bins: 4.9 MB); PITCH4 > 0 is that with the pitch as a compile-time constant.  PITCH4 < 0: integer
+// arithmetic (two conversions, one 24-bit multiply-add) for Radon intermediates of any size up to 16384 x 16384 bins
+// (offsets < 2^32); chosen per launch by the host (EccPairParams::wide_offsets), ~5 % slower.
+template <int PITCH4>
+__device__ __forceinline__ unsigned footprint_offset(float row_f, float bin_f, unsigned pitch4, float pitch4_f)
+{
+    if (PITCH4 >= 0) return (unsigned)fmaf(row_f, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, bin_f * 8.0f);
+    return __umul24((unsigned)row_f, pitch4) + ((unsigned)bin_f << 3);
+}
+
 // One line (l0, l1, l2) -> signed bilinear sample of the dtr.
 // Instruction selection follows measured gfx950 issue costs (scripts/micro/valu_rate.hip):
 // v_fma/v_add/v_xor 2 cycles per wave64, v_floor/v_fract/v_cvt 4, v_cmp+v_cndmask 8 per pair,
@@ -236,9 +248,8 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     float yd = fmaf(-(l2f * inv), dist_scale, dist_bias);
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
-    // byte offset floor(xa)*pitch4 + floor(yd)*8 in the row-paired copy, formed exactly in fp32 (< 2^24, checked
-    // at metric creation), one conversion; ONE 16-byte load fetches the whole 2x2 footprint
-    const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 8.0f);
+    // byte offset floor(xa)*pitch4 + floor(yd)*8 in the row-paired copy; ONE 16-byte load fetches the whole 2x2 footprint
+    const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
     const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
     const float r0 = fmaf(fx, q.y - q.x, q.x);
     const float r1 = fmaf(fx, q.w - q.z, q.z);
@@ -320,7 +331,7 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
     xa = __builtin_amdgcn_fmed3f(xa, 1.f, n_t_f);  // square bin grids only
 #endif
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
-    const unsigned off = (unsigned)fmaf(xa - fx, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, (yd - fy) * 8.0f);
+    const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
 #if defined(PK_EXP_NO_LOAD)   // timing experiment: no memory traffic at all (wrong results)
     const F4 q = {__uint_as_float(off), fx, fy, xa};
 #else
@@ -804,7 +815,10 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     if (poly_ok) {
 #define ECC_POLY_LOOP(P4, DEG) \
     kappa_loop_poly<DERIV, CORR, P4, DEG>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4)
-        if (pitch4 == 6400u) {
+        if (p.wide_offsets) {
+            if (poly_ok <= 6) ECC_POLY_LOOP(-1, 6);
+            else ECC_POLY_LOOP(-1, ECC_POLY_DEG);
+        } else if (pitch4 == 6400u) {
             if (poly_ok <= 4) ECC_POLY_LOOP(6400, 4);
             else if (poly_ok <= 6) ECC_POLY_LOOP(6400, 6);
             else if (poly_ok <= 8) ECC_POLY_LOOP(6400, 8);
@@ -814,6 +828,9 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
             else ECC_POLY_LOOP(0, ECC_POLY_DEG);
         }
 #undef ECC_POLY_LOOP
+    } else if (p.wide_offsets) {
+        kappa_loop<DERIV, CORR, true, -1>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
+                                          pitch4_f, acc, mom2, mom3, mom4);
     } else if (pitch4 == 6400u) {  // 768 distance bins, the reference's default (Gui/ComputeRadonIntermediate.hxx:43-44)
         if (reduce)
             kappa_loop<DERIV, CORR, true, 6400>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,

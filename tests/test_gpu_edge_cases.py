@@ -298,3 +298,24 @@ def test_host_sampling_helpers_and_replace(gpu_ctx, oracle_mod):
     assert abs(d.getRadonBinSize(1) - np.sqrt(n_u ** 2 + n_v ** 2) / 64) < 1e-9
     d.clearRawData()
     assert d.data() is None
+
+
+def test_large_radon_intermediates_1448_bins(gpu_ctx, oracle_mod):
+    """Radon intermediates of 1448 x 1448 bins (row-paired copy 17 MB > 2^24 bytes): the pair kernel switches to integer
+    offset arithmetic (EccPairParams::wide_offsets); the reference has no size limit (RadonIntermediate.cpp:198-211).
+    Both throughput paths and the reference-arithmetic path against the oracle."""
+    import epipolarconsistency_amd as E
+    from conftest import make_small_scan
+    Ps, imgs = make_small_scan(n=5)
+    B = 1448
+    dtrs = E.RadonIntermediate.compute_batch(gpu_ctx, imgs, B, B)
+    host = [d.readback() for d in dtrs]
+    bins = np.random.default_rng(4).integers(0, B * B, size=2000).astype(np.int32)
+    assert np.array_equal(host[3].reshape(-1)[bins], oracle_mod.radon_bins(imgs[3], B, B, bins))
+    want = oracle_mod.evaluate_all(Ps, host, 128, 128)
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    for mode, pair_tol in (("polynomial", 5e-4), ("per_sample", 5e-4), ("reference", 1e-6)):
+        total, vals = m.setSampling(mode).evaluate_range(0, 10, want_pairs=True)
+        assert abs(total / 10 - want["mean"]) <= (1e-6 if mode == "reference" else 5e-5) * want["mean"], mode
+        np.testing.assert_allclose(vals, want["pairs"], rtol=pair_tol, err_msg=mode)
+    m.close()
