@@ -53,6 +53,7 @@ SIGNATURES = {
     "ecc_dtr_destroy": (_i, [_vp]),
     "ecc_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "ecc_metric_destroy": (_i, [_vp]),
+    "ecc_metric_refresh_dtrs": (_i, [_vp, _i, _i]),
     "ecc_metric_set_projections": (_i, [_vp, _vp, _i]),
     "ecc_metric_debug_geometry": (_i, [_vp, _vp, _vp]),
     "ecc_metric_set_params": (_i, [_vp, _d, _d, _i]),

@@ -359,6 +359,13 @@ class MetricRadonIntermediate:
     def getRadonIntermediates(self):
         return self._dtrs
 
+    def refreshRadonIntermediates(self, first=0, count=None):
+        """Not in the reference (ecc_metric_refresh_dtrs): the metric samples private row-paired copies of its dtrs;
+        after the slabs behind dtrs [first, first+count) were recomputed in place, re-copy them (asynchronous)."""
+        count = len(self._dtrs) - first if count is None else count
+        check(_lib.lib().ecc_metric_refresh_dtrs(self._h, int(first), int(count)))
+        return self
+
     def setProjectionMatrices(self, Ps):
         """Ps: list of 3x4 matrices, or (fast path) an (n, 12) float64 C-contiguous array that is
         already column-major per view (what Eigen's Ps[i].data() holds)."""

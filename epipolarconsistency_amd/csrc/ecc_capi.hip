@@ -102,6 +102,16 @@ struct ecc_ctx {
     int ramp_n_t = 0;
     // constant tables of the pair kernel's polynomial path
     EccPolyTables* poly_d = nullptr;
+    // arena of ecc_preprocess, reused between calls and freed with the context: device tables + their pinned host
+    // image (uploaded asynchronously; pre_ev marks the last upload, so the host image is not rewritten under a copy
+    // in flight) and the scratch stack of the host-input / in-place forms
+    char* pre_tables_d = nullptr;
+    char* pre_tables_h = nullptr;
+    size_t pre_tables_cap = 0;
+    hipEvent_t pre_ev = nullptr;
+    bool pre_ev_recorded = false;
+    float* pre_scratch_d[2] = {nullptr, nullptr};
+    size_t pre_scratch_cap[2] = {0, 0};
 };
 
 struct ecc_dtr {
@@ -494,6 +504,11 @@ ECC_EXPORT int ecc_ctx_destroy(ecc_ctx* ctx)
     if (ctx->trig_d) (void)hipFree(ctx->trig_d);
     if (ctx->ramp_d) (void)hipFree(ctx->ramp_d);
     if (ctx->poly_d) (void)hipFree(ctx->poly_d);
+    if (ctx->pre_tables_d) (void)hipFree(ctx->pre_tables_d);
+    if (ctx->pre_tables_h) (void)hipHostFree(ctx->pre_tables_h);
+    if (ctx->pre_ev) (void)hipEventDestroy(ctx->pre_ev);
+    for (float* b : ctx->pre_scratch_d)
+        if (b) (void)hipFree(b);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -776,6 +791,21 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
         HIP_TRY(e);
     }
     *out = m;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    const int n = (int)m->dtrs.size();
+    if (first < 0 || count < 0 || first > n || count > n - first) return fail(ECC_ERR_INVALID_ARGUMENT, "dtr range outside the metric's list");
+    if (count == 0) return ECC_OK;
+    int rc = set_device(m->ctx);
+    if (rc) return rc;
+    const int64_t paired_floats = (int64_t)(m->n_alpha + 1) * m->pitch * 2;
+    // stream-ordered behind whatever produced the new slab contents on this stream, in front of the next evaluation
+    HIP_TRY(ecc_launch_build_paired(m->dtr_table_d + first, m->paired_d + (size_t)paired_floats * first, paired_floats, count,
+                                    m->n_alpha + 1, m->pitch, m->ctx->stream));
     return ECC_OK;
 }
 
@@ -1282,35 +1312,74 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
     const size_t cosw_b = sizeof(float) * cosw.size(), valid_b = sizeof(int) * valid.size();
     const size_t max_b = sizeof(float) * (size_t)n;
     auto up8 = [](size_t b) { return (b + 7) / 8 * 8; };
-    const size_t table_b = up8(kernel_b) + up8(blanks_b) + up8(cosw_b) + up8(valid_b) + up8(max_b);
-    char* tables = nullptr;
-    float* staging_in = nullptr;   // host input, or in-place scratch
-    float* staging_out = nullptr;
-    hipError_t e = hipMalloc((void**)&tables, table_b);
+    const size_t upload_b = up8(kernel_b) + up8(blanks_b) + up8(cosw_b) + up8(valid_b);
+    const size_t table_b = upload_b + up8(max_b);
+    const size_t stack_b = sizeof(float) * img_floats * n;
     const bool in_place = on_device && images == out;
-    if (e == hipSuccess && (!on_device || in_place)) e = hipMalloc((void**)&staging_out, sizeof(float) * img_floats * n);
-    if (e == hipSuccess && !on_device) e = hipMalloc((void**)&staging_in, sizeof(float) * img_floats * n);
-    auto cleanup = [&]() {
-        if (tables) (void)hipFree(tables);
-        if (staging_in) (void)hipFree(staging_in);
-        if (staging_out) (void)hipFree(staging_out);
-    };
-    if (e != hipSuccess) {
-        cleanup();
-        HIP_TRY(e);
+    if (on_device && !in_place) {
+        // tiles read halos of their neighbours: a partially overlapping output would race with those reads
+        const char *a0 = reinterpret_cast<const char*>(images), *b0 = reinterpret_cast<const char*>(out);
+        if (a0 < b0 + stack_b && b0 < a0 + stack_b)
+            return fail(ECC_ERR_INVALID_ARGUMENT, "out overlaps images without being identical to it");
     }
-    char* t = tables;
+    // arena (kept in the context): tables, their pinned host image, scratch stacks
+    if (ctx->pre_tables_cap < table_b) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pre_tables_d) HIP_TRY(hipFree(ctx->pre_tables_d));
+        if (ctx->pre_tables_h) HIP_TRY(hipHostFree(ctx->pre_tables_h));
+        ctx->pre_tables_d = ctx->pre_tables_h = nullptr;
+        ctx->pre_tables_cap = 0;
+        const size_t cap = std::max(table_b * 2, (size_t)4096);
+        HIP_TRY(hipMalloc((void**)&ctx->pre_tables_d, cap));
+        HIP_TRY(hipHostMalloc((void**)&ctx->pre_tables_h, cap, hipHostMallocDefault));
+        ctx->pre_tables_cap = cap;
+        ctx->pre_ev_recorded = false;
+    }
+    if (!ctx->pre_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->pre_ev, hipEventDisableTiming));
+    auto ensure_scratch = [&](int which) -> int {
+        if (ctx->pre_scratch_cap[which] >= stack_b) return ECC_OK;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pre_scratch_d[which]) HIP_TRY(hipFree(ctx->pre_scratch_d[which]));
+        ctx->pre_scratch_d[which] = nullptr;
+        ctx->pre_scratch_cap[which] = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->pre_scratch_d[which], stack_b));
+        ctx->pre_scratch_cap[which] = stack_b;
+        return ECC_OK;
+    };
+    float* staging_in = nullptr;   // host input
+    float* staging_out = nullptr;  // host output, or the in-place form's scratch
+    if (!on_device || in_place) {
+        rc = ensure_scratch(0);
+        if (rc) return rc;
+        staging_out = ctx->pre_scratch_d[0];
+    }
+    if (!on_device) {
+        rc = ensure_scratch(1);
+        if (rc) return rc;
+        staging_in = ctx->pre_scratch_d[1];
+    }
+    // the previous call's table upload may still be reading the pinned image
+    if (ctx->pre_ev_recorded) HIP_TRY(hipEventSynchronize(ctx->pre_ev));
+    char* th = ctx->pre_tables_h;
+    if (kernel_b) std::memcpy(th, kernel.data(), kernel_b);
+    th += up8(kernel_b);
+    if (blanks_b) std::memcpy(th, cfg->blanks, blanks_b);
+    th += up8(blanks_b);
+    if (cosw_b) std::memcpy(th, cosw.data(), cosw_b);
+    th += up8(cosw_b);
+    if (valid_b) std::memcpy(th, valid.data(), valid_b);
+    char* t = ctx->pre_tables_d;
     double* kernel_d = reinterpret_cast<double*>(t); t += up8(kernel_b);
     int* blanks_d = reinterpret_cast<int*>(t); t += up8(blanks_b);
     float* cosw_d = reinterpret_cast<float*>(t); t += up8(cosw_b);
     int* valid_d = reinterpret_cast<int*>(t); t += up8(valid_b);
     float* max_d = reinterpret_cast<float*>(t);
-    e = hipMemcpyAsync(kernel_d, kernel.data(), kernel_b, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && blanks_b) e = hipMemcpyAsync(blanks_d, cfg->blanks, blanks_b, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && cosw_b) e = hipMemcpyAsync(cosw_d, cosw.data(), cosw_b, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && valid_b) e = hipMemcpyAsync(valid_d, valid.data(), valid_b, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (upload_b) e = hipMemcpyAsync(ctx->pre_tables_d, ctx->pre_tables_h, upload_b, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ctx->pre_ev, ctx->stream);
+    if (e == hipSuccess) ctx->pre_ev_recorded = true;
     if (e == hipSuccess && !on_device)
-        e = hipMemcpyAsync(staging_in, images, sizeof(float) * img_floats * n, hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(staging_in, images, stack_b, hipMemcpyHostToDevice, ctx->stream);
 
     EccPreprocessParams p;
     std::memset(&p, 0, sizeof(p));
@@ -1345,12 +1414,12 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
         ctx->ev_valid[2] = true;
     }
     if (e == hipSuccess && in_place)
-        e = hipMemcpyAsync(out, staging_out, sizeof(float) * img_floats * n, hipMemcpyDeviceToDevice, ctx->stream);
-    if (e == hipSuccess && !on_device)
-        e = hipMemcpyAsync(out, staging_out, sizeof(float) * img_floats * n, hipMemcpyDeviceToHost, ctx->stream);
-    // the host tables and the scratch buffers go out of scope here
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    cleanup();
+        e = hipMemcpyAsync(out, staging_out, stack_b, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && !on_device) {
+        e = hipMemcpyAsync(out, staging_out, stack_b, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host output: the caller reads it next
+    }
+    // device forms (in place or not) are asynchronous on the context's stream: tables and scratch live in the context
     HIP_TRY(e);
     return ECC_OK;
 }

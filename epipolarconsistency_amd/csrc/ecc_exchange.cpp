@@ -66,6 +66,7 @@ struct ecc_exchange {
     int rank = 0, world = 1;
     uint64_t generation = 0;
     double timeout_s = 60.0;
+    bool failed = false;  // a sum timed out: the ranks no longer agree on the generation, every later sum fails
 };
 
 ECC_EXPORT int ecc_exchange_open(const char* name, int rank, int world, ecc_exchange** out)
@@ -137,6 +138,10 @@ ECC_EXPORT int ecc_exchange_open(const char* name, int rank, int world, ecc_exch
 ECC_EXPORT int ecc_exchange_sum(ecc_exchange* ex, double partial, double* total)
 {
     if (!ex || !total) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    // After a timeout this rank has published a generation the others may never complete; retrying would publish the
+    // next one into the other slot set and overwrite what slower ranks still wait for.  The exchange stays failed:
+    // the caller tears the job down (or falls back to a collective on all ranks), it does not retry.
+    if (ex->failed) return ecc_set_error(ECC_ERR_UNSUPPORTED, "exchange failed earlier (a rank timed out); close it");
     const uint64_t g = ++ex->generation;
     Slot* slots = ex->seg->slots[g & 1];
     slots[ex->rank].value = partial;
@@ -154,6 +159,7 @@ ECC_EXPORT int ecc_exchange_sum(ecc_exchange* ex, double partial, double* total)
                     t0 = now;
                     timing = true;
                 } else if (std::chrono::duration<double>(now - t0).count() > ex->timeout_s) {
+                    ex->failed = true;
                     return ecc_set_error(ECC_ERR_UNSUPPORTED, "exchange timed out waiting for another rank");
                 }
             }

@@ -83,7 +83,13 @@ class ScalarExchange:
 
 def open_exchange(rank, world, barrier, name=None):
     """Opens the exchange on all ranks: rank 0 first (it removes a stale segment of the same name and creates a
-    fresh one), then -- after `barrier()` -- the others, so that nobody can attach to a leftover of a crashed job."""
+    fresh one), then -- after `barrier()` -- the others, so that nobody can attach to a leftover of a crashed job.
+    The segment is node-local shared memory: a job whose ranks span several nodes (WORLD_SIZE != LOCAL_WORLD_SIZE
+    under torchrun) is refused here -- every rank raises before touching /dev/shm -- and takes the collective."""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if local_world != world:
+        raise RuntimeError("the shared-memory exchange is single-node (WORLD_SIZE %d, LOCAL_WORLD_SIZE %d)"
+                           % (world, local_world))
     ex = ScalarExchange(rank, world, name) if rank == 0 else None
     barrier()
     if rank != 0:

@@ -86,7 +86,8 @@ int ecc_radon_compute_batch(ecc_ctx* ctx, const float* images, int images_on_dev
 /* Device-to-device form for callers that own both buffers (e.g. torch tensors): images_d holds n
  * images, slabs_d receives n dtrs in the private layout (ecc_dtr_slab_floats(n_alpha, n_t) floats
  * each, written completely incl. the replicated border).  Asynchronous on the context's stream;
- * adopt the result with ecc_dtr_wrap_device. */
+ * adopt the result with ecc_dtr_wrap_device.  A metric that already holds handles on these slabs keeps
+ * sampling its snapshot of the old contents until ecc_metric_refresh_dtrs (see there). */
 int ecc_radon_compute_into(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, int n_alpha,
                            int n_t, int filter, int post_process, float* slabs_d);
 
@@ -106,7 +107,8 @@ int ecc_dtr_info(const ecc_dtr* dtr, int* n_alpha, int* n_t, int* n_u, int* n_v,
 int ecc_dtr_device_view(const ecc_dtr* dtr, float** base, int* pitch, int* rows);
 /* Size in floats of one dtr in the private layout, so that a caller (e.g. torch) can own the slab. */
 int64_t ecc_dtr_slab_floats(int n_alpha, int n_t);
-/* Adopt caller-owned device memory already holding a dtr in the private layout (no copy, no free). */
+/* Adopt caller-owned device memory already holding a dtr in the private layout (no copy, no free).  The handle
+ * aliases the caller's memory: see ecc_metric_refresh_dtrs for what a metric sees when the memory changes. */
 int ecc_dtr_wrap_device(ecc_ctx* ctx, float* base, int n_alpha, int n_t, int n_u, int n_v, int filter,
                         ecc_dtr** out);
 int ecc_dtr_destroy(ecc_dtr* dtr);
@@ -136,7 +138,9 @@ void ecc_preprocess_defaults(ecc_preprocess_config* cfg);
  * dropped last tap, cosine weight).  images / out: n * n_u * n_v floats, both on the host
  * (on_device = 0) or both on ctx's device (= 1); out may equal images (in place, like the reference).
  * Ps: n x 12 float64 column-major or NULL (no cosine weighting; an all-zero matrix skips that view,
- * PreProccess.cpp:149).  Asynchronous on the context's stream when on_device = 1 and out != images. */
+ * PreProccess.cpp:149).  on_device = 1: asynchronous on the context's stream, in place (through a scratch stack kept
+ * in the context) or out of place; `out` must be identical to `images` or disjoint from it (partial overlap is
+ * rejected: tiles read halos of their neighbours).  on_device = 0 returns with `out` filled. */
 int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, float* out, int n, int n_u, int n_v,
                    const ecc_preprocess_config* cfg, const double* Ps);
 /* K(0,0), K(0,2), K(1,2) of P = K[R|t] (ref: getCameraIntrinsics, ProjectionMatrix.cpp:61-67). */
@@ -148,6 +152,14 @@ void ecc_host_intrinsics(const double* P, float* sdd_px, float* ppu, float* ppv)
  * the derivative flag are taken from dtrs[0] only, as the reference does (.cpp:92-98). */
 int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs, ecc_metric** out);
 int ecc_metric_destroy(ecc_metric* m);
+/* SNAPSHOT SEMANTICS.  ecc_metric_create copies every dtr into a private row-paired layout and the
+ * all-pairs / range / index-list evaluations in the polynomial and per-sample modes sample THOSE copies: new slab
+ * contents (ecc_radon_compute_into into the same slabs, an image-domain correction loop) are not seen until
+ * ecc_metric_refresh_dtrs(m, first, count) re-copies dtrs [first, first + count) -- asynchronous on the context's
+ * stream, ~1 us per dtr, ordered behind the kernels that wrote the slabs when they ran on the same stream.
+ * ECC_SAMPLING_REFERENCE and ecc_metric_evaluate_for_image_pair read the slabs themselves (always current).  The
+ * handles must stay alive for the metric's lifetime either way ("DO NOT delete or change _dtrs", ref: .h:45). */
+int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count);
 
 /* ref: MetricRadonIntermediate::setProjectionMatrices (…RadonIntermediate.cpp:134-163): per view
  * (P^+)^T and the source position in float64 (same Householder-QR arithmetic as
@@ -349,7 +361,11 @@ int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m)
  * involved.  All ranks call ecc_exchange_sum the same number of times.
  * name: shm name starting with '/', the same on all ranks and unique per job; rank 0 creates the segment, the other
  * ranks wait for it.  A rank that does not show up makes the others fail with ECC_ERR_UNSUPPORTED after
- * ECC_EXCHANGE_TIMEOUT_S seconds (environment, default 60) instead of hanging. */
+ * ECC_EXCHANGE_TIMEOUT_S seconds (environment, default 60) instead of hanging; after such a failure the exchange
+ * stays failed (every later ecc_exchange_sum returns the error at once) -- close it, do not retry.
+ * SINGLE NODE ONLY: the segment lives in this node's /dev/shm, so rank / world are the node-local rank and the number
+ * of ranks on this node (LOCAL_RANK / LOCAL_WORLD_SIZE under torchrun); a job that spans nodes adds the node sums
+ * with a collective of its own (sharding.open_exchange refuses WORLD_SIZE != LOCAL_WORLD_SIZE). */
 #define ECC_EXCHANGE_MAX_RANKS 64
 typedef struct ecc_exchange ecc_exchange;
 int ecc_exchange_open(const char* name, int rank, int world, ecc_exchange** out);

@@ -319,3 +319,37 @@ def test_large_radon_intermediates_1448_bins(gpu_ctx, oracle_mod):
         assert abs(total / 10 - want["mean"]) <= (1e-6 if mode == "reference" else 5e-5) * want["mean"], mode
         np.testing.assert_allclose(vals, want["pairs"], rtol=pair_tol, err_msg=mode)
     m.close()
+
+
+def test_refresh_after_recomputing_slabs_in_place(gpu_ctx, oracle_mod, small_scan):
+    """A metric samples a snapshot (row-paired copies) of its dtrs: slabs recomputed in place are seen after
+    refreshRadonIntermediates() (ecc_metric_refresh_dtrs), and only then -- except in reference mode, which reads the
+    slabs themselves."""
+    import torch
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dev = torch.device("cuda", gpu_ctx.device)
+    imgs = torch.from_numpy(np.ascontiguousarray(s["imgs"])).to(dev)
+    slabs = torch.zeros((8, E.slab_floats(96, 96)), dtype=torch.float32, device=dev)
+    dtrs = E.RadonIntermediate.compute_into(gpu_ctx, imgs, slabs, 96, 96)
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs).setSampling("polynomial")
+    before = m.evaluate()
+    # new image content for views 2 and 5, same slabs
+    imgs2 = imgs.clone()
+    imgs2[2] *= 1.5
+    imgs2[5] = torch.flip(imgs2[5], dims=[1])
+    keep = E.RadonIntermediate.compute_into(gpu_ctx, imgs2[2:3], slabs[2:3], 96, 96)
+    keep += E.RadonIntermediate.compute_into(gpu_ctx, imgs2[5:6], slabs[5:6], 96, 96)
+    gpu_ctx.synchronize()
+    assert m.evaluate() == before  # still the snapshot
+    host = [oracle_mod.radon(im, 96, 96) for im in imgs2.cpu().numpy()]
+    want = oracle_mod.evaluate_all(s["Ps"], host, 128, 128)["mean"]
+    assert abs(m.setSampling("reference").evaluate() - want) <= 1e-6 * want  # reads the live slabs
+    m.setSampling("polynomial")
+    m.refreshRadonIntermediates(2, 1)
+    m.refreshRadonIntermediates(5, 1)
+    after = m.evaluate()
+    assert abs(after - want) <= 1e-5 * want and abs(after - before) > 1e-3 * before
+    with pytest.raises(E.EccError):
+        m.refreshRadonIntermediates(7, 2)
+    m.close()

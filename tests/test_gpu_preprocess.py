@@ -101,3 +101,25 @@ def test_preprocess_errors(gpu_ctx):
     pp.border.zero = [-1, 0, 0, 0]
     with pytest.raises(E.EccError):
         pp.process(gpu_ctx, _images((20, 20)))
+
+
+def test_preprocess_overlap_rejected_and_arena_reused(gpu_ctx, oracle_mod):
+    """Device form: `out` identical to `images` (in place, through the context's scratch stack) or disjoint; a partially
+    overlapping output would race with the halo reads and is refused.  Repeated calls of different sizes reuse / grow the
+    context's arena and stay bit-exact."""
+    import torch
+    import epipolarconsistency_amd as E
+    pp = E.PreProccess()
+    big = torch.zeros((5, 40, 48), dtype=torch.float32, device="cuda")
+    with pytest.raises(E.EccError) as ei:
+        pp.process(gpu_ctx, big[0:4], out=big[1:5])
+    assert "overlaps" in str(ei.value)
+    rng = np.random.default_rng(9)
+    for shape in ((3, 40, 48), (2, 33, 21), (6, 64, 80), (3, 40, 48)):
+        imgs = rng.uniform(0.1, 2.0, size=shape).astype(np.float32)
+        want = np.stack([oracle_mod.preprocess(im) for im in imgs])
+        t = torch.from_numpy(imgs).cuda()
+        pp.process(gpu_ctx, t)  # in place, asynchronous on the context's stream
+        gpu_ctx.synchronize()
+        assert np.array_equal(t.cpu().numpy(), want)
+        assert np.array_equal(pp.process(gpu_ctx, imgs), want)  # host form

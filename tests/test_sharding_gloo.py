@@ -115,7 +115,17 @@ def test_exchange_times_out_instead_of_hanging(monkeypatch):
     with pytest.raises(E.EccError) as ei:
         ex.sum(1.0)
     assert time.time() - t0 < 20 and "timed out" in str(ei.value)
+    # the exchange stays failed: a retry returns at once instead of publishing the next generation
+    t0 = time.time()
+    with pytest.raises(E.EccError) as ei:
+        ex.sum(1.0)
+    assert time.time() - t0 < 0.2 and "failed earlier" in str(ei.value)
     ex.close()
+    # single node only: refused before any segment is touched when the job spans nodes
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    with pytest.raises(RuntimeError):
+        sharding.open_exchange(0, 8, lambda: None, "/ecc_hip_test_multinode_%d" % os.getpid())
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
     with pytest.raises(E.EccError):
         sharding.ScalarExchange(3, 2, "/x")          # rank outside the world
     with pytest.raises(E.EccError):
