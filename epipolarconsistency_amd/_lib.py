@@ -80,6 +80,7 @@ SIGNATURES = {
     "ecc_direct_evaluate": (_i, [_vp, _vp, _pd]),
     "ecc_direct_lines_bound": (_i, [_vp, _pi]),
     "ecc_direct_evaluate_for_image_pair": (_i, [_vp, _i, _i, _i, _pi, _vp, _vp, _vp, _vp, _pd]),
+    "ecc_direct_evaluate_for_image_pair_kappas": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _pd]),
     "ecc_preprocess_defaults": (None, [_vp]),
     "ecc_preprocess": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "ecc_host_intrinsics": (None, [_vp, _pf, _pf, _pf]),

@@ -738,9 +738,18 @@ class MetricDirect:
         check(_lib.lib().ecc_direct_evaluate(self._h, C.c_void_p(cost.ctypes.data if cost is not None else 0), C.byref(s)))
         return s.value
 
-    def evaluateForImagePair(self, i, j):
-        """ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas); also returns the lines."""
+    def evaluateForImagePair(self, i, j, kappas=None):
+        """ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas); also returns the lines.
+        kappas: optional caller-provided grid of plane angles (the reference takes a non-empty `kappas` as input)."""
         L = _lib.lib()
+        if kappas is not None:
+            kap = np.ascontiguousarray(kappas, np.float32).reshape(-1)
+            s0, s1, lines = np.empty(len(kap), np.float32), np.empty(len(kap), np.float32), np.empty((len(kap), 6), np.float32)
+            m = C.c_double()
+            check(L.ecc_direct_evaluate_for_image_pair_kappas(self._h, int(i), int(j), len(kap), C.c_void_p(kap.ctypes.data),
+                                                              C.c_void_p(s0.ctypes.data), C.c_void_p(s1.ctypes.data),
+                                                              C.c_void_p(lines.ctypes.data), C.byref(m)))
+            return m.value, dict(redundant_samples0=s0, redundant_samples1=s1, kappas=kap, lines=lines)
         cap = C.c_int()
         check(L.ecc_direct_lines_bound(self._h, C.byref(cap)))
         cap = cap.value

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void direct_pair_kernel(EccDirectParams p)
     const double nl = (k_second - k_first) / dkappa;
     int n_lines = nl < 2147483000.0 ? (int)nl : 2147483000;
     if (!(nl >= 0)) n_lines = 0;            // NaN geometry (coincident source positions)
+    if (p.user_kappas) n_lines = p.n_user_kappas;  // ref: :105-106: a non-empty `kappas` is taken as the grid
     if (n_lines > p.n_max) n_lines = p.n_max;  // cannot happen for the host's bound; keeps the stores in range
     r.k_first = k_first;
     r.dkappa = dkappa;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void direct_lines_kernel(EccDirectParams p)
     const EccDirectPair& r = p.pairs[pair];
     if (k >= r.n_lines) return;
     // ref: EpipolarConsistencyDirect.cpp:113-117 (kappa grid, float) and :49-63 (the line of plane kappa)
-    const float kf = (float)(r.k_first + r.dkappa * k);
+    const float kf = p.user_kappas ? p.user_kappas[k] : (float)(r.k_first + r.dkappa * k);
     const double kappa = kf, c = cos(kappa), s = sin(kappa);
     double E[4], l[3];
     for (int q = 0; q < 4; ++q) E[q] = c * r.E0[q] + s * r.E90[q];

@@ -1662,8 +1662,29 @@ ECC_EXPORT int ecc_direct_evaluate(ecc_direct* d, float* cost_nxn, double* cost_
     return ECC_OK;
 }
 
+namespace {
+int direct_pair_impl(ecc_direct* d, int i, int j, int capacity, int* n_lines, float* rs0, float* rs1, float* kappas,
+                     float* lines01, double* metric, const float* kappas_in, int n_kappas_in);
+}
+
 ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, int capacity, int* n_lines, float* rs0,
                                                   float* rs1, float* kappas, float* lines01, double* metric)
+{
+    return direct_pair_impl(d, i, j, capacity, n_lines, rs0, rs1, kappas, lines01, metric, nullptr, 0);
+}
+
+ECC_EXPORT int ecc_direct_evaluate_for_image_pair_kappas(ecc_direct* d, int i, int j, int n_kappas, const float* kappas_in,
+                                                         float* rs0, float* rs1, float* lines01, double* metric)
+{
+    if (!kappas_in || n_kappas < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "empty kappa grid");
+    if (n_kappas > (1 << 24)) return fail(ECC_ERR_INVALID_ARGUMENT, "more than 2^24 epipolar planes");
+    int n = 0;
+    return direct_pair_impl(d, i, j, n_kappas, &n, rs0, rs1, nullptr, lines01, metric, kappas_in, n_kappas);
+}
+
+namespace {
+int direct_pair_impl(ecc_direct* d, int i, int j, int capacity, int* n_lines, float* rs0, float* rs1, float* kappas,
+                     float* lines01, double* metric, const float* kappas_in, int n_kappas_in)
 {
     if (!d || !n_lines) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (d->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
@@ -1675,16 +1696,18 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
     int n_max = 0;
     rc = direct_n_max(d, &n_max);
     if (rc) return rc;
-    rc = direct_scratch(d, 1, n_max);
+    rc = direct_scratch(d, 1, std::max(n_max, n_kappas_in));
     if (rc) return rc;
     n_max = d->n_max_capacity;
-    // debug outputs of pair 0: 6 floats per kappa (lines) + kappa grid + line count + the (i, j) tuple
+    // debug outputs of pair 0: 6 floats per kappa (lines) + kappa grid + line count + the (i, j) tuple; the grid
+    // buffer doubles as the input of a caller-provided grid
     char* dbg = nullptr;
     const size_t lines_b = sizeof(float) * 6 * (size_t)n_max, kap_b = sizeof(float) * (size_t)n_max;
-    HIP_TRY(hipMalloc((void**)&dbg, lines_b + kap_b + 4 * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&dbg, lines_b + 2 * kap_b + 4 * sizeof(int)));
     float* lines_d = reinterpret_cast<float*>(dbg);
     float* kap_d = reinterpret_cast<float*>(dbg + lines_b);
-    int* count_d = reinterpret_cast<int*>(dbg + lines_b + kap_b);
+    float* kap_in_d = reinterpret_cast<float*>(dbg + lines_b + kap_b);
+    int* count_d = reinterpret_cast<int*>(dbg + lines_b + 2 * kap_b);
     int* idx_d = count_d + 1;
     const int idx[2] = {i, j};
     EccDirectParams p;
@@ -1709,11 +1732,15 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
     p.object_radius_mm = direct_radius(d);
     p.dkappa = d->dkappa;
     p.use_fbcc = d->use_fbcc ? 1 : 0;
+    p.user_kappas = kappas_in ? kap_in_d : nullptr;
+    p.n_user_kappas = n_kappas_in;
     std::vector<float> v((size_t)n_max * 2), L((size_t)n_max * 6), K((size_t)n_max);
     int n = 0;
     double m = 0;
     hipError_t e = hipMemcpyAsync(idx_d, idx, sizeof(idx), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dbg, 0, lines_b + kap_b + sizeof(int), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dbg, 0, lines_b + 2 * kap_b + sizeof(int), ctx->stream);
+    if (e == hipSuccess && kappas_in)
+        e = hipMemcpyAsync(kap_in_d, kappas_in, sizeof(float) * (size_t)n_kappas_in, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = ecc_launch_direct_batch(&p, nullptr, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(v.data(), d->samples_d, sizeof(float) * v.size(), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(L.data(), lines_d, lines_b, hipMemcpyDeviceToHost, ctx->stream);
@@ -1735,6 +1762,7 @@ ECC_EXPORT int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, i
     if (metric) *metric = m;
     return ECC_OK;
 }
+}  // namespace
 
 // ---- Metric's free helper functions (host, float64) ------------------------------------------------
 ECC_EXPORT void ecc_host_angular_range(const double* P0, const double* P1, double object_radius_mm, double* kappa_first,

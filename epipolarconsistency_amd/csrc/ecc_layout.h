@@ -174,6 +174,8 @@ struct EccDirectParams {
     int n_views, n_u, n_v, n_max;
     double object_radius_mm, dkappa;
     int use_fbcc;               // MetricDirect::setFanBeamConsistency
+    const float* user_kappas;   // optional caller-provided kappa grid (ref: EpipolarConsistencyDirect.cpp:105-117), device
+    int n_user_kappas;
 };
 
 // ---- evaluateForImagePair (E7, visualisation) -------------------------------------------------

@@ -279,6 +279,13 @@ int ecc_direct_evaluate_for_image_pair(ecc_direct* d, int i, int j, int capacity
                                        float* redundant_samples0, float* redundant_samples1, float* kappas,
                                        float* lines01, double* metric);
 
+/* The same with a caller-provided grid of epipolar-plane angles (the reference takes a non-empty `kappas` vector as
+ * the grid, .cpp:105-117): n_kappas float32 angles on the host; outputs hold n_kappas entries each; the metric is
+ * SUM (v0 - v1)^2 dkappa with the dkappa of ecc_direct_set_params (or the automatic one), as in the reference. */
+int ecc_direct_evaluate_for_image_pair_kappas(ecc_direct* d, int i, int j, int n_kappas, const float* kappas_in,
+                                              float* redundant_samples0, float* redundant_samples1, float* lines01,
+                                              double* metric);
+
 /* Debug: what the pair-geometry kernel fitted for pairs ij in [first, first+count): per pair
  * ECC_POLY_RECORD_FLOATS floats = { degree evaluated (4, 6, 8, 10; 0 = exact path), x_scale, fold0, fold1 (1 = folded on the +kappa side),
  * ca[0][0..DEG+2], ca[1][...], cd[0][0..DEG+1], cd[1][...] } with DEG = 10.  Host output. */

@@ -100,3 +100,27 @@ def test_fan_beam_consistency_variant(gpu_ctx, oracle_mod, small_scan):
     assert _rel(m.evaluate(), want["sum"]) < 1e-3
     # switching back gives the derivative form again
     assert _rel(m.setFanBeamConsistency(False).evaluate(), oracle_mod.direct_evaluate(Ps, imgs)["sum"]) < 1e-5
+
+
+def test_caller_provided_kappa_grid(gpu_ctx, small_scan):
+    """ref: computeForImagePair takes a non-empty `kappas` vector as the grid (EpipolarConsistencyDirect.cpp:105-117).
+    The automatic grid handed back in reproduces the same bits; a thinned grid picks out exactly those lines and the
+    metric is the sum over them with the same dkappa."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    d = E.MetricDirect(gpu_ctx, s["Ps"][:3], np.ascontiguousarray(s["imgs"][:3]))
+    m0, a = d.evaluateForImagePair(0, 2)
+    m1, b = d.evaluateForImagePair(0, 2, kappas=a["kappas"])
+    assert m1 == m0 and np.array_equal(b["redundant_samples0"], a["redundant_samples0"])
+    assert np.array_equal(b["redundant_samples1"], a["redundant_samples1"]) and np.array_equal(b["lines"], a["lines"])
+    thin = a["kappas"][::3]
+    m2, c = d.evaluateForImagePair(0, 2, kappas=thin)
+    assert np.array_equal(c["redundant_samples0"], a["redundant_samples0"][::3])
+    assert np.array_equal(c["redundant_samples1"], a["redundant_samples1"][::3])
+    dk = float(a["kappas"][1] - a["kappas"][0])
+    diff = (c["redundant_samples0"] - c["redundant_samples1"]).astype(np.float32)
+    want = float(np.sum((diff * diff).astype(np.float64)) * (m0 / np.sum(((a["redundant_samples0"] - a["redundant_samples1"]).astype(np.float32) ** 2).astype(np.float64))))
+    assert abs(m2 - want) <= 1e-9 * abs(want) and dk > 0
+    with pytest.raises(E.EccError):
+        d.evaluateForImagePair(0, 2, kappas=np.zeros(0, np.float32))
+    d.close()
