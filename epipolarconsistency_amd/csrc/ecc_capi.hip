@@ -39,6 +39,8 @@ extern "C" hipError_t ecc_launch_dtr_export(const float* slab, float* dst, int n
                                             hipStream_t stream);
 extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, float* paired_d, int64_t paired_stride, int n,
                                               int rows, int pitch, hipStream_t stream);
+extern "C" hipError_t ecc_launch_build_quad(const float* const* slabs_tbl_d, float* quads_d, int64_t quad_stride_floats, int n,
+                                            int rows, int pitch, hipStream_t stream);
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream);
@@ -138,6 +140,9 @@ struct ecc_metric {
     const float** dtr_table_d = nullptr;     // the dtrs' slabs (borrowed)
     float* paired_d = nullptr;               // row-paired copies of all dtrs (owned; what the pair kernel samples)
     const float** paired_table_d = nullptr;  // per dtr: base of its paired copy
+    float* quads_d = nullptr;                // row-quad copies of all dtrs (owned; sampled by the pairs with kappa_max > pi/4), or null
+    const float** quads_table_d = nullptr;
+    int64_t quad_floats = 0;                 // floats per row-quad copy
     float* Cs_d = nullptr;
     float* PinvTs_d = nullptr;
     int geom_capacity = 0;
@@ -775,6 +780,18 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) ptable[k] = m->paired_d + (size_t)paired_floats * k;
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->paired_table_d, ptable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
+    // row-quad copies: opt-in (ECC_QUAD_COPIES=1; 4x the slab memory, see pairs_kernel.hip); offsets must fit 32 bits
+    std::vector<const float*> qtable(n_dtrs);
+    m->quad_floats = (int64_t)((m->n_alpha + 1 + 3) / 4) * m->pitch * 16;
+    const char* quads_env = std::getenv("ECC_QUAD_COPIES");
+    const bool want_quads = m->quad_floats * 4 < ((int64_t)1 << 32) && quads_env && quads_env[0] == '1';
+    if (e == hipSuccess && want_quads) {
+        e = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
+        if (e == hipSuccess) e = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);
+        for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) qtable[k] = m->quads_d + (size_t)m->quad_floats * k;
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(m->quads_table_d, qtable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
 
     if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, 64, hipHostMallocMapped);
@@ -785,6 +802,8 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     // the paired copies are built once, here
     if (e == hipSuccess)
         e = ecc_launch_build_paired(m->dtr_table_d, m->paired_d, paired_floats, n_dtrs, m->n_alpha + 1, m->pitch, ctx->stream);
+    if (e == hipSuccess && m->quads_d)
+        e = ecc_launch_build_quad(m->dtr_table_d, m->quads_d, m->quad_floats, n_dtrs, m->n_alpha + 1, m->pitch, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ecc_metric_destroy(m);
@@ -806,6 +825,9 @@ ECC_EXPORT int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count)
     // stream-ordered behind whatever produced the new slab contents on this stream, in front of the next evaluation
     HIP_TRY(ecc_launch_build_paired(m->dtr_table_d + first, m->paired_d + (size_t)paired_floats * first, paired_floats, count,
                                     m->n_alpha + 1, m->pitch, m->ctx->stream));
+    if (m->quads_d)
+        HIP_TRY(ecc_launch_build_quad(m->dtr_table_d + first, m->quads_d + (size_t)m->quad_floats * first, m->quad_floats, count,
+                                      m->n_alpha + 1, m->pitch, m->ctx->stream));
     return ECC_OK;
 }
 
@@ -817,6 +839,8 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->dtr_table_d) (void)hipFree((void*)m->dtr_table_d);
     if (m->paired_table_d) (void)hipFree((void*)m->paired_table_d);
     if (m->paired_d) (void)hipFree(m->paired_d);
+    if (m->quads_table_d) (void)hipFree((void*)m->quads_table_d);
+    if (m->quads_d) (void)hipFree(m->quads_d);
     if (m->Cs_d) (void)hipFree(m->Cs_d);
     if (m->PinvTs_d) (void)hipFree(m->PinvTs_d);
     if (m->pair_values_d) (void)hipFree(m->pair_values_d);
@@ -962,6 +986,15 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t count)
     p->slabs = m->dtr_table_d;  // ECC_SAMPLING_REFERENCE samples the dtrs themselves (clamped taps), not the paired copies
     p->reference_arithmetic = resolve_sampling(m, count) == ECC_SAMPLING_REFERENCE ? 1 : 0;
     p->wide_offsets = ((int64_t)(m->n_alpha + 1) * m->pitch * 8 >= (int64_t)1 << 24) ? 1 : 0;
+    p->quads = m->quads_table_d;
+    p->quad_group_bytes = (unsigned)m->pitch * 64u;
+    {
+        static const float tol = [] {
+            const char* e = std::getenv("ECC_POLY_TOL");  // experiments only
+            return e ? (float)std::atof(e) : 2e-8f;
+        }();
+        p->economise_tol = tol;
+    }
     return ECC_OK;
 }
 

@@ -117,6 +117,9 @@ struct EccPairParams {
     int use_corr;              // MetricRadonIntermediate::useCorrelation (ref: ...RadonIntermediate.cu:116-149)
     const float* const* slabs; // device table of the dtrs' slabs (private layout); sampled by ECC_SAMPLING_REFERENCE
     int reference_arithmetic;  // ECC_SAMPLING_REFERENCE: pairs_reference_kernel instead of pairs_kernel
+    const float* const* quads; // device table of the dtrs' ROW-QUAD copies (build_quad_kernel) or null
+    unsigned quad_group_bytes; // bytes of one group of four rows in a row-quad copy (pitch * 64)
+    float economise_tol;       // bins: bound on what lowering a pair's polynomial degree may cost (k01_kernel, economise)
     int wide_offsets;          // a row-paired copy is 2^24 bytes or more: integer instead of fp32 offset arithmetic
 };
 

@@ -183,10 +183,17 @@ __device__ __forceinline__ float atan_over_pi_small(float t)
 // (768 x 768 bins: 4.9 MB); PITCH4 > 0 is that with the pitch as a compile-time constant.  PITCH4 < 0: integer
 // arithmetic (two conversions, one 24-bit multiply-add) for Radon intermediates of any size up to 16384 x 16384 bins
 // (offsets < 2^32); chosen per launch by the host (EccPairParams::wide_offsets), ~5 % slower.
+// PITCH4 == ECC_QUAD_LAYOUT: the offset in a ROW-QUAD copy (build_quad_kernel), where one 128-byte line holds the
+// footprints of 4 consecutive rows x 2 bins; `pitch4` is then the byte size of one group of four rows.
+constexpr int ECC_QUAD_LAYOUT = -2;
 template <int PITCH4>
 __device__ __forceinline__ unsigned footprint_offset(float row_f, float bin_f, unsigned pitch4, float pitch4_f)
 {
     if (PITCH4 >= 0) return (unsigned)fmaf(row_f, PITCH4 > 0 ? (float)PITCH4 : pitch4_f, bin_f * 8.0f);
+    if (PITCH4 == ECC_QUAD_LAYOUT) {
+        const unsigned r = (unsigned)row_f;
+        return __umul24(r >> 2, pitch4) + ((unsigned)bin_f << 6) + ((r & 3u) << 4);
+    }
     return __umul24((unsigned)row_f, pitch4) + ((unsigned)bin_f << 3);
 }
 
@@ -196,9 +203,15 @@ __device__ __forceinline__ unsigned footprint_offset(float row_f, float bin_f, u
 // v_rcp/v_rsq 8.6 -- so selects are replaced by sign-bit arithmetic and a wave-uniform branch.
 // PITCH4 > 0: row pitch in bytes known at
 // compile time (the 768-bin default), the second row's load then uses an immediate offset.
-template <bool DERIV, int PITCH4>
-__device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
-                                             float n_t_f, float dist_scale, float dist_bias, float pitch4_f)
+struct LineTap {
+    const F4* ptr;  // the 2x2 footprint in the row-paired copy
+    float fx, fy;   // bilinear weights
+    unsigned m;     // sign bit of the fold
+};
+
+template <int PITCH4>
+__device__ __forceinline__ LineTap sample_line_prep(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
+                                                    float n_t_f, float dist_scale, float dist_bias, float pitch4_f)
 {
     // fold: a line whose normal points to negative y is negated (the reference's a > 1 branch).  l0/l1 is
     // invariant under the negation, so only the distance term and the sample take the sign.
@@ -249,12 +262,38 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
     // byte offset floor(xa)*pitch4 + floor(yd)*8 in the row-paired copy; ONE 16-byte load fetches the whole 2x2 footprint
+#if defined(PK_EXP_ROWQUANT)  // timing experiment: rows quantised to multiples of PK_EXP_ROWQUANT (wrong results): fewer lines per gather
+    const unsigned off = footprint_offset<PITCH4>(floorf((xa - fx) * (1.0f / PK_EXP_ROWQUANT)) * (float)PK_EXP_ROWQUANT, yd - fy, sv.pitch4, pitch4_f);
+#else
     const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
-    const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
-    const float r0 = fmaf(fx, q.y - q.x, q.x);
-    const float r1 = fmaf(fx, q.w - q.z, q.z);
-    const float v = fmaf(fy, r1 - r0, r0);
-    return DERIV ? __uint_as_float(__float_as_uint(v) ^ m) : v;
+#endif
+    LineTap t;
+    t.ptr = reinterpret_cast<const F4*>(sv.origin + off);
+    t.fx = fx;
+    t.fy = fy;
+    t.m = m;
+    return t;
+}
+
+template <bool DERIV>
+__device__ __forceinline__ float line_tap_finish(const F4 q, const LineTap t)
+{
+    const float r0 = fmaf(t.fx, q.y - q.x, q.x);
+    const float r1 = fmaf(t.fx, q.w - q.z, q.z);
+    const float v = fmaf(t.fy, r1 - r0, r0);
+    return DERIV ? __uint_as_float(__float_as_uint(v) ^ t.m) : v;
+}
+
+template <bool DERIV, int PITCH4>
+__device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
+                                             float n_t_f, float dist_scale, float dist_bias, float pitch4_f)
+{
+    const LineTap t = sample_line_prep<PITCH4>(l0, l1, l2, sv, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+#if defined(PK_EXP_NO_LOAD)
+    return line_tap_finish<DERIV>(F4{t.fx, t.fy, __uint_as_float((unsigned)(size_t)t.ptr), 1.f}, t);
+#else
+    return line_tap_finish<DERIV>(*t.ptr, t);
+#endif
 }
 
 // One kappa sample (four bilinear samples) of the pair loop; returns false when kappa is past kappa_max.
@@ -376,6 +415,9 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         ca[v][ECC_POLY_DEG + 2] = uniformf(rec->ca[v][ECC_POLY_DEG + 2]);
     }
     const float xs = uniformf(rec->x_scale);
+#if defined(PK_EXP_F32_ACC)
+    float acc32 = 0.f;
+#endif
     for (int k = lane; k < k_limit; k += 64) {
         const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
         if (kappa >= kappa_max) break;
@@ -392,7 +434,11 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         if (!CORR) {
             const float vp = v0p - v1p, vm = v0m - v1m;
             const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
+#if defined(PK_EXP_F32_ACC)
+            acc32 += consistency * dkappa;
+#else
             acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
+#endif
         } else {
             const float one_over_n = kappa_max / kappa;
             mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
@@ -400,6 +446,9 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
             mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
         }
     }
+#if defined(PK_EXP_F32_ACC)
+    acc += (double)acc32;
+#endif
 }
 
 // The kappa loop of one pair, exact per-sample path.
@@ -410,6 +459,8 @@ __device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&
                                            double& mom3, double& mom4)
 {
     const float dkappa = K1[6], kappa_max = K1[7];
+    // (Two kappa steps per trip with all eight gathers issued before the first is consumed were measured for the pairs
+    // with kappa_max > pi/4, which wait on memory: no change, 0.3349 vs 0.3340 ms for the benchmark's launch.)
     for (int k = lane; k < k_limit; k += 64)
         if (!kappa_step<DERIV, CORR, REDUCE, PITCH4>(k, K0, K1, dkappa, kappa_max, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
                                                      dist_bias, pitch4_f, acc, mom2, mom3, mom4))
@@ -605,10 +656,9 @@ __device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, doubl
 // monomials can be folded into the lower ones at an error of at most |c_n| / 2^(n-1) + |c_(n-1)| / 2^(n-2) -- two to
 // three orders of magnitude less than dropping them.  Lowers the degree two at a time while the accumulated bound
 // stays below 2e-8 bins and returns the degree the pair kernel has to evaluate (10, 8, 6 or 4); c is updated.
-__device__ __forceinline__ int economise(double* c)
+__device__ __forceinline__ int economise(double* c, double tol)
 {
     static_assert(ECC_POLY_DEG == 10, "degree classes 4 / 6 / 8 / 10");
-    const double tol = 2e-8;
     double err = fabs(c[10]) * (1.0 / 512.0) + fabs(c[9]) * (1.0 / 256.0);
     if (!(err <= tol)) return 10;
     {   // T10 = 512x^10 - 1280x^8 + 1120x^6 - 400x^4 + 50x^2 - 1,  T9 = 256x^9 - 576x^7 + 432x^5 - 120x^3 + 9x
@@ -708,7 +758,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 #if defined(PK_EXP_NO_ECONOMISE)
     if (ok) ok = ECC_POLY_DEG;
 #else
-    if (ok) ok = economise(c);
+    if (ok) ok = economise(c, (double)p.economise_tol);
 #endif
     ok_flags[role][slot] = ok;
     if (angle_role) {
@@ -761,8 +811,13 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     }
 }
 
+#if defined(PK_WAVES_PER_EU)  // experiment: cap the scalar registers so that PK_WAVES_PER_EU waves fit a SIMD
+#define PK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER_EU, PK_WAVES_PER_EU)))
+#else
+#define PK_OCCUPANCY
+#endif
 template <bool DERIV, bool CORR>
-__global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
+__global__ __launch_bounds__(PK_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Workgroup -> pairs.  XCD-aware: workgroups b and b+8 share an XCD, and an XCD walks a contiguous part of the
@@ -777,6 +832,9 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     // waves, 89 us with two, 106 us with four waves per pair.)
     // (Persistent waves -- a launch sized to be resident at once, every wave handling several pairs in turn -- were
     // measured too: 79 800 pairs 0.38 / 0.43 ms with 5 / 10 pairs per wave against 0.33 ms, the shard 86 us with two.)
+#if defined(PK_EXP_STAMPS)  // diagnostic build: wave start / end times (100 MHz), XCC id and path -> K01_out[16 * pair + 0..5]
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const long long nblk = (p.count + 3) / 4;
     const long long per_xcd = (nblk + 7) / 8;
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -811,7 +869,20 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     double acc = 0.0;
     double mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;  // CORR: sums of x*x, y*y, x*y (x, y alone are not used by cc())
     const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
+#if defined(PK_EXP_FORCE_DEG)   // timing experiment: every pair on the polynomial path at this degree (wrong results)
+    const int poly_ok = PK_EXP_FORCE_DEG;
+#elif defined(PK_EXP_NO_EXACT)  // timing experiment: pairs of the exact path take degree 8 instead (wrong results for them)
+    const int poly_ok_rec = __builtin_amdgcn_readfirstlane(rec->poly_ok);
+    const int poly_ok = poly_ok_rec ? poly_ok_rec : 8;
+#elif defined(PK_EXP_NO_DEG10)  // timing experiment: degree-10 pairs take degree 8 (slightly wrong results for them)
+    const int poly_ok_rec = __builtin_amdgcn_readfirstlane(rec->poly_ok);
+    const int poly_ok = poly_ok_rec > 8 ? 8 : poly_ok_rec;
+#else
     const int poly_ok = __builtin_amdgcn_readfirstlane(rec->poly_ok);
+#endif
+#if defined(PK_EXP_ONLY_DEG)    // timing experiment: the kernel contains nothing but this one instantiation (wrong results)
+    kappa_loop_poly<DERIV, CORR, 6400, PK_EXP_ONLY_DEG>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4);
+#else
     if (poly_ok) {
 #define ECC_POLY_LOOP(P4, DEG) \
     kappa_loop_poly<DERIV, CORR, P4, DEG>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4)
@@ -828,6 +899,23 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
             else ECC_POLY_LOOP(0, ECC_POLY_DEG);
         }
 #undef ECC_POLY_LOOP
+#if defined(PK_EXP_SKIP_HEAVY)   // timing experiment: the pairs with kappa_max > pi/4 do nothing (wrong results)
+    } else if (reduce) {
+#endif
+    } else if (reduce && p.quads) {
+        // kappa_max > pi/4: in practice the pairs whose baseline passes through the object (kappa_max = pi/2).  Their
+        // sampling curve crosses the whole Radon intermediate diagonally -- the 64 samples of a gather sit in ~17
+        // different angle rows, one cache line each in the row-major copies -- and on their own they are memory-bound
+        // (27.6 us per 1000 pairs against 8.5 us with the loads removed, scripts/exp_pair_classes.py).  In the row-quad
+        // copy four consecutive rows share a line: 11.3 us per 1000 such pairs.  OPT-IN (ECC_QUAD_COPIES=1, 4x the slab
+        // memory): inside the benchmark's mixed launch, where these are 3.5 % of the pairs, it buys 1 % (0.328 vs
+        // 0.331 ms) -- there they cost 5 % as their own wave time and 5 % by slowing everybody else down
+        // (scripts/exp_wave_timeline.py: a degree-8 wave takes 26.2 us next to them, 25.0 us without), whichever copy
+        // they sample.  Useful for per-sample / index-list workloads made of such pairs.
+        const SlabView q0 = {reinterpret_cast<const char*>(p.quads[iD0]), p.quad_group_bytes};
+        const SlabView q1 = {reinterpret_cast<const char*>(p.quads[iD1]), p.quad_group_bytes};
+        kappa_loop<DERIV, CORR, true, ECC_QUAD_LAYOUT>(lane, p.k_limit, K0, K1, q0, q1, n_alpha_f, n_t_f, dist_scale, dist_bias,
+                                                       pitch4_f, acc, mom2, mom3, mom4);
     } else if (p.wide_offsets) {
         kappa_loop<DERIV, CORR, true, -1>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
                                           pitch4_f, acc, mom2, mom3, mom4);
@@ -842,6 +930,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
         kappa_loop<DERIV, CORR, true, 0>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
                                          pitch4_f, acc, mom2, mom3, mom4);
     }
+#endif
     float val;
     if (!CORR) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
@@ -861,6 +950,15 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_kernel(EccPairParams p)
     if (lane == 0) {
         if (p.pair_values) p.pair_values[local] = val;
         if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
+#if defined(PK_EXP_STAMPS)
+        if (p.K01_out) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            unsigned* o = reinterpret_cast<unsigned*>(p.K01_out + 16 * local);
+            o[0] = (unsigned)t_start; o[1] = (unsigned)(t_start >> 32); o[2] = (unsigned)t_end; o[3] = (unsigned)(t_end >> 32);
+            o[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+            o[5] = (unsigned)poly_ok | (reduce ? 0x100u : 0u);
+        }
+#endif
     }
     // (Fusing the final float64 sum in here -- last-ticket wave reduces -- was measured and dropped: one
     // device-scope atomic per wave on a single counter serialises, 0.51 -> 1.05 ms, and with acquire/release
@@ -1111,6 +1209,37 @@ __global__ __launch_bounds__(256) void build_paired_kernel(const float* const* _
 }
 
 }  // namespace
+
+namespace {
+// Row-quad copy of a dtr for the pairs that sweep many angle rows per gather (see pairs_kernel): per group g of four
+// padded rows and bin j four float4 footprints (row 4g+q, bin j) = { S(r,j), S(r+1,j), S(r,j+1), S(r+1,j+1) }, q = 0..3,
+// so that one 128-byte line holds 4 rows x 2 bins.  rows = n_alpha + 1 footprint rows, groups = ceil(rows / 4); rows
+// past the slab repeat its last row pair (never sampled).  4x the slab's size (3.9 GB for 400 views of 768 x 768 bins).
+__global__ __launch_bounds__(256) void build_quad_kernel(const float* const* __restrict__ slabs, F4* __restrict__ quads,
+                                                         int64_t quad_stride_f4, int rows, int pitch)
+{
+    const float* __restrict__ s = slabs[blockIdx.z];
+    F4* __restrict__ d = quads + (int64_t)blockIdx.z * quad_stride_f4;
+    const int g = blockIdx.y;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < pitch * 4; e += gridDim.x * blockDim.x) {
+        const int j = e >> 2, q = e & 3;
+        const int r = min(4 * g + q, rows - 1);
+        const int j1 = min(j + 1, pitch - 1);
+        const F4 v = {s[(size_t)r * pitch + j], s[(size_t)(r + 1) * pitch + j], s[(size_t)r * pitch + j1],
+                      s[(size_t)(r + 1) * pitch + j1]};
+        d[(size_t)g * pitch * 4 + e] = v;
+    }
+}
+}  // namespace
+
+extern "C" hipError_t ecc_launch_build_quad(const float* const* slabs_tbl_d, float* quads_d, int64_t quad_stride_floats, int n,
+                                            int rows, int pitch, hipStream_t stream)
+{
+    dim3 grid((pitch * 4 + 255) / 256, (rows + 3) / 4, n);
+    hipLaunchKernelGGL(build_quad_kernel, grid, dim3(256), 0, stream, slabs_tbl_d, reinterpret_cast<F4*>(quads_d),
+                       quad_stride_floats / 4, rows, pitch);
+    return hipGetLastError();
+}
 
 // slabs_tbl_d: device table of n slab pointers (private layout, rows+1 rows each); paired_d: n paired copies of
 // `rows` x pitch x 2 floats each, rows = n_alpha + 1.

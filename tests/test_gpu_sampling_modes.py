@@ -80,3 +80,27 @@ def test_reference_mode_variants(gpu_ctx, oracle_mod, small_scan):
     total, vals = m.useCorrelation(True).evaluate_range(0, 28, want_pairs=True)
     np.testing.assert_allclose(vals, want["pairs"], rtol=2e-5, atol=1e-7)  # 1 - cc: cancellation of a float near 1
     m.close()
+
+
+def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan, monkeypatch):
+    """Opt-in row-quad copies (ECC_QUAD_COPIES=1 at metric creation): the pairs with kappa_max > pi/4 on the per-sample
+    path sample them instead of the row-paired copies -- the same taps, the same arithmetic, identical values; also
+    after refreshRadonIntermediates()."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    m0, _ = _metric(gpu_ctx, s)
+    monkeypatch.setenv("ECC_QUAD_COPIES", "1")
+    m1, dtrs1 = _metric(gpu_ctx, s)
+    monkeypatch.delenv("ECC_QUAD_COPIES")
+    K = m0.debug_K01(0, 28)
+    assert (K[:, 15] > np.pi / 4).sum() >= 3, "the scan needs pairs with kappa_max > pi/4 for this test"
+    for mode in ("per_sample", "polynomial"):
+        a = m0.setSampling(mode).evaluate_range(0, 28, want_pairs=True)
+        b = m1.setSampling(mode).evaluate_range(0, 28, want_pairs=True)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), mode
+    m1.refreshRadonIntermediates()
+    b = m1.setSampling("per_sample").evaluate_range(0, 28, want_pairs=True)
+    a = m0.setSampling("per_sample").evaluate_range(0, 28, want_pairs=True)
+    assert np.array_equal(a[1], b[1])
+    m0.close()
+    m1.close()
