@@ -114,6 +114,9 @@ struct ecc_ctx {
     bool pre_ev_recorded = false;
     float* pre_scratch_d[2] = {nullptr, nullptr};
     size_t pre_scratch_cap[2] = {0, 0};
+    // transposed copy of (a sub-batch of) the projection images for the Radon kernel's transposed tiles
+    float* radon_T_d = nullptr;
+    size_t radon_T_cap = 0;  // floats
 };
 
 struct ecc_dtr {
@@ -389,26 +392,48 @@ int radon_launch(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, i
         rc = ensure_ramp(ctx, n_t);
         if (rc) return rc;
     }
-    EccRadonParams p;
-    p.images = images_d;
-    p.out = slabs;
-    p.trig = ctx->trig_d;
-    p.image_stride = (int64_t)n_u * n_v;
-    p.out_stride = slab_stride;
-    p.n_img = n;
-    p.n_u = n_u;
-    p.n_v = n_v;
-    p.n_alpha = n_alpha;
-    p.n_t = n_t;
-    p.pitch = ecc_layout_pitch(n_t);
-    p.post_process = post;
+    // Workgroups whose lines run closer to x than to y (normal closer to y) stage their LDS tile transposed, from a
+    // transposed copy of the images (radon_kernel.hip): one extra pass over the stack (8 bytes per pixel, ~2 us per
+    // 1024^2 image against ~700 us of Radon kernel).  The copy is scratch in the context, at most RADON_SUB images
+    // (256 MB at 1024^2) at a time; larger batches are launched in sub-batches on the same stream.
+    constexpr int RADON_SUB = 64;
+    const int64_t img_floats = (int64_t)n_u * n_v;
+    const int sub = std::min(n, RADON_SUB);
+    if (ctx->radon_T_cap < (size_t)img_floats * sub) {
+        if (ctx->radon_T_d) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->radon_T_d));
+            ctx->radon_T_d = nullptr;
+            ctx->radon_T_cap = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&ctx->radon_T_d, sizeof(float) * (size_t)img_floats * sub));
+        ctx->radon_T_cap = (size_t)img_floats * sub;
+    }
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    // gridDim.z is limited to 65535; batches are far below that.
-    HIP_TRY(ecc_launch_radon(&p, filter == ECC_FILTER_DERIVATIVE ? 1 : 0, ctx->stream));
+    for (int first = 0; first < n; first += sub) {
+        const int cnt = std::min(sub, n - first);
+        EccRadonParams p;
+        p.images = images_d + img_floats * first;
+        p.imagesT = ctx->radon_T_d;
+        p.out = slabs + slab_stride * first;
+        p.trig = ctx->trig_d;
+        p.image_stride = img_floats;
+        p.out_stride = slab_stride;
+        p.n_img = cnt;
+        p.n_u = n_u;
+        p.n_v = n_v;
+        p.n_alpha = n_alpha;
+        p.n_t = n_t;
+        p.pitch = ecc_layout_pitch(n_t);
+        p.post_process = post;
+        HIP_TRY(ecc_launch_direct_transpose(p.images, ctx->radon_T_d, cnt, n_u, n_v, ctx->stream));
+        HIP_TRY(ecc_launch_radon(&p, filter == ECC_FILTER_DERIVATIVE ? 1 : 0, ctx->stream));
+    }
+    const int pitch = ecc_layout_pitch(n_t);
     if (filter == ECC_FILTER_RAMP) {
         // ref: RadonIntermediate.cu:166-167 (apply1DRampFilter after the plain line integrals)
-        HIP_TRY(ecc_launch_ramp(slabs, slab_stride, n, n_alpha, n_t, p.pitch, ctx->ramp_d, ctx->stream));
-        HIP_TRY(ecc_launch_dtr_border(slabs, slab_stride, n, n_alpha, n_t, p.pitch, ctx->stream));
+        HIP_TRY(ecc_launch_ramp(slabs, slab_stride, n, n_alpha, n_t, pitch, ctx->ramp_d, ctx->stream));
+        HIP_TRY(ecc_launch_dtr_border(slabs, slab_stride, n, n_alpha, n_t, pitch, ctx->stream));
     }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
@@ -514,6 +539,7 @@ ECC_EXPORT int ecc_ctx_destroy(ecc_ctx* ctx)
     if (ctx->pre_ev) (void)hipEventDestroy(ctx->pre_ev);
     for (float* b : ctx->pre_scratch_d)
         if (b) (void)hipFree(b);
+    if (ctx->radon_T_d) (void)hipFree(ctx->radon_T_d);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;

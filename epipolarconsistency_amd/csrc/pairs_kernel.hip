@@ -837,7 +837,12 @@ __global__ __launch_bounds__(PK_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairP
 #endif
     const long long nblk = (p.count + 3) / 4;
     const long long per_xcd = (nblk + 7) / 8;
+#if defined(PK_XCD_CHUNK)  // experiment: XCD x walks chunks x, x + 8, x + 16, ... of PK_XCD_CHUNK blocks instead of one contiguous eighth
+    const long long seq = blockIdx.x >> 3;
+    const long long blk = (seq / PK_XCD_CHUNK) * (8LL * PK_XCD_CHUNK) + (long long)(blockIdx.x & 7) * PK_XCD_CHUNK + (seq % PK_XCD_CHUNK);
+#else
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+#endif
     if (blk >= nblk) return;
     long long local = (long long)wave * nblk + blk;
     if (local >= p.count) return;  // no barriers below: waves leave independently
@@ -1269,6 +1274,9 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
         return hipGetLastError();
     }
     long long per_xcd = (nblk + 7) / 8;
+#if defined(PK_XCD_CHUNK)
+    per_xcd = (nblk + 8LL * PK_XCD_CHUNK - 1) / (8LL * PK_XCD_CHUNK) * PK_XCD_CHUNK;
+#endif
     dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
     if (p->use_corr) {
         if (p->is_derivative)

@@ -70,7 +70,8 @@ __device__ __forceinline__ float tex_global(const float* __restrict__ img, int W
 
 // Same rule on the staged tile.  tile_off = by0*TILE_S + bx0 (tile origin in image texels); the
 // tile already holds clamped (replicated) texels, so taps need no index clamps.
-template <int TILE_S>
+// TRANSP: the tile holds the image transposed (image y is the tile's fast axis; staged from a transposed copy of the image).
+template <int TILE_S, bool TRANSP>
 __device__ __forceinline__ float tex_lds(const float* tile_shifted, float x, float y)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
@@ -78,9 +79,9 @@ __device__ __forceinline__ float tex_lds(const float* tile_shifted, float x, flo
     float fx = xb - fi, fy = yb - fj;
     // fj*TILE_S + fi is an exact small integer in fp32 (|.| < 2^24) whether or not it is fused;
     // tile_shifted = tile - tile_off folds the tile origin into the base (one v_lshl_add per sample).
-    const float* tp = tile_shifted + (int)(fj * (float)TILE_S + fi);
-    float T00 = tp[0], T10 = tp[1];
-    float T01 = tp[TILE_S], T11 = tp[TILE_S + 1];
+    const float* tp = tile_shifted + (TRANSP ? (int)(fi * (float)TILE_S + fj) : (int)(fj * (float)TILE_S + fi));
+    float T00 = tp[0], T10 = tp[TRANSP ? TILE_S : 1];
+    float T01 = tp[TRANSP ? 1 : TILE_S], T11 = tp[TILE_S + 1];
     float r0 = (1.f - fx) * T00 + fx * T10;
     float r1 = (1.f - fx) * T01 + fx * T11;
     return (1.f - fy) * r0 + fy * r1;
@@ -124,7 +125,7 @@ struct RadonShared {
 // banks of a linear layout.  Tried and rejected: a float2 "texel pair" tile read with ds_read_b64 (256 B/clk,
 // 64 banks) halves the LDS cycles but doubles the tile to 74 KB = 2 workgroups per CU, and this kernel needs
 // >= 4 waves per SIMD to keep the VALU fed (2 WG/CU: 0.96 ms with the plain tile, 1.12 ms with pairs).
-template <bool DERIV, int TILE_S>
+template <bool DERIV, int TILE_S, bool TRANSP = false>
 __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared& sh)
 {
     float* tile = sh.tile;
@@ -285,7 +286,8 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
             }
             any = bx1 >= bx0;
             w = bx1 - bx0 + 1, h = by1 - by0 + 1;
-            fits = any && w <= (TILE_S < TILE_W ? TILE_S : TILE_W) && h <= TILE_H;
+            fits = any && (TRANSP ? (h <= (TILE_S < TILE_W ? TILE_S : TILE_W) && w <= TILE_H)
+                                  : (w <= (TILE_S < TILE_W ? TILE_S : TILE_W) && h <= TILE_H));
             if (fits || !any || attempt == 4) break;
             L *= 0.5f;
             __syncthreads();  // everyone has read s_box before it is rewritten
@@ -299,18 +301,24 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
             // Stage the footprint: all of a thread's (up to 36) global loads are issued before the first
             // LDS store so their latencies overlap (a load -> store loop serialises one L2 round trip per
             // element).  Rows by wave-quarter, 32 consecutive texels per half-wave = one 128-B segment.
+            // TRANSP: the same with the roles of x and y exchanged, reading the transposed copy of the image (rows of
+            // length H), so the loads stay coalesced and the LDS stores conflict-free.
             const int cx = tid & 31, ry = tid >> 5;
+            const int fast0 = TRANSP ? by0 : bx0, slow0 = TRANSP ? bx0 : by0;
+            const int nfast = TRANSP ? h : w, nslow = TRANSP ? w : h;
+            const int Wf = TRANSP ? H : W, Hs = TRANSP ? W : H;
+            const float* __restrict__ src = TRANSP ? p.imagesT + (int64_t)blockIdx.z * p.image_stride : img;
             float stage[(TILE_H / RT_STAGE_ROWS) * (TILE_W / 32)];
 #pragma unroll
             for (int q = 0; q < TILE_H / RT_STAGE_ROWS; ++q) {
                 const int r = ry + RT_STAGE_ROWS * q;
-                const int gy = min(max(by0 + r, 0), H - 1);
-                const float* __restrict__ row = img + (size_t)gy * W;
+                const int gs = min(max(slow0 + r, 0), Hs - 1);
+                const float* __restrict__ row = src + (size_t)gs * Wf;
 #pragma unroll
                 for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
                     const int c = cx + 32 * c3;
-                    const int gx = min(max(bx0 + c, 0), W - 1);
-                    stage[q * (TILE_W / 32) + c3] = (r < h && c < w) ? row[gx] : 0.f;
+                    const int gf = min(max(fast0 + c, 0), Wf - 1);
+                    stage[q * (TILE_W / 32) + c3] = (r < nslow && c < nfast) ? row[gf] : 0.f;
                 }
             }
 #pragma unroll
@@ -319,22 +327,22 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
 #pragma unroll
                 for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
                     const int c = cx + 32 * c3;
-                    if (r < h && c < w) tile[r * TILE_S + c] = stage[q * (TILE_W / 32) + c3];
+                    if (r < nslow && c < nfast) tile[r * TILE_S + c] = stage[q * (TILE_W / 32) + c3];
                 }
             }
         }
         __syncthreads();  // (B) tile complete; s_box/s_pend may be rewritten by the next chunk
         if (has) {
             if (fits) {
-                const float* tile_shifted = tile - (by0 * TILE_S + bx0);
+                const float* tile_shifted = tile - (TRANSP ? (bx0 * TILE_S + by0) : (by0 * TILE_S + bx0));
                 // t <= t_max && t < lim  <=>  t <= min(t_max, pred(lim)): one compare per step
                 const float t_end = fminf(t_max, nextafterf(lim, -FLT_MAX));
                 // ref: RadonIntermediate.cu:105-123 (t += step accumulates in fp32)
                 for (; t <= t_end; t += RADON_STEP) {
                     RSTAT(4, 1);
                     float x = o0 + t * d0, y = o1 + t * d1;
-                    sum += tex_lds<TILE_S>(tile_shifted, x, y);
-                    if (DERIV) sumo += tex_lds<TILE_S>(tile_shifted, x + d1, y - d0);
+                    sum += tex_lds<TILE_S, TRANSP>(tile_shifted, x, y);
+                    if (DERIV) sumo += tex_lds<TILE_S, TRANSP>(tile_shifted, x + d1, y - d0);
                 }
             } else {
                 for (; t <= t_max && t < lim; t += RADON_STEP) {
@@ -377,7 +385,21 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
     // line normal of this workgroup's first angle: (nx, ny) = (-sin a, cos a)
     const int ix0 = min((int)blockIdx.x * RT_A, p.n_alpha - 1);
     const float nx = -p.trig[2 * ix0], ny = p.trig[2 * ix0 + 1];
-    if (fabsf(nx + ny) >= fabsf(nx - ny))
+    // Row stride.  A half-wave is two "combs" (two adjacent angles) of 16 points spaced 1.9 px along the line normal; the
+    // two combs nearly coincide, so any bank function gives at least a 2-way conflict between them (simulation:
+    // scripts/analysis/radon_lds_layouts.py).  With stride 96 the bank is the texel's index along the tile's fast axis
+    // alone: a comb whose normal is closer to that axis than to the other advances >= 1.33 banks per lane over < 32 banks,
+    // conflict-free in itself, and the pass costs exactly two cycles.  So: normal closer to x -> plain tile, stride 96;
+    // normal closer to y -> the tile is staged TRANSPOSED (from the transposed copy of the image stack made by
+    // ecc_launch_radon), stride 96 again.  Without the transposed copy (p.imagesT null) those workgroups keep the
+    // 97 / 95 rule (the bank advances along x+y or x-y, whichever the normal is closer to).
+    // Measured per 1024^2 image: 97/95 rule everywhere 0.771 ms, stride 96 for x-normals only 0.740 ms, with the transposed
+    // tile for y-normals as well 0.699 ms.
+    if (fabsf(nx) >= fabsf(ny))
+        radon_body<DERIV, TILE_W>(p, sh);
+    else if (p.imagesT)
+        radon_body<DERIV, TILE_W, true>(p, sh);
+    else if (fabsf(nx + ny) >= fabsf(nx - ny))
         radon_body<DERIV, TILE_W + 1>(p, sh);
     else
         radon_body<DERIV, TILE_W - 1>(p, sh);
