@@ -983,6 +983,20 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
     // eight loads in flight per thread: the kernel is one workgroup reading what other XCDs have just written
     // (HBM latency each time), issued one at a time it took 10 us for 79 800 values
     long long k = threadIdx.x;
+    // (All of a thread's ~20 loads in flight at once would make it one round trip, but 1024 threads x 20 float4 do not fit
+    // the 128 registers a thread of this workgroup may have: it spilled.  Ten per batch = two round trips.)
+    for (; k + 9 * 1024 < n4; k += 10 * 1024) {
+        float4 v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = v4[k + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            a0 += (double)v[u].x;
+            a1 += (double)v[u].y;
+            a2 += (double)v[u].z;
+            a3 += (double)v[u].w;
+        }
+    }
     for (; k + 7 * 1024 < n4; k += 8 * 1024) {
         float4 v[8];
 #pragma unroll
