@@ -193,7 +193,9 @@ def main():
 
     # ---- shard of the pair range --------------------------------------------------------------
     n_pairs = n * (n - 1) // 2
-    first, count = sharding.pair_range(rank, world, n_pairs)
+    # cost-balanced contiguous shards (equal-count shards leave rank 0 the straggler: the expensive pairs of a circular
+    # scan sit in the first rows of the pair triangle); the same boundaries on every rank, fixed for the whole run
+    first, count = sharding.balanced_pair_range(metric, rank, world) if world > 1 else (0, n_pairs)
     sum_t = torch.zeros(1, dtype=torch.float64, device=dev)
     moving = n // 2  # view perturbed per step, like SingleImageMotion does for its input view
 
@@ -233,8 +235,8 @@ def main():
             if world == 1:
                 return metric.evaluate()
             if mode == "shm":
-                return sharding.exchanged_evaluate(metric, n, exchange)
-            return sharding.distributed_evaluate(metric, n, sum_t, rank, world)
+                return sharding.exchanged_evaluate(metric, n, exchange, shard=(first, count))
+            return sharding.distributed_evaluate(metric, n, sum_t, rank, world, shard=(first, count))
         return step
 
     def fence():
@@ -365,7 +367,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%d-projection %dx%d circular short scan, %dx%d Radon bins, all %d pairs"
                                % (n, S, S, B, B, n_pairs),
-                   "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d" % world,
+                   "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d (contiguous, cost-balanced)" % world,
                    "sum_exchange": exch_name[best]},
         "timing": {"value_is": "median of %d blocks of %d steps" % (len(res["blocks"]), args.steps),
                    "blocks_ms_per_step": [1e3 * b / args.steps for b in res["blocks"]],

@@ -94,6 +94,9 @@ SIGNATURES = {
     "ecc_group_ctx": (_i, [_vp, _i, C.POINTER(_vp)]),
     "ecc_group_radon_compute_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_pair_shard": (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
+    "ecc_pair_shards_balanced": (_i, [_vp, _i, _d, _i, _vp]),
+    "ecc_metric_balanced_shards": (_i, [_vp, _i, _vp]),
+    "ecc_group_metric_rebalance": (_i, [_vp]),
     "ecc_group_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "ecc_group_metric_destroy": (_i, [_vp]),
     "ecc_group_metric_set_projections": (_i, [_vp, _vp, _i]),

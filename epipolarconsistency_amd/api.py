@@ -473,6 +473,12 @@ class MetricRadonIntermediate:
         return ecc.value, dict(redundant_samples0=s0[:n], redundant_samples1=s1[:n], kappas=kap[:n],
                                radon_samples0=r0[:n], radon_samples1=r1[:n], K01=K01)
 
+    def balanced_shards(self, world):
+        """ecc_metric_balanced_shards: cost-balanced shard boundaries for the current matrices and object radius."""
+        b = np.zeros(int(world) + 1, np.int64)
+        check(_lib.lib().ecc_metric_balanced_shards(self._h, int(world), C.c_void_p(b.ctypes.data)))
+        return [int(v) for v in b]
+
     def evaluate_range(self, first, count, want_pairs=False):
         """Partial sum over pairs [first, first+count) of the get_ij order (multi-GPU shard)."""
         s = C.c_double()
@@ -588,6 +594,19 @@ def pair_shard(n_pairs, world, rank):
     return a.value, b.value
 
 
+def pair_shards_balanced(Ps, object_radius_mm, world):
+    """ecc_pair_shards_balanced: world + 1 boundaries of contiguous, cost-balanced chunks of the get_ij order (rank r
+    evaluates [b[r], b[r+1])).  Ps: list of 3x4 matrices or an (n, 12) column-major array."""
+    if isinstance(Ps, np.ndarray) and Ps.ndim == 2 and Ps.shape[1] == 12:
+        flat = np.ascontiguousarray(Ps, np.float64)
+    else:
+        flat = _Ps_colmajor(Ps)
+    b = np.zeros(int(world) + 1, np.int64)
+    check(_lib.lib().ecc_pair_shards_balanced(C.c_void_p(flat.ctypes.data), len(flat), float(object_radius_mm), int(world),
+                                              C.c_void_p(b.ctypes.data)))
+    return [int(v) for v in b]
+
+
 class GroupMetricRadonIntermediate:
     """MetricRadonIntermediate over a Group: the same setProjectionMatrices / evaluate calls, every device of the
     group evaluating a contiguous shard of the pair range (ecc_group_metric_* of the C ABI)."""
@@ -639,6 +658,11 @@ class GroupMetricRadonIntermediate:
     def setSampling(self, mode="auto"):
         mode = MetricRadonIntermediate._SAMPLING[mode] if isinstance(mode, str) else int(mode)
         check(_lib.lib().ecc_group_metric_set_sampling(self._h, mode))
+        return self
+
+    def rebalance(self):
+        """Recompute the cost-balanced shard boundaries at the next evaluation (ecc_group_metric_rebalance)."""
+        check(_lib.lib().ecc_group_metric_rebalance(self._h))
         return self
 
     def evaluate(self, cost=None):

@@ -1875,6 +1875,69 @@ ECC_EXPORT void ecc_host_iso_center(const double* Ps, int n_views, double* O)
     O[3] = 1.0;
 }
 
+// ---- cost-balanced shards of the pair range -------------------------------------------------------------------
+// Equal-COUNT chunks of the get_ij order are not equal-TIME chunks: the pair kernel's time per pair grows with the
+// pair's kappa_max (the sampling curve gets longer, a gather touches more cache lines) and the pairs whose baseline
+// passes through the object (kappa_max = pi/2, per-sample path) cost ~5x a short-curve pair; for a circular scan both
+// kinds sit in the first rows of the pair triangle.  Measured on MI355X, 400 views of 1024^2 (scripts/shard_step.py): the
+// eight equal-count shards of an 8-rank job take 93, 88, 84, 72, 71, 71, 70, 68 us per step.  A least-squares fit over the
+// 15 shard timings of 1, 2, 4 and 8 ranks (residual <= 3 us) gives
+//     step = 34.7 us + SUM over the shard's pairs of (2.5 ns + 7.0 ns x kappa_max [kappa_max <= pi/4] + 10.4 ns [kappa_max > pi/4]),
+// i.e. relative weights 1 + 2.8 kappa_max and 5.2.  ecc_pair_shards_balanced cuts the pair range into contiguous chunks of
+// equal model cost (model: 77.5 us for every rank at 8 ranks, 120 us at 4, 206 us at 2).  kappa_max per pair comes from
+// the source positions alone (ref: computeK01, EpipolarConsistencyCommon.hxx:115-123,137-145), float64 on the host,
+// ~0.3 ms for 79 800 pairs -- once per data set, not per evaluation.
+ECC_EXPORT int ecc_pair_shards_balanced(const double* Ps, int n_views, double object_radius_mm, int world, int64_t* bounds)
+{
+    if (!Ps || !bounds) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_views < 2 || world < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "need two views and one rank at least");
+    const int64_t n = n_views, n_pairs = n * (n - 1) / 2;
+    std::vector<double> C(4 * (size_t)n);
+    for (int v = 0; v < n_views; ++v) {
+        float c4[4];
+        ecc_host::source_position(Ps + 12 * (size_t)v, c4);
+        for (int k = 0; k < 4; ++k) C[4 * (size_t)v + k] = c4[k];
+    }
+    std::vector<double> prefix((size_t)n_pairs + 1);
+    prefix[0] = 0.0;
+    int64_t q = 0;
+    for (int i = 0; i < n_views; ++i)
+        for (int j = i + 1; j < n_views; ++j, ++q) {
+            const double *a = &C[4 * (size_t)i], *b = &C[4 * (size_t)j];
+            const double B01 = a[0] * b[1] - a[1] * b[0], B02 = a[0] * b[2] - a[2] * b[0], B03 = a[0] * b[3] - a[3] * b[0];
+            const double B12 = a[1] * b[2] - a[2] * b[1], B13 = a[1] * b[3] - a[3] * b[1], B23 = a[2] * b[3] - a[3] * b[2];
+            const double s2 = std::sqrt(B12 * B12 + B02 * B02 + B01 * B01), s3 = std::sqrt(B03 * B03 + B13 * B13 + B23 * B23);
+            const double dist = s2 / s3;  // baseline to origin
+            double w;
+            if (!(dist > object_radius_mm)) w = 5.2;                       // kappa_max = pi/2 (also NaN geometry)
+            else {
+                const double kmax = std::asin(object_radius_mm / dist);
+                w = kmax > 0.78539816339744831 ? 5.2 : 1.0 + 2.8 * kmax;
+            }
+            prefix[(size_t)q + 1] = prefix[(size_t)q] + w;
+        }
+    const double total = prefix[(size_t)n_pairs];
+    bounds[0] = 0;
+    for (int r = 1; r < world; ++r) {
+        const double target = total * (double)r / (double)world;
+        int64_t b = std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin();
+        b = std::max<int64_t>(bounds[r - 1], std::min<int64_t>(b, n_pairs));
+        bounds[r] = b;
+    }
+    bounds[world] = n_pairs;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_balanced_shards(ecc_metric* m, int world, int64_t* bounds)
+{
+    if (!m || !bounds) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (m->n_views < 2) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
+    double radius = 0;
+    ecc_metric_get_object_radius(m, &radius);
+    // the matrices of the last setProjectionMatrices are still in their pinned staging buffer
+    return ecc_pair_shards_balanced(m->Ps_h[m->set_generation & 1], m->n_views, radius, world, bounds);
+}
+
 // ---- debug: the fitted sample-coordinate polynomials ---------------------------------------------
 ECC_EXPORT int ecc_metric_debug_polynomials(ecc_metric* m, int64_t first, int64_t count, float* out)
 {

@@ -270,6 +270,9 @@ struct ecc_group_metric {
     // hand-off (the optimiser pattern is set, evaluate, set, evaluate, ...)
     std::vector<double> pending_Ps;
     bool pending = false;
+    // cost-balanced shard boundaries (ecc_pair_shards_balanced), fixed at the first evaluation / by ..._rebalance
+    std::vector<int64_t> bounds;
+    int bounds_views = 0;
 };
 
 ECC_EXPORT int ecc_group_metric_destroy(ecc_group_metric* gm)
@@ -448,12 +451,29 @@ int group_evaluate(ecc_group_metric* gm, const double* Ps, int n_views, float* c
         gm->pair_values.resize((size_t)n_pairs);
         vals = gm->pair_values.data();
     }
+    if (gm->bounds_views != n_views || (int)gm->bounds.size() != G + 1) {
+        // first evaluation with this many views: fix the shard boundaries from the matrices at hand
+        const double* P = Ps ? Ps : nullptr;
+        std::vector<int64_t> b((size_t)G + 1);
+        int e = ECC_OK;
+        if (P) {
+            double radius = 0;
+            ecc_metric_set_projections(gm->metrics[0], P, n_views);  // rank 0 knows the matrices for the radius estimate
+            e = ecc_metric_get_object_radius(gm->metrics[0], &radius);
+            if (e == ECC_OK) e = ecc_pair_shards_balanced(P, n_views, radius, G, b.data());
+        } else {
+            e = ecc_metric_balanced_shards(gm->metrics[0], G, b.data());
+        }
+        if (e != ECC_OK) return e;
+        gm->bounds = b;
+        gm->bounds_views = n_views;
+    }
+    const int64_t* bounds = gm->bounds.data();
     int rc = run_all(g, [=](int r) -> int {
         int e = ECC_OK;
         if (Ps) e = ecc_metric_set_projections(gm->metrics[r], Ps, n_views);
         if (e != ECC_OK) return e;
-        int64_t first = 0, count = 0;
-        ecc_pair_shard(n_pairs, G, r, &first, &count);
+        const int64_t first = bounds[r], count = bounds[r + 1] - bounds[r];
         return ecc_metric_evaluate_range(gm->metrics[r], first, count, vals ? vals + first : nullptr, &gm->partial[r]);
     });
     if (rc != ECC_OK) return rc;
@@ -470,6 +490,14 @@ int group_evaluate(ecc_group_metric* gm, const double* Ps, int n_views, float* c
 }
 
 }  // namespace
+
+ECC_EXPORT int ecc_group_metric_rebalance(ecc_group_metric* gm)
+{
+    if (!gm) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "group metric is null");
+    gm->bounds.clear();  // recomputed by the next evaluation from the matrices it runs with
+    gm->bounds_views = 0;
+    return ECC_OK;
+}
 
 ECC_EXPORT int ecc_group_metric_set_projections(ecc_group_metric* gm, const double* Ps, int n_views)
 {

@@ -17,6 +17,15 @@ def pair_range(rank, world, n_pairs):
     return first, (rank + 1) * n_pairs // world - first
 
 
+def balanced_pair_range(metric, rank, world):
+    """Cost-balanced contiguous shard of `rank` (ecc_metric_balanced_shards): the pair kernel's time per pair grows
+    with the pair's kappa_max, and for a circular scan the expensive pairs sit in the first rows of the pair triangle,
+    so equal-count shards leave rank 0 the straggler (8 ranks: 93 us against 68 us).  Every rank computes the same
+    boundaries from the same matrices.  Call once per data set and keep the result for all evaluations."""
+    b = metric.balanced_shards(world)
+    return b[rank], b[rank + 1] - b[rank]
+
+
 def view_range(rank, world, n_views):
     """Views whose Radon intermediates `rank` computes before the all-gather (equal chunks, the
     last ranks may get fewer)."""
@@ -38,11 +47,12 @@ def allreduce_mean(partial_sum_tensor, n_pairs, group=None):
     return float(partial_sum_tensor.item()) / n_pairs
 
 
-def distributed_evaluate(metric, n_views, sum_tensor, rank, world, group=None):
+def distributed_evaluate(metric, n_views, sum_tensor, rank, world, group=None, shard=None):
     """One all-pairs evaluation sharded over `world` ranks: launches this rank's shard
-    asynchronously on the metric's stream, all-reduces the 8-byte partial sum, returns the mean."""
+    asynchronously on the metric's stream, all-reduces the 8-byte partial sum, returns the mean.
+    shard: (first, count) of this rank (default: the equal-count chunk)."""
     n_pairs = n_views * (n_views - 1) // 2
-    first, count = pair_range(rank, world, n_pairs)
+    first, count = shard if shard is not None else pair_range(rank, world, n_pairs)
     metric.evaluate_range_async(first, count, sum_tensor)
     return allreduce_mean(sum_tensor, n_pairs, group)
 
@@ -102,11 +112,12 @@ def default_exchange_name():
     return "/ecc_hip_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
 
 
-def exchanged_evaluate(metric, n_views, exchange):
+def exchanged_evaluate(metric, n_views, exchange, shard=None):
     """One all-pairs evaluation sharded over the ranks of `exchange`: this rank's shard through the synchronous
-    range call (partial sum lands in pinned host memory), then the host-side sum; returns the mean."""
+    range call (partial sum lands in pinned host memory), then the host-side sum; returns the mean.
+    shard: (first, count) of this rank (default: the equal-count chunk)."""
     n_pairs = n_views * (n_views - 1) // 2
-    first, count = pair_range(exchange.rank, exchange.world, n_pairs)
+    first, count = shard if shard is not None else pair_range(exchange.rank, exchange.world, n_pairs)
     return exchange.sum(metric.evaluate_range(first, count)) / n_pairs
 
 

@@ -319,8 +319,8 @@ void ecc_host_iso_center(const double* Ps, int n_views, double* O);
 /* The reference's callers are one process, one optimiser thread: ecc->setProjectionMatrices(Ps); ecc->evaluate()
  * (ref: Gui/SingleImageMotion.h:84-90, HeaderOnly/LibOpterix/WrapNLOpt.hxx:151-173).  A group gives such a caller
  * every GPU of the node: one context, stream and host thread per device, the Radon-intermediate stack replicated on
- * every device, the pair range cut into contiguous equal-count shards of the get_ij order (ecc_pair_shard), the
- * partial sums (8 bytes per device, pinned host memory) added on the host in rank order -- the same bits on every
+ * every device, the pair range cut into contiguous cost-balanced shards of the get_ij order (ecc_pair_shards_balanced,
+ * fixed at the first evaluation; ecc_group_metric_rebalance recomputes them), the partial sums (8 bytes per device, pinned host memory) added on the host in rank order -- the same bits on every
  * call.  Nothing is exchanged between devices on the per-evaluation path.
  * devices: n_dev HIP device indices (NULL = 0 .. n_dev-1).  An index may repeat: ranks on the same device get their
  * own stream and thread and share the caller's slabs (rehearsal of the multi-rank path on one GPU). */
@@ -339,6 +339,14 @@ int ecc_group_radon_compute_batch(ecc_group* g, const float* images, int n, int 
                                   int filter, int post_process, ecc_dtr** out);
 /* rank r of `world` evaluates pairs [first, first + count) of the get_ij order: first = r*n_pairs/world (integer). */
 void ecc_pair_shard(int64_t n_pairs, int world, int rank, int64_t* first, int64_t* count);
+/* Cost-balanced alternative: contiguous chunks of equal MODEL COST instead of equal count -- the pair kernel's time per
+ * pair grows with the pair's kappa_max, and for a circular scan the expensive pairs sit in the first rows of the pair
+ * triangle (equal-count shards of an 8-rank job measured 93 ... 68 us; model for balanced shards 77.5 us each; the fit is in
+ * ecc_capi.hip).  bounds receives world + 1 pair indices, rank r evaluates [bounds[r], bounds[r+1]).  Host, float64, a
+ * function of the matrices and the object radius only (every rank of a job computes the same bounds); ~0.3 ms for 400
+ * views -- once per data set.  ecc_metric_balanced_shards uses the metric's current matrices and object radius. */
+int ecc_pair_shards_balanced(const double* Ps, int n_views, double object_radius_mm, int world, int64_t* bounds);
+int ecc_metric_balanced_shards(ecc_metric* m, int world, int64_t* bounds);
 
 /* ref: MetricRadonIntermediate(Ps, dtrs) (...RadonIntermediate.cpp:53-66,87-106) over a group.  dtrs may live on
  * any devices; every rank gets a replica of the whole stack (device-to-device copies, peer access where available;
@@ -356,6 +364,9 @@ int ecc_group_metric_get_object_radius(ecc_group_metric* gm, double* radius_mm);
  * cost_nxn (host, nullable): entry (i,j), i<j at index i + j*n is written, the rest preserved.  With one rank the
  * result is bit-identical to ecc_metric_evaluate_all; with G ranks it is the rank-ordered float64 sum of G shard sums. */
 int ecc_group_metric_evaluate_all(ecc_group_metric* gm, float* cost_nxn, double* mean);
+/* Recompute the cost-balanced shard boundaries from the current matrices (they are otherwise fixed at the first
+ * evaluation so that repeated evaluations add the same partial sums in the same order). */
+int ecc_group_metric_rebalance(ecc_group_metric* gm);
 /* The per-rank metric (borrowed): few-pair calls (index lists, evaluateForImagePair) go to rank 0's metric.  Pending
  * projection matrices are handed to the devices first. */
 int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m);

@@ -24,11 +24,16 @@ for a in range(0, n, 50):
 dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs[k], B, B, S, S) for k in range(n)]
 metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
 P = E.pack_projection_matrices(Ps)
-first, count = sharding.pair_range(world // 2, world, n * (n - 1) // 2)
-for _ in range(20):
-    metric.setProjectionMatrices(P); metric.evaluate_range(first, count)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(steps):
-    metric.setProjectionMatrices(P); metric.evaluate_range(first, count)
-torch.cuda.synchronize()
-print("world %d: %d pairs per rank, %.1f us per step (one rank, no exchange)" % (world, count, 1e6 * (time.perf_counter() - t0) / steps))
+ranks = [int(r) for r in sys.argv[3].split(",")] if len(sys.argv) > 3 else [world // 2]
+for rank in ranks:
+    if os.environ.get("ECC_EQUAL_COUNT_SHARDS"):
+        first, count = sharding.pair_range(rank, world, n * (n - 1) // 2)
+    else:
+        first, count = sharding.balanced_pair_range(metric, rank, world)
+    for _ in range(20):
+        metric.setProjectionMatrices(P); metric.evaluate_range(first, count)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        metric.setProjectionMatrices(P); metric.evaluate_range(first, count)
+    torch.cuda.synchronize()
+    print("world %d rank %d: %d pairs, %.1f us per step (one rank, no exchange)" % (world, rank, count, 1e6 * (time.perf_counter() - t0) / steps))

@@ -25,6 +25,39 @@ def test_pair_shard_arithmetic():
     assert E.pair_shard(79800, 8, 3) == (29925, 9975)  # BASELINE config 4: 9 975 pairs per GPU
 
 
+def test_balanced_shards_model():
+    """ecc_pair_shards_balanced against a numpy statement of its cost model (weights 1 + 2.8 kappa_max, 5.2 for
+    kappa_max > pi/4; kappa_max from the source positions as in computeK01): contiguous, complete, every shard within
+    one pair's weight of the mean cost, and -- for a circular scan -- fewer pairs for the first ranks."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    n, S = 400, 1024
+    Ps = synthetic.short_scan(n, S, S, 0.308)
+    radius = E.host_object_radius(Ps[0], S, S)
+    C = np.stack([E.host_source_position(P).astype(np.float64) for P in Ps])
+    iu = np.triu_indices(n, 1)
+    a, b = C[iu[0]], C[iu[1]]
+
+    def w2(p, q):
+        return a[:, p] * b[:, q] - a[:, q] * b[:, p]
+    s2 = np.sqrt(w2(1, 2) ** 2 + w2(0, 2) ** 2 + w2(0, 1) ** 2)
+    s3 = np.sqrt(w2(0, 3) ** 2 + w2(1, 3) ** 2 + w2(2, 3) ** 2)
+    dist = s2 / s3
+    kmax = np.where(dist > radius, np.arcsin(np.minimum(radius / dist, 1.0)), np.pi / 2)
+    w = np.where(kmax > np.pi / 4, 5.2, 1.0 + 2.8 * kmax)
+    n_pairs = n * (n - 1) // 2
+    for world in (1, 2, 4, 8, 7):
+        bnd = E.pair_shards_balanced(Ps, radius, world)
+        assert bnd[0] == 0 and bnd[-1] == n_pairs and len(bnd) == world + 1 and all(x <= y for x, y in zip(bnd, bnd[1:]))
+        cost = np.array([w[bnd[r]:bnd[r + 1]].sum() for r in range(world)])
+        assert np.all(np.abs(cost - w.sum() / world) <= 5.3), (world, cost)
+    bnd = E.pair_shards_balanced(Ps, radius, 8)
+    counts = np.diff(bnd)
+    assert counts[0] < counts[3] < counts[7] and counts[0] < 0.8 * n_pairs / 8  # the expensive pairs come first
+    with pytest.raises(E.EccError):
+        E.pair_shards_balanced(Ps[:1], radius, 2)
+
+
 @pytest.mark.gpu
 def test_one_rank_group_is_the_plain_metric(gpu_ctx, small_scan):
     import epipolarconsistency_amd as E
@@ -60,7 +93,9 @@ def test_multi_rank_group_on_one_device(gpu_ctx, oracle_mod, small_scan, ranks):
     m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"])
                                                      for d in s["dtrs"]])
     total, vals = m.evaluate_range(0, 28, want_pairs=True)
-    parts = [m.evaluate_range(*E.pair_shard(28, ranks, r)) for r in range(ranks)]
+    bnd = m.balanced_shards(ranks)  # the group cuts the pair range into cost-balanced contiguous shards
+    assert bnd[0] == 0 and bnd[-1] == 28 and bnd == E.pair_shards_balanced(s["Ps"], m.getObjectRadius(), ranks)
+    parts = [m.evaluate_range(bnd[r], bnd[r + 1] - bnd[r]) for r in range(ranks)]
     cost = np.full((8, 8), -1.0, np.float32)
     mean = gm.evaluate(cost)
     acc = 0.0
@@ -90,6 +125,7 @@ def test_multi_rank_group_on_one_device(gpu_ctx, oracle_mod, small_scan, ranks):
     gm.setProjectionMatrices(s["Ps"])
     gm.setObjectRadius(0.0, 0.0)
     assert gm.evaluate() == mean
+    assert abs(gm.rebalance().evaluate() - mean) <= 1e-13 * mean  # same geometry: the same boundaries again
     gm.close()
     m.close()
     del dtrs
