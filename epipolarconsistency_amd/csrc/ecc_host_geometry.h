@@ -7,11 +7,12 @@
 // and Metric::getObjectRadius' estimate (ref: EpipolarConsistency.cpp:35-47,76-84).
 //
 // P P^T of a C-arm projection matrix has a condition number of ~1e11, so the float32 results
-// depend on HOW the inverse is formed.  To be a drop-in, this code performs the same Householder
-// QR factorisation + back substitution, with the same operation order in binary64, as the
-// reference's culaut routines (xgeinv.hxx:40-168); it is written from that arithmetic
-// specification, not from the reference text, and is checked bit-for-bit against the
-// reference headers in tests/test_oracle_pins.py.
+// depend on HOW the inverse is formed.  To be a drop-in, householder_qr / back_substitute below
+// follow the reference's culaut routines (xsqqr / xutsolve / xgeinv, xgeinv.hxx:40-168) step for
+// step -- the same Householder QR with the same operation order in binary64, including its
+// never-reset running column scale: any other order gives different float32 bits at this
+// condition number.  Bit equality with the reference headers (compiled where they lie) is
+// checked in tests/test_oracle_pins.py; everything around these ~70 lines is this project's.
 #ifndef ECC_HOST_GEOMETRY_H
 #define ECC_HOST_GEOMETRY_H
 
