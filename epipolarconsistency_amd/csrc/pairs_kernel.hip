@@ -830,6 +830,11 @@ __global__ __launch_bounds__(PK_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairP
     // (Several waves per pair for small shards -- wave h takes the kappa iterations it % split == h, float64 partial
     // sums combined by the sum kernel -- were measured and dropped: a 9 975-pair shard 80 us per step with whole-pair
     // waves, 89 us with two, 106 us with four waves per pair.)
+    // (A host-made launch schedule that gives the kappa_max = pi/2 pairs evenly spaced positions, everything else keeping
+    // its order: with explicit index lists over all 79 800 pairs it looked promising -- natural order 0.361 ms, those
+    // pairs first 0.460, last 0.422, as whole workgroups first 0.601, spread evenly 0.348, scripts/exp_heavy_first.py --
+    // but built into this mapping it was 1.5 % SLOWER, 0.3365 vs 0.3315 ms: the four-quarters mapping already spreads
+    // them over the first quarter of every workgroup.)
     // (Persistent waves -- a launch sized to be resident at once, every wave handling several pairs in turn -- were
     // measured too: 79 800 pairs 0.38 / 0.43 ms with 5 / 10 pairs per wave against 0.33 ms, the shard 86 us with two.)
 #if defined(PK_EXP_STAMPS)  // diagnostic build: wave start / end times (100 MHz), XCC id and path -> K01_out[16 * pair + 0..5]
