@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--exchange", default="both", choices=["both", "shm", "collective"],
                     help="N > 1: per-evaluation sum of the partial results through the library's shared-memory "
                          "exchange, an all-reduce of a device scalar, or (default) both, one after the other")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not run the rocprofv3 --pmc pass of this same bench (a child process, ~15 s) that "
+                         "measures the pair kernel's HBM bytes and vector instructions for the roofline objects; the "
+                         "committed profiles/pmc_current.json is used instead")
     ap.add_argument("--blocks", type=int, default=0,
                     help="number of timed K-step blocks (0 = automatic: up to 9, about 1 s in total)")
     ap.add_argument("--single-device", action="store_true",
@@ -104,6 +108,48 @@ def load_pmc(kernel_prefix):
     except Exception:
         pass
     return None
+
+
+def live_pmc(args):
+    """One rocprofv3 --pmc pass over a short run of THIS bench (child process: python3 bench.py --steps 3 --no-live-pmc):
+    per-launch averages of FETCH_SIZE, SQ_INSTS_VALU and SQ_INSTS_VMEM_RD of the pair kernel, measured on this box in
+    this run.  FETCH_SIZE (TCC) and the SQ counters fit one pass; WRITE_SIZE cannot ride along (TCC slots,
+    MI355X_MICROARCH.md) and is taken as the kernel's algorithmic 4 bytes per pair (the separate pass under profiles/
+    measures 328 KiB for 79 800 pairs: 4.2 B per pair).  Returns a dict or None (rocprofv3 missing, timeout, parse error)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out_dir = tempfile.mkdtemp(prefix="ecc_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "--output-format", "csv",
+               "-d", out_dir, "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--blocks", "3",
+               "--no-cpu-baseline", "--no-live-pmc", "--views", str(args.views), "--size", str(args.size), "--bins", str(args.bins)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        per = {}
+        for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "pairs_kernel<true, false>" in r["Kernel_Name"]:
+                    # a dispatch's counter can come in several rows (one per XCC group): they add up
+                    key = (r["Dispatch_Id"], r["Counter_Name"])
+                    per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
+        res = {}
+        for name in ("FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD"):
+            v = [val for (d, c), val in per.items() if c == name]
+            if not v:
+                return None
+            res[name] = sum(v) / len(v)
+        res["dispatches"] = len([1 for (d, c) in per if c == "FETCH_SIZE"])
+        return res
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
 
 
 def n_kappa_auto(n_u, n_v, n_t):
@@ -315,6 +361,13 @@ def main():
                     "note": "algorithmic gather bytes through the vector L1: %.0f B/clk/CU x %d CUs x %.1f GHz"
                             % (L1_BYTES_PER_CLK_CU, N_CU, ENGINE_CLOCK_GHZ)}}
     pmc = load_pmc("pairs_kernel<true, false>") if (world == 1 and (n, S, B) == (400, 1024, 768)) else None
+    pmc_origin = "separate rocprofv3 --pmc passes of bench.py --steps 5, profiles/pmc_current.json (%s); not this run" % (pmc or {}).get("_tag")
+    live = live_pmc(args) if (world == 1 and rank == 0 and not args.no_live_pmc) else None
+    if live:
+        pmc = {"SQ_INSTS_VALU": live["SQ_INSTS_VALU"], "FETCH_SIZE": live["FETCH_SIZE"], "WRITE_SIZE": 4.0 * count / 1024.0,
+               "SQ_INSTS_VMEM_RD": live["SQ_INSTS_VMEM_RD"], "_tag": "live"}
+        pmc_origin = ("measured in this run: one rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_VMEM_RD pass over "
+                      "a child run of this bench (--steps 3), %d launches averaged; WRITE_SIZE taken as 4 B per pair" % live["dispatches"])
     traffic, traffic_src = None, None
     if pmc and "SQ_INSTS_VALU" in pmc and pair_ms > 0:
         valu_peak = N_CU * SIMD_PER_CU * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTR  # G wave-instructions/s
@@ -322,10 +375,11 @@ def main():
         roofs["valu"] = {"achieved": valu_ach, "peak": valu_peak, "unit": "G wave-instr/s", "frac": valu_ach / valu_peak,
                          "note": "SQ_INSTS_VALU = %.4g per launch (PMC, %s) at %.0f cycles per wave64 instruction on %d SIMDs"
                                  % (pmc["SQ_INSTS_VALU"], pmc["_tag"], VALU_CYCLES_PER_WAVE_INSTR, N_CU * SIMD_PER_CU)}
+        if "SQ_INSTS_VMEM_RD" in pmc:
+            roofs["l1"]["gathers_per_launch"] = pmc["SQ_INSTS_VMEM_RD"]
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         traffic = int(2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024)
-        traffic_src = ("PMC, not this run: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 counts 128-B fabric reads as 64 B) "
-                       "from separate rocprofv3 --pmc passes of bench.py --steps 5, profiles/pmc_current.json (%s)" % pmc["_tag"])
+        traffic_src = "2 x FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 counts 128-B fabric reads as 64 B); " + pmc_origin
         roofs["hbm_measured"] = {"achieved": traffic / pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": traffic / pair_s / 1e9 / HBM_PEAK_GBS}
     bound = max(roofs, key=lambda r: roofs[r]["frac"])
