@@ -97,6 +97,7 @@ SIGNATURES = {
     "ecc_pair_shards_balanced": (_i, [_vp, _i, _d, _i, _vp]),
     "ecc_metric_balanced_shards": (_i, [_vp, _i, _vp]),
     "ecc_group_metric_rebalance": (_i, [_vp]),
+    "ecc_group_metric_evaluate_poses": (_i, [_vp, _i, _vp, _i, _vp]),
     "ecc_group_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
     "ecc_group_metric_destroy": (_i, [_vp]),
     "ecc_group_metric_set_projections": (_i, [_vp, _vp, _i]),

@@ -660,6 +660,17 @@ class GroupMetricRadonIntermediate:
         check(_lib.lib().ecc_group_metric_set_sampling(self._h, mode))
         return self
 
+    def evaluate_poses(self, poses):
+        """Independent all-pairs evaluations of several poses (ecc_group_metric_evaluate_poses): poses is a sequence of
+        (n, 12) column-major arrays (pack_projection_matrices) or lists of 3x4 matrices; returns the means.  Pose p runs
+        entirely on rank p mod G."""
+        flat = np.ascontiguousarray(np.stack([p if (isinstance(p, np.ndarray) and p.ndim == 2 and p.shape[1] == 12)
+                                              else _Ps_colmajor(p) for p in poses]), np.float64)
+        means = np.zeros(len(flat), np.float64)
+        check(_lib.lib().ecc_group_metric_evaluate_poses(self._h, len(flat), C.c_void_p(flat.ctypes.data), flat.shape[1],
+                                                         C.c_void_p(means.ctypes.data)))
+        return means
+
     def rebalance(self):
         """Recompute the cost-balanced shard boundaries at the next evaluation (ecc_group_metric_rebalance)."""
         check(_lib.lib().ecc_group_metric_rebalance(self._h))

@@ -491,6 +491,31 @@ int group_evaluate(ecc_group_metric* gm, const double* Ps, int n_views, float* c
 
 }  // namespace
 
+// Independent evaluations (a sweep of poses as in Gui/Visualization.h:78-98 plotCostFunction, finite-difference
+// gradients): pose p goes to rank p mod G, every rank evaluates ALL pairs of its poses on its own device -- nothing is
+// exchanged at all, the throughput is G times one device's ("shard the sweep points").
+ECC_EXPORT int ecc_group_metric_evaluate_poses(ecc_group_metric* gm, int n_poses, const double* Ps_batch, int n_views,
+                                               double* means)
+{
+    if (!gm || !Ps_batch || !means) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_poses < 1 || n_views < 2) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "need one pose of two views at least");
+    ecc_group* g = gm->g;
+    const int G = g->size();
+    const size_t pose_doubles = 12 * (size_t)n_views;
+    const int rc = run_all(g, [=](int r) -> int {
+        for (int p = r; p < n_poses; p += G) {
+            int e = ecc_metric_set_projections(gm->metrics[r], Ps_batch + pose_doubles * (size_t)p, n_views);
+            if (e == ECC_OK) e = ecc_metric_evaluate_all(gm->metrics[r], nullptr, &means[p]);
+            if (e != ECC_OK) return e;
+        }
+        return ECC_OK;
+    });
+    // the ranks' metrics now hold different matrices: the next sharded evaluation must hand them over again
+    if (gm->n_views == n_views && !gm->pending_Ps.empty()) gm->pending = true;
+    else if (gm->n_views != n_views) gm->n_views = 0;
+    return rc;
+}
+
 ECC_EXPORT int ecc_group_metric_rebalance(ecc_group_metric* gm)
 {
     if (!gm) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "group metric is null");

@@ -364,6 +364,12 @@ int ecc_group_metric_get_object_radius(ecc_group_metric* gm, double* radius_mm);
  * cost_nxn (host, nullable): entry (i,j), i<j at index i + j*n is written, the rest preserved.  With one rank the
  * result is bit-identical to ecc_metric_evaluate_all; with G ranks it is the rank-ordered float64 sum of G shard sums. */
 int ecc_group_metric_evaluate_all(ecc_group_metric* gm, float* cost_nxn, double* mean);
+/* n_poses INDEPENDENT all-pairs evaluations (Ps_batch: n_poses x n_views x 12 float64; means: n_poses results): a sweep
+ * of poses (ref: Gui/Visualization.h:78-98 plotCostFunction; BASELINE config 5) or the probes of a finite-difference
+ * gradient.  Pose p is evaluated entirely on rank p mod G -- no exchange, G times one device's throughput; every value
+ * is bit-identical to ecc_metric_evaluate_all on one device.  The matrices of the last ecc_group_metric_set_projections
+ * stay the group's current ones. */
+int ecc_group_metric_evaluate_poses(ecc_group_metric* gm, int n_poses, const double* Ps_batch, int n_views, double* means);
 /* Recompute the cost-balanced shard boundaries from the current matrices (they are otherwise fixed at the first
  * evaluation so that repeated evaluations add the same partial sums in the same order). */
 int ecc_group_metric_rebalance(ecc_group_metric* gm);

@@ -49,4 +49,12 @@ for name, m in (("group", gm), ("single_context", single)):
         blocks.append((time.perf_counter() - t0) / steps)
     out[name + "_ms_per_step"] = 1e3 * sorted(blocks)[2]
     out[name + "_evaluations_per_s"] = 1.0 / sorted(blocks)[2]
+# BASELINE config 5 through the group: 600 independent sweep poses, pose p on rank p mod G (no exchange)
+sweep = [poses[k % 64] for k in range(600)]
+gm.evaluate_poses(sweep[:16])
+t0 = time.perf_counter()
+vals = gm.evaluate_poses(sweep)
+el = time.perf_counter() - t0
+out["config5_poses_per_s"] = 600 / el
+out["config5_check"] = bool(vals[5] == single.setProjectionMatrices(poses[5]).evaluate())
 print(json.dumps(out))

@@ -126,6 +126,17 @@ def test_multi_rank_group_on_one_device(gpu_ctx, oracle_mod, small_scan, ranks):
     gm.setObjectRadius(0.0, 0.0)
     assert gm.evaluate() == mean
     assert abs(gm.rebalance().evaluate() - mean) <= 1e-13 * mean  # same geometry: the same boundaries again
+    # independent evaluations of several poses, pose p on rank p mod G: each bit-identical to the single-device value,
+    # and the group's own matrices are still current afterwards
+    poses, want_p = [], []
+    for k in range(5):
+        Pk = list(s["Ps"])
+        Pk[k + 1] = Pk[k + 1] @ E.geometry.rigid_transform(tx=0.5 * k, rz=0.01 * k)
+        poses.append(Pk)
+        want_p.append(m.setSampling("polynomial").setProjectionMatrices(Pk).evaluate())
+    got_p = gm.evaluate_poses(poses)
+    assert list(got_p) == want_p and abs(got_p[0] - mean) <= 1e-13 * mean
+    assert gm.evaluate() == mean
     gm.close()
     m.close()
     del dtrs
