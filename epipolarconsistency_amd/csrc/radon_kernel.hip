@@ -395,6 +395,11 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
     // 97 / 95 rule (the bank advances along x+y or x-y, whichever the normal is closer to).
     // Measured per 1024^2 image: 97/95 rule everywhere 0.771 ms, stride 96 for x-normals only 0.740 ms, with the transposed
     // tile for y-normals as well 0.699 ms.
+    // (On top of this a texel-pair tile -- element = float2 {T(c), T(c+1)} along the fast axis, one aligned ds_read_b64 per
+    // footprint row at 256 B/clk instead of ds_read2_b32's 128 -- was measured at the same LDS budget, 72 slow x 64 fast
+    // elements = 36.9 KB, 4 workgroups per CU: bit-exact and 1.010 ms.  The chunks get 0.55-0.74x as long and the cost per
+    // chunk -- bounding box, staging, three barriers -- outweighs the halved read cycles; round 1 had found the same for
+    // the full-size pair tile at 2 workgroups per CU, 1.12 ms.)
     if (fabsf(nx) >= fabsf(ny))
         radon_body<DERIV, TILE_W>(p, sh);
     else if (p.imagesT)
