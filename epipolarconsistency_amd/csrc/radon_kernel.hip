@@ -399,7 +399,8 @@ __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
     // footprint row at 256 B/clk instead of ds_read2_b32's 128 -- was measured at the same LDS budget, 72 slow x 64 fast
     // elements = 36.9 KB, 4 workgroups per CU: bit-exact and 1.010 ms.  The chunks get 0.55-0.74x as long and the cost per
     // chunk -- bounding box, staging, three barriers -- outweighs the halved read cycles; round 1 had found the same for
-    // the full-size pair tile at 2 workgroups per CU, 1.12 ms.)
+    // the full-size pair tile at 2 workgroups per CU, 1.12 ms.  The chunk machinery alone -- the kernel with its sampling
+    // loop skipped -- takes 0.103 ms per image: 15 % of the kernel, and about what separates it from its LDS time.)
     if (fabsf(nx) >= fabsf(ny))
         radon_body<DERIV, TILE_W>(p, sh);
     else if (p.imagesT)
