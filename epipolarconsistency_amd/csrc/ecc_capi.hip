@@ -50,7 +50,8 @@ extern "C" hipError_t ecc_launch_direct_views(const double* Ps_d, int n, EccDire
 extern "C" hipError_t ecc_launch_direct_transpose(const float* src, float* dst, int n, int W, int H, hipStream_t stream);
 extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* total, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream);
-extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream);
+extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, void* scratch, hipStream_t stream);
+extern "C" size_t ecc_sum_scratch_bytes();
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
 
 #define ECC_EXPORT extern "C" __attribute__((visibility("default")))
@@ -160,6 +161,7 @@ struct ecc_metric {
     EccPairRecord* records_d = nullptr;  // per-pair geometry between k01_kernel and pairs_kernel
     int64_t records_capacity = 0;
     double* sum_d = nullptr;
+    void* sum_scratch_d = nullptr;  // partials + ticket of the multi-workgroup sum (zeroed; pairs_kernel.hip)
     double* Ps_d = nullptr;   // n x 12 float64 as handed over by the caller
     // pinned host staging, mapped into the device's address space (zero-copy: the 38 KB of matrices and the 8-byte
     // result cross PCIe inside the kernels, no copy commands).  Two matrix buffers, used alternately: an evaluate
@@ -819,6 +821,8 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
             e = hipMemcpyAsync(m->quads_table_d, qtable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&m->sum_scratch_d, ecc_sum_scratch_bytes());
+    if (e == hipSuccess) e = hipMemsetAsync(m->sum_scratch_d, 0, ecc_sum_scratch_bytes(), ctx->stream);
 
     if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, 64, hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&m->sum_h_dev, m->sum_h, 0);
@@ -875,6 +879,7 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->K01_d) (void)hipFree(m->K01_d);
     if (m->records_d) (void)hipFree(m->records_d);
     if (m->sum_d) (void)hipFree(m->sum_d);
+    if (m->sum_scratch_d) (void)hipFree(m->sum_scratch_d);
     if (m->Ps_d) (void)hipFree(m->Ps_d);
     for (double* b : m->Ps_h)
         if (b) (void)hipHostFree(b);
@@ -1055,7 +1060,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         ctx->ev_valid[0] = true;
     }
     if (sum_d) {
-        if (count > 0) HIP_TRY(ecc_launch_sum_pairs(pair_values_d, count, sum_d, ctx->stream));
+        if (count > 0) HIP_TRY(ecc_launch_sum_pairs(pair_values_d, count, sum_d, m->sum_scratch_d, ctx->stream));
         else if (sum_d == m->sum_h_dev) std::memset(m->sum_h, 0, sizeof(double));  // empty shard: nothing is launched
         else HIP_TRY(hipMemsetAsync(sum_d, 0, sizeof(double), ctx->stream));
     }
@@ -1177,7 +1182,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
         ctx->ev_valid[0] = true;
     }
     arm_result(m);
-    HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, ctx->stream));
+    HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, m->sum_scratch_d, ctx->stream));
     if (out) {
         HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(wait_stream_spin(ctx->stream));

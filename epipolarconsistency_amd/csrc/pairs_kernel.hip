@@ -1311,8 +1311,85 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
     return hipGetLastError();
 }
 
-extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, hipStream_t stream)
+namespace {
+// The same sum over SUM_BLOCKS workgroups inside ONE launch (large counts): every workgroup reduces a contiguous slice in a
+// fixed order -- one memory round trip instead of the single workgroup's two -- and publishes its float64 partial; the
+// workgroup that arrives last (a ticket counter) adds the partials in slice order and stores the result.  Deterministic:
+// the same slices, the same order within a slice, the same order of the partials, whichever workgroup happens to be last.
+// Hand-off between workgroups as the CDNA4 guide prescribes for it (MI355X_MICROARCH.md, "Valid forms"): the partial is an
+// agent-scope (sc1, write-through) store, the storing lane drains it (s_waitcnt vmcnt(0)) before its agent-scope ticket
+// add, the last arriver -- told by the value its add returned -- reads the partials with agent-scope (sc1) loads.
+constexpr int SUM_BLOCKS = 16;
+struct SumScratch {
+    double partial[SUM_BLOCKS];
+    unsigned ticket;  // zero between launches (reset by the last arriver)
+};
+
+__global__ __launch_bounds__(1024) void sum_pairs_split_kernel(const float* __restrict__ vals, long long count,
+                                                               double* __restrict__ out, SumScratch* __restrict__ scratch)
 {
-    hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, stream, vals, count, out);
+    __shared__ double s[1024 / 64];
+    __shared__ unsigned s_ticket;
+    const long long n4 = count >> 2;
+    const long long per = (n4 + SUM_BLOCKS - 1) / SUM_BLOCKS;  // float4 per slice
+    const long long lo = (long long)blockIdx.x * per, hi = min(n4, lo + per);
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(vals);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    long long k = lo + threadIdx.x;
+    for (; k + 3 * 1024 < hi; k += 4 * 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = v4[k + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0 += (double)v[u].x;
+            a1 += (double)v[u].y;
+            a2 += (double)v[u].z;
+            a3 += (double)v[u].w;
+        }
+    }
+    for (; k < hi; k += 1024) {
+        const float4 v = v4[k];
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+        a2 += (double)v.z;
+        a3 += (double)v.w;
+    }
+    double acc = (a0 + a1) + (a2 + a3);
+    if (blockIdx.x == SUM_BLOCKS - 1 && threadIdx.x == 0)
+        for (long long q = n4 << 2; q < count; ++q) acc += (double)vals[q];  // the up to three values past the last float4
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double part = 0.0;
+        for (int w = 0; w < 1024 / 64; w++) part += s[w];
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&scratch->partial[blockIdx.x]),
+                           (unsigned long long)__double_as_longlong(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ticket = __hip_atomic_fetch_add(&scratch->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_ticket == SUM_BLOCKS - 1) {  // every other workgroup's partial was drained before its add: all are visible
+            double tot = 0.0;
+            for (int b = 0; b < SUM_BLOCKS; ++b)
+                tot += __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<unsigned long long*>(&scratch->partial[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(&scratch->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(tot),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t ecc_sum_scratch_bytes() { return sizeof(SumScratch); }
+
+// scratch: ecc_sum_scratch_bytes() of zeroed device memory owned by the caller (one per stream of launches), or null.
+extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, void* scratch, hipStream_t stream)
+{
+    if (scratch && count >= 32768)
+        hipLaunchKernelGGL(sum_pairs_split_kernel, dim3(SUM_BLOCKS), dim3(1024), 0, stream, vals, count, out,
+                           static_cast<SumScratch*>(scratch));
+    else
+        hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, stream, vals, count, out);
     return hipGetLastError();
 }

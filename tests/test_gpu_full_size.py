@@ -88,3 +88,24 @@ def test_random_pairs_against_oracle(full_scan, oracle_mod):
     m.evaluate(cost)
     entries = [cost[b, a] for k, a in enumerate(views) for b in views[k + 1:]]
     assert abs(m.evaluate(set(views)) - float(np.mean(np.asarray(entries, np.float64)))) <= 2e-6 * np.mean(entries)
+
+
+def test_multi_workgroup_sum_is_stable_under_repetition(full_scan):
+    """The final float64 sum runs over 16 workgroups of one launch with a last-arriver combine (pairs_kernel.hip,
+    sum_pairs_split_kernel).  400 evaluations alternating between two poses: every result for a pose must carry the
+    same bits (a stale partial from the other pose or the previous launch would move the sum by percents), and agree
+    with the float64 sum of the pair values."""
+    from epipolarconsistency_amd import geometry
+    m, Ps = full_scan["metric"], full_scan["Ps"]
+    n_pairs = N * (N - 1) // 2
+    moved = list(Ps)
+    moved[123] = Ps[123] @ geometry.rigid_transform(ty=1.5, rx=0.005)
+    seen = {0: set(), 1: set()}
+    for k in range(400):
+        m.setProjectionMatrices(moved if k & 1 else Ps)
+        seen[k & 1].add(m.evaluate())
+    assert len(seen[0]) == 1 and len(seen[1]) == 1 and seen[0] != seen[1]
+    m.setProjectionMatrices(Ps)
+    total, vals = m.evaluate_range(0, n_pairs, want_pairs=True)
+    assert abs(total - float(np.sum(vals.astype(np.float64)))) <= 1e-13 * total
+    assert total / n_pairs == next(iter(seen[0]))
