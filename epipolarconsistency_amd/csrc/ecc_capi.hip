@@ -1371,12 +1371,36 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
             else ecc_host::intrinsics(P, &cosw[3 * v], &cosw[3 * v + 1], &cosw[3 * v + 2]);
         }
     }
+    // border factors as tables over the source column / row (the kernel multiplies instead of re-deriving them per
+    // pixel): ref Gui/PreProccess.cpp:86-113, same float / double expressions as the oracle's
+    std::vector<float> border_w(2 * (size_t)n_u + 2 * (size_t)n_v, 1.0f);
+    if (cfg->process) {
+        auto weighting = [](double x) {  // ref: Gui/PreProccess.cpp:8-13
+            if (x < -1.0 || x > 1.0) return 0.0;
+            const double xx = x * x;
+            return 1.0 - 2 * xx + xx * xx;
+        };
+        float *wl = border_w.data(), *wr = wl + n_u, *wb = wr + n_u, *wt = wb + n_v;
+        const int* z = cfg->zero;
+        const int* f = cfg->feather;
+        for (int sx = 0; sx < n_u; ++sx) {
+            if (sx < z[0] + f[0]) wl[sx] = sx <= z[0] ? 0.f : (float)weighting(1 - (float)(sx - z[0]) / f[0]);
+            const int b = n_u - sx;
+            if (b <= z[1] + f[1]) wr[sx] = b <= z[1] ? 0.f : (float)weighting(1 - (float)(b - z[1]) / f[1]);
+        }
+        for (int sy = 0; sy < n_v; ++sy) {
+            const int b = n_v - sy;
+            if (b <= z[2] + f[2]) wb[sy] = b <= z[2] ? 0.f : (float)weighting(1 - (float)(b - z[2]) / f[2]);
+            if (sy < z[3] + f[3]) wt[sy] = sy <= z[3] ? 0.f : (float)weighting(1 - (float)(sy - z[3]) / f[3]);
+        }
+    }
+    const size_t border_b = sizeof(float) * border_w.size();
     const size_t kernel_b = sizeof(double) * kernel.size();
     const size_t blanks_b = sizeof(int32_t) * 4 * (size_t)cfg->n_blanks;
     const size_t cosw_b = sizeof(float) * cosw.size(), valid_b = sizeof(int) * valid.size();
     const size_t max_b = sizeof(float) * (size_t)n;
     auto up8 = [](size_t b) { return (b + 7) / 8 * 8; };
-    const size_t upload_b = up8(kernel_b) + up8(blanks_b) + up8(cosw_b) + up8(valid_b);
+    const size_t upload_b = up8(kernel_b) + up8(blanks_b) + up8(cosw_b) + up8(valid_b) + up8(border_b);
     const size_t table_b = upload_b + up8(max_b);
     const size_t stack_b = sizeof(float) * img_floats * n;
     const bool in_place = on_device && images == out;
@@ -1432,11 +1456,14 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
     if (cosw_b) std::memcpy(th, cosw.data(), cosw_b);
     th += up8(cosw_b);
     if (valid_b) std::memcpy(th, valid.data(), valid_b);
+    th += up8(valid_b);
+    std::memcpy(th, border_w.data(), border_b);
     char* t = ctx->pre_tables_d;
     double* kernel_d = reinterpret_cast<double*>(t); t += up8(kernel_b);
     int* blanks_d = reinterpret_cast<int*>(t); t += up8(blanks_b);
     float* cosw_d = reinterpret_cast<float*>(t); t += up8(cosw_b);
     int* valid_d = reinterpret_cast<int*>(t); t += up8(valid_b);
+    float* border_d = reinterpret_cast<float*>(t); t += up8(border_b);
     float* max_d = reinterpret_cast<float*>(t);
     hipError_t e = hipSuccess;
     if (upload_b) e = hipMemcpyAsync(ctx->pre_tables_d, ctx->pre_tables_h, upload_b, hipMemcpyHostToDevice, ctx->stream);
@@ -1471,6 +1498,7 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
     p.kernel = kernel_d;
     p.cosw = Ps ? cosw_d : nullptr;
     p.cosw_valid = Ps ? valid_d : nullptr;
+    p.border_w = border_d;
     if (ctx->timing && e == hipSuccess) e = hipEventRecord(ctx->ev[4], ctx->stream);
     if (e == hipSuccess) e = ecc_launch_preprocess(&p, ctx->stream);
     if (ctx->timing && e == hipSuccess) {

@@ -143,6 +143,9 @@ struct EccPreprocessParams {
     const double* kernel;     // 2k+1 doubles on the device
     const float* cosw;        // n_img x 3 (sdd_px, ppu, ppv) or null
     const int* cosw_valid;    // n_img flags: 0 when the projection matrix is all zero (ref: PreProccess.cpp:149)
+    // border factors by SOURCE position, 1.0f where the reference does not multiply (x * 1.0f == x bit for bit):
+    // left[n_u], right[n_u], bottom[n_v], top[n_v], applied in this order (ref: Gui/PreProccess.cpp:86-113)
+    const float* border_w;
 };
 
 // ---- MetricDirect -----------------------------------------------------------

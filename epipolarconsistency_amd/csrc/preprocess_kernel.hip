@@ -15,11 +15,14 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <algorithm>
+
 #include "ecc_layout.h"
 
 namespace {
 
 constexpr int PP_TW = 64, PP_TH = 64, PP_THREADS = 256;  // PP_TW = one wave per tile row
+constexpr int PP_SEG = 16;  // outputs per thread along the direction of a convolution pass
 
 // ref: Gui/PreProccess.cpp:8-13 (weighting, double)
 __device__ __forceinline__ double weighting_d(double x)
@@ -29,13 +32,37 @@ __device__ __forceinline__ double weighting_d(double x)
     return 1.0 - 2 * xx + xx * xx;
 }
 
-// Pixel-wise part of PreProccess::process for the pixel at SOURCE position (sx, sy)
-// (ref: Gui/PreProccess.cpp:78-120, same order: intensity, left, right, bottom, top, blanks).
-__device__ __forceinline__ float pointwise(const EccPreprocessParams& p, float v, int sx, int sy, float scale, float bias)
+// ref: Gui/PreProccess.cpp:156-165
+__device__ __forceinline__ float cos_weight(int gx, int gy, float ppu, float ppv, float sdd)
+{
+    const float pou = (float)gx - ppu;
+    const float pov = (float)gy - ppv;
+    return sdd / sqrtf(pou * pou + pov * pov + sdd * sdd);
+}
+
+// ref: Gui/PreProccess.cpp:78-84 (intensity map, optional -log, negative / non-finite values to zero)
+__device__ __forceinline__ float intensity(const EccPreprocessParams& p, float v, float scale, float bias)
 {
     float pixel = v * scale + bias;
     if (p.apply_log) pixel = (float)-(float)log((double)pixel);
     if (pixel < 0 || isnan(pixel) || isinf(pixel)) pixel = 0;
+    return pixel;
+}
+
+// Pixel-wise part of PreProccess::process for the pixel at SOURCE position (sx, sy)
+// (ref: Gui/PreProccess.cpp:78-120, same order: intensity, left, right, bottom, top, blanks).
+__device__ __forceinline__ float blanked(const EccPreprocessParams& p, float pixel, int sx, int sy)
+{
+    for (int q = 0; q < p.n_blanks; ++q) {
+        const int* bl = p.blanks + 4 * q;
+        // ref: :116-119 (the y loop is bounded by img.size(0) there; clipped to the image as well)
+        if (sx >= bl[0] && sx < bl[2] && sy >= bl[1] && sy < bl[3] && sy < p.n_u) pixel = 0;
+    }
+    return pixel;
+}
+
+__device__ __forceinline__ float borders(const EccPreprocessParams& p, float pixel, int sx, int sy)
+{
     if (sx < p.zero[0] + p.feather[0])
         pixel *= sx <= p.zero[0] ? 0 : (float)weighting_d(1 - (float)(sx - p.zero[0]) / p.feather[0]);
     {
@@ -50,12 +77,12 @@ __device__ __forceinline__ float pointwise(const EccPreprocessParams& p, float v
     }
     if (sy < p.zero[3] + p.feather[3])
         pixel *= sy <= p.zero[3] ? 0 : (float)weighting_d(1 - (float)(sy - p.zero[3]) / p.feather[3]);
-    for (int q = 0; q < p.n_blanks; ++q) {
-        const int* bl = p.blanks + 4 * q;
-        // ref: :116-119 (the y loop is bounded by img.size(0) there; clipped to the image as well)
-        if (sx >= bl[0] && sx < bl[2] && sy >= bl[1] && sy < bl[3] && sy < p.n_u) pixel = 0;
-    }
-    return pixel;
+    return blanked(p, pixel, sx, sy);
+}
+
+__device__ __forceinline__ float pointwise(const EccPreprocessParams& p, float v, int sx, int sy, float scale, float bias)
+{
+    return borders(p, intensity(p, v, scale, bias), sx, sy);
 }
 
 // KT: half kernel width known at compile time (taps live in registers, loops unroll), or -1 = runtime k with
@@ -66,9 +93,12 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(EccPreprocessPar
     extern __shared__ float lds[];
     const int k = KT >= 0 ? KT : p.k;
     const int AW = PP_TW + 2 * k, AH = PP_TH + 2 * k;
+    // odd row strides: both passes are conflict-free whether the lanes of a wave are 64 columns or 64 rows
+    const int AS = AW | 1;
+    constexpr int BS = PP_TW + 1;
     float* A = lds;            // AH x AW : pixel-wise result incl. halo (clamped = the convolution's clamp addressing)
-    float* B = lds + AH * AW;  // AH x PP_TW : after the horizontal pass
-    double* taps_lds = reinterpret_cast<double*>(B + AH * PP_TW);  // runtime-k path only (8-byte aligned: even counts)
+    float* B = lds + AH * AS;  // AH x PP_TW : after the horizontal pass
+    double* taps_lds = reinterpret_cast<double*>(lds + ((AH * AS + AH * BS + 1) & ~1));  // runtime-k path only (8-byte aligned)
     double taps[KT > 0 ? 2 * KT : 1];
     if (KT > 0) {
 #pragma unroll
@@ -95,39 +125,88 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(EccPreprocessPar
         // compile-time footprint: ALL of a thread's loads are issued before the first is consumed (a load -> pointwise ->
         // store loop waits one memory round trip per element, ~20 per thread): 9.8 -> 7.9 us per 1024^2 image with the
         // default low-pass.  (Without a low-pass the plain loop below is faster, 3.2 against 6.1 us.)
-        constexpr int AHc = PP_TH + 2 * (KT > 0 ? KT : 0), AWc = PP_TW + 2 * (KT > 0 ? KT : 0);
-        constexpr int NR = (AHc + 3) / 4, NC = (AWc + 63) / 64;
-        float v[NR][NC];
-#pragma unroll
-        for (int q = 0; q < NR; ++q) {
-            const int ly = ty + 4 * q;
-            const int gy = min(max(y0 + ly - k, 0), H - 1);
-            const int sy = p.flip_v ? H - 1 - gy : gy;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int lx = tx + 64 * c;
-                const int gx = min(max(x0 + lx - k, 0), W - 1);
-                const int sx = p.flip_u ? W - 1 - gx : gx;
-                v[q][c] = (ly < AHc && lx < AWc) ? src[(size_t)sy * W + sx] : 0.f;
+        // The footprint is walked as ONE flat index range: with rows of 64 + 2k texels per wave the second trip of each
+        // row had 2k of 64 lanes active and the pixel-wise stage -- the most expensive part of this kernel, not the
+        // convolution -- ran at half efficiency.
+        constexpr int KK = KT > 0 ? KT : 1, AHc = PP_TH + 2 * KK, AWc = PP_TW + 2 * KK;
+        constexpr int NE = (AHc * AWc + PP_THREADS - 1) / PP_THREADS;
+        // pixel-wise stages other than the intensity map touch only pixels near the image border or inside a blank
+        // rectangle; a workgroup whose footprint lies clear of them skips their tests (they are conditional in the
+        // reference as well, so nothing changes for those pixels)
+        bool interior = p.n_blanks == 0;
+        {
+            const int gx_lo = min(max(x0 - k, 0), W - 1), gx_hi = min(max(x0 + AWc - 1 - k, 0), W - 1);
+            const int gy_lo = min(max(y0 - k, 0), H - 1), gy_hi = min(max(y0 + AHc - 1 - k, 0), H - 1);
+            const int sx_lo = p.flip_u ? W - 1 - gx_hi : gx_lo, sx_hi = p.flip_u ? W - 1 - gx_lo : gx_hi;
+            const int sy_lo = p.flip_v ? H - 1 - gy_hi : gy_lo, sy_hi = p.flip_v ? H - 1 - gy_lo : gy_hi;
+            interior = interior && sx_lo >= p.zero[0] + p.feather[0] && p.n_u - sx_hi > p.zero[1] + p.feather[1] &&
+                       p.n_v - sy_hi > p.zero[2] + p.feather[2] && sy_lo >= p.zero[3] + p.feather[3];
+        }
+        // border factors of this footprint's columns and rows (host-made tables, see EccPreprocessParams::border_w)
+        float* T = reinterpret_cast<float*>(taps_lds);  // the runtime-k taps are not used on this path
+        if (p.process && !interior) {
+            for (int i = threadIdx.x; i < 2 * AWc + 2 * AHc; i += PP_THREADS) {
+                const bool col = i < 2 * AWc;
+                const int l = col ? (i < AWc ? i : i - AWc) : (i - 2 * AWc < AHc ? i - 2 * AWc : i - 2 * AWc - AHc);
+                const int g = col ? min(max(x0 + l - k, 0), W - 1) : min(max(y0 + l - k, 0), H - 1);
+                const int sp = col ? (p.flip_u ? W - 1 - g : g) : (p.flip_v ? H - 1 - g : g);
+                const int table = col ? (i < AWc ? 0 : W) : (i - 2 * AWc < AHc ? 2 * W : 2 * W + H);
+                T[i] = p.border_w[table + sp];
             }
         }
+        float v[NE];
 #pragma unroll
-        for (int q = 0; q < NR; ++q) {
-            const int ly = ty + 4 * q;
-            const int gy = min(max(y0 + ly - k, 0), H - 1);
-            const int sy = p.flip_v ? H - 1 - gy : gy;
+        for (int q = 0; q < NE; ++q) {
+            const int e = threadIdx.x + PP_THREADS * q;
+            const int ly = e / AWc, lx = e - ly * AWc;
+            const int gy = min(max(y0 + ly - k, 0), H - 1), gx = min(max(x0 + lx - k, 0), W - 1);
+            const int sy = p.flip_v ? H - 1 - gy : gy, sx = p.flip_u ? W - 1 - gx : gx;
+            v[q] = e < AHc * AWc ? src[(size_t)sy * W + sx] : 0.f;
+        }
+        // The unrolled part (registers -> LDS) carries only the intensity map; -log and the border / blank stages are
+        // rolled loops over the thread's own LDS elements, entered only where they apply.  (With all of pointwise()
+        // inlined 22 times -- two float64 logarithms each -- the kernel was 13 000 instructions, larger than the
+        // instruction cache, and the pixel-wise stage cost 2 us per image on workgroups that skip almost all of it.)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int lx = tx + 64 * c;
-                if (ly < AHc && lx < AWc) {
-                    const int gx = min(max(x0 + lx - k, 0), W - 1);
-                    const int sx = p.flip_u ? W - 1 - gx : gx;
-                    float val = v[q][c];
-                    if (p.process) val = pointwise(p, val, sx, sy, scale, bias);
-                    A[ly * AW + lx] = val;
+        for (int q = 0; q < NE; ++q) {
+            const int e = threadIdx.x + PP_THREADS * q;
+            const int ly = e / AWc, lx = e - ly * AWc;
+            if (e < AHc * AWc) {
+                float val = v[q];
+#if !defined(PP_EXP_NO_POINTWISE)  // timing experiment
+                if (p.process) {
+                    val = val * scale + bias;  // ref: Gui/PreProccess.cpp:78-84, continued below when apply_log
+                    if (!p.apply_log && (val < 0 || isnan(val) || isinf(val))) val = 0;
                 }
+#endif
+                A[ly * AS + lx] = val;
             }
         }
+#if !defined(PP_EXP_NO_POINTWISE)
+        if (p.process && !interior) __syncthreads();  // T (uniform per workgroup)
+        if (p.process && (p.apply_log || !interior)) {
+#pragma unroll 1
+            for (int e = threadIdx.x; e < AHc * AWc; e += PP_THREADS) {
+                const int ly = e / AWc, lx = e - ly * AWc;
+                float val = A[ly * AS + lx];
+                if (p.apply_log) {
+                    val = (float)-(float)log((double)val);
+                    if (val < 0 || isnan(val) || isinf(val)) val = 0;
+                }
+                if (!interior) {
+                    val = val * T[lx];                   // left   (each product rounded to float, the reference's
+                    val = val * T[AWc + lx];             // right    sequence of `pixel *= w`)
+                    val = val * T[2 * AWc + ly];         // bottom
+                    val = val * T[2 * AWc + AHc + ly];   // top
+                    if (p.n_blanks) {
+                        const int gy = min(max(y0 + ly - k, 0), H - 1), gx = min(max(x0 + lx - k, 0), W - 1);
+                        val = blanked(p, val, p.flip_u ? W - 1 - gx : gx, p.flip_v ? H - 1 - gy : gy);
+                    }
+                }
+                A[ly * AS + lx] = val;
+            }
+        }
+#endif
     } else {
         for (int ly = ty; ly < AH; ly += PP_THREADS / 64) {
             const int gy = min(max(y0 + ly - k, 0), H - 1);
@@ -137,52 +216,95 @@ __global__ __launch_bounds__(PP_THREADS) void preprocess_kernel(EccPreprocessPar
                 const int sx = p.flip_u ? W - 1 - gx : gx;
                 float v = src[(size_t)sy * W + sx];
                 if (p.process) v = pointwise(p, v, sx, sy, scale, bias);
-                A[ly * AW + lx] = v;
+                A[ly * AS + lx] = v;
             }
         }
     }
     __syncthreads();
     if (k > 0) {
         // horizontal pass, ref: nrrd_lowpass.hxx:52-63 (o = -kx .. kx-1, double sum, result cast to T)
-        for (int ly = ty; ly < AH; ly += PP_THREADS / 64) {
-            double sum = 0;
-            if (KT > 0) {
+        if (KT > 0) {
+            // A thread owns PP_SEG consecutive outputs of one row and walks their PP_SEG + 2k - 1 inputs once: each
+            // input is read and widened to double ONCE and feeds up to 2k running sums (for a fixed output the taps
+            // still arrive in the order o = 0 .. 2k-1, so the sums are the oracle's bit for bit).  One output per
+            // thread widens every input 2k times, and v_cvt_f64_f32 is the slow instruction of this kernel.
+            constexpr int KK = KT > 0 ? KT : 1, AHc = PP_TH + 2 * KK, NSEG = PP_TW / PP_SEG, NIN = PP_SEG + 2 * KK - 1;
+            for (int i = threadIdx.x; i < AHc * NSEG; i += PP_THREADS) {
+                const int row = i % AHc, seg = i / AHc;  // lanes = consecutive rows
+                const float* a = A + row * AS + seg * PP_SEG;
+                double sum[PP_SEG];
 #pragma unroll
-                for (int o = 0; o < 2 * KT; ++o) sum += A[ly * AW + tx + o] * taps[o];
-            } else {
-                for (int o = 0; o < 2 * k; ++o) sum += A[ly * AW + tx + o] * taps_lds[o];
+                for (int s = 0; s < PP_SEG; ++s) sum[s] = 0;
+#pragma unroll
+                for (int j = 0; j < NIN; ++j) {
+                    const double d = a[j];
+#pragma unroll
+                    for (int s = 0; s < PP_SEG; ++s)
+#if defined(PP_EXP_NO_H)  // timing experiment: one tap (wrong results)
+                        if (j - s == 0) sum[s] += d * taps[j - s];
+#else
+                        if (j - s >= 0 && j - s < 2 * KK) sum[s] += d * taps[j - s];
+#endif
+                }
+#pragma unroll
+                for (int s = 0; s < PP_SEG; ++s) B[row * BS + seg * PP_SEG + s] = (float)sum[s];
             }
-            B[ly * PP_TW + tx] = (float)sum;
+        } else {
+            for (int ly = ty; ly < AH; ly += PP_THREADS / 64) {
+                double sum = 0;
+                for (int o = 0; o < 2 * k; ++o) sum += A[ly * AS + tx + o] * taps_lds[o];
+                B[ly * BS + tx] = (float)sum;
+            }
         }
         __syncthreads();
     }
     const float sdd = p.cosw ? p.cosw[3 * img_i] : 0.f;
     const float ppu = p.cosw ? p.cosw[3 * img_i + 1] : 0.f, ppv = p.cosw ? p.cosw[3 * img_i + 2] : 0.f;
     const bool weight = p.cosw && p.cosw_valid[img_i];
+    if (KT > 0) {
+        // vertical pass, ref: nrrd_lowpass.hxx:64-75 (uses kernelx again, o = -ky .. ky-1): thread = column tx, rows
+        // PP_SEG * ty .. + PP_SEG - 1, same single widening per input as above
+        constexpr int KK = KT > 0 ? KT : 1, NIN = PP_SEG + 2 * KK - 1;
+        static_assert(PP_SEG * (PP_THREADS / 64) == PP_TH, "one row segment per wave");
+        const int lx = tx, gx = x0 + lx;
+        const float* b = B + (PP_SEG * ty) * BS + lx;
+        double sum[PP_SEG];
+#pragma unroll
+        for (int s = 0; s < PP_SEG; ++s) sum[s] = 0;
+#pragma unroll
+        for (int j = 0; j < NIN; ++j) {
+            const double d = b[j * BS];
+#pragma unroll
+            for (int s = 0; s < PP_SEG; ++s)
+#if defined(PP_EXP_NO_V)  // timing experiment: one tap (wrong results)
+                if (j - s == 0) sum[s] += d * taps[j - s];
+#else
+                if (j - s >= 0 && j - s < 2 * KK) sum[s] += d * taps[j - s];
+#endif
+        }
+#pragma unroll
+        for (int s = 0; s < PP_SEG; ++s) {
+            const int gy = y0 + PP_SEG * ty + s;
+            if (gx >= W || gy >= H) continue;
+            float pixel = (float)sum[s];
+            if (weight) pixel *= cos_weight(gx, gy, ppu, ppv, sdd);
+            dst[(size_t)gy * W + gx] = pixel;
+        }
+        return;
+    }
     for (int ly = ty; ly < PP_TH; ly += PP_THREADS / 64) {
         const int lx = tx;
         const int gx = x0 + lx, gy = y0 + ly;
         if (gx >= W || gy >= H) continue;
         float pixel;
         if (k > 0) {
-            // vertical pass, ref: nrrd_lowpass.hxx:64-75 (uses kernelx again, o = -ky .. ky-1)
             double sum = 0;
-            if (KT > 0) {
-#pragma unroll
-                for (int o = 0; o < 2 * KT; ++o) sum += B[(ly + o) * PP_TW + lx] * taps[o];
-            } else {
-                for (int o = 0; o < 2 * k; ++o) sum += B[(ly + o) * PP_TW + lx] * taps_lds[o];
-            }
+            for (int o = 0; o < 2 * k; ++o) sum += B[(ly + o) * BS + lx] * taps_lds[o];
             pixel = (float)sum;
         } else {
-            pixel = A[ly * AW + lx];
+            pixel = A[ly * AS + lx];
         }
-        if (weight) {  // ref: Gui/PreProccess.cpp:156-165
-            const float pou = (float)gx - ppu;
-            const float pov = (float)gy - ppv;
-            const float cos_weight = sdd / sqrtf(pou * pou + pov * pov + sdd * sdd);
-            pixel *= cos_weight;
-        }
+        if (weight) pixel *= cos_weight(gx, gy, ppu, ppv, sdd);
         dst[(size_t)gy * W + gx] = pixel;
     }
 }
@@ -218,7 +340,9 @@ __global__ __launch_bounds__(1024) void image_max_kernel(const float* __restrict
 extern "C" size_t ecc_preprocess_lds_bytes(int k)
 {
     const int AW = PP_TW + 2 * k, AH = PP_TH + 2 * k;
-    return sizeof(float) * ((size_t)AH * AW + (k > 0 ? (size_t)AH * PP_TW : 0)) + sizeof(double) * 2 * (size_t)k;
+    const size_t floats = (size_t)AH * (AW | 1) + (k > 0 ? (size_t)AH * (PP_TW + 1) : 0);  // A and B with odd row strides
+    // tail: the runtime-k taps (2k doubles) or the footprint's border factors (2 AW + 2 AH floats), whichever is larger
+    return sizeof(float) * ((floats + 1) & ~(size_t)1) + std::max(sizeof(double) * 2 * (size_t)k, sizeof(float) * 2 * (size_t)(AW + AH));
 }
 
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream)
