@@ -58,6 +58,8 @@ SIGNATURES = {
     "ecc_metric_debug_geometry": (_i, [_vp, _vp, _vp]),
     "ecc_metric_set_params": (_i, [_vp, _d, _d, _i]),
     "ecc_metric_set_sampling": (_i, [_vp, _i]),
+    "ecc_metric_set_incremental": (_i, [_vp, _i]),
+    "ecc_metric_last_evaluated_pairs": (_i, [_vp, C.POINTER(_i64)]),
     "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
     "ecc_metric_evaluate_range": (_i, [_vp, _i64, _i64, _vp, _pd]),
@@ -103,6 +105,7 @@ SIGNATURES = {
     "ecc_group_metric_set_projections": (_i, [_vp, _vp, _i]),
     "ecc_group_metric_set_params": (_i, [_vp, _d, _d, _i]),
     "ecc_group_metric_set_sampling": (_i, [_vp, _i]),
+    "ecc_group_metric_set_incremental": (_i, [_vp, _i]),
     "ecc_group_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_group_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
     "ecc_group_metric_rank_metric": (_i, [_vp, _i, C.POINTER(_vp)]),

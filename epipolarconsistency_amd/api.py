@@ -338,6 +338,7 @@ class MetricRadonIntermediate:
         self._params = [0.0, 0.0, 0]
         d = type(self).default_sampling
         self._sampling = 0 if d is None else (self._SAMPLING[d] if isinstance(d, str) else int(d))
+        self._incremental = False
         if dtrs is not None:
             self.setRadonIntermediates(dtrs)
         if Ps is not None:
@@ -352,6 +353,7 @@ class MetricRadonIntermediate:
         check(_lib.lib().ecc_metric_create(self.ctx._h, len(self._dtrs), hs, C.byref(self._h)))
         check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
         check(_lib.lib().ecc_metric_set_sampling(self._h, self._sampling))
+        check(_lib.lib().ecc_metric_set_incremental(self._h, int(self._incremental)))
         if self._Ps is not None:
             self.setProjectionMatrices(self._Ps)
         return self
@@ -421,6 +423,21 @@ class MetricRadonIntermediate:
         if self._h:
             check(_lib.lib().ecc_metric_set_sampling(self._h, self._sampling))
         return self
+
+    def setIncremental(self, enable=True):
+        """Not in the reference (ecc_metric_set_incremental): keep the pair values of the last all-pairs / range
+        evaluation on the device and re-evaluate only the pairs of views whose matrix changed since -- the optimiser
+        pattern of Gui/SingleImageMotion.h (one view moves per call).  Results are bit-identical to full evaluations."""
+        self._incremental = bool(enable)
+        if self._h:
+            check(_lib.lib().ecc_metric_set_incremental(self._h, int(self._incremental)))
+        return self
+
+    def last_evaluated_pairs(self):
+        """Pairs the last evaluate() / evaluate_range() actually recomputed."""
+        v = C.c_int64()
+        check(_lib.lib().ecc_metric_last_evaluated_pairs(self._h, C.byref(v)))
+        return v.value
 
     # -- evaluation ----------------------------------------------------------------------------
     def evaluate(self, arg=None, out=None):
@@ -659,6 +676,22 @@ class GroupMetricRadonIntermediate:
         mode = MetricRadonIntermediate._SAMPLING[mode] if isinstance(mode, str) else int(mode)
         check(_lib.lib().ecc_group_metric_set_sampling(self._h, mode))
         return self
+
+    def setIncremental(self, enable=True):
+        """ecc_group_metric_set_incremental: every rank keeps the pair values of its shard (see
+        MetricRadonIntermediate.setIncremental)."""
+        check(_lib.lib().ecc_group_metric_set_incremental(self._h, int(bool(enable))))
+        return self
+
+    def last_evaluated_pairs(self):
+        """Pairs the ranks recomputed in the last evaluation, summed over the ranks."""
+        total = 0
+        for r in range(len(self.group)):
+            m, v = C.c_void_p(), C.c_int64()
+            check(_lib.lib().ecc_group_metric_rank_metric(self._h, r, C.byref(m)))
+            check(_lib.lib().ecc_metric_last_evaluated_pairs(m, C.byref(v)))
+            total += v.value
+        return total
 
     def evaluate_poses(self, poses):
         """Independent all-pairs evaluations of several poses (ecc_group_metric_evaluate_poses): poses is a sequence of

@@ -362,6 +362,7 @@ class MetricRadonIntermediate : public Metric {
     std::vector<RadonIntermediate*> dtrs;
     bool use_corr;
     int sampling;
+    bool incremental;
     ecc_metric* m_h;          // single-device metric, or the group's rank-0 metric (borrowed) when m_gh is set
     ecc_group_metric* m_gh;   // sharded over a group of devices (ecc_group_*), else null
     ecc_ctx* m_ctx;
@@ -372,9 +373,11 @@ class MetricRadonIntermediate : public Metric {
         if (m_gh) {
             detail::check(ecc_group_metric_set_params(m_gh, object_radius_mm, dkappa, use_corr ? 1 : 0));
             detail::check(ecc_group_metric_set_sampling(m_gh, sampling));
+            detail::check(ecc_group_metric_set_incremental(m_gh, incremental ? 1 : 0));
         } else if (m_h) {
             detail::check(ecc_metric_set_params(m_h, object_radius_mm, dkappa, use_corr ? 1 : 0));
             detail::check(ecc_metric_set_sampling(m_h, sampling));
+            detail::check(ecc_metric_set_incremental(m_h, incremental ? 1 : 0));
         }
     }
     void push_projections()
@@ -402,13 +405,13 @@ class MetricRadonIntermediate : public Metric {
 
 public:
     explicit MetricRadonIntermediate(ecc_ctx* ctx = nullptr)
-        : use_corr(false), sampling(ECC_SAMPLING_AUTO), m_h(nullptr), m_gh(nullptr), m_ctx(ctx), m_group(nullptr)
+        : use_corr(false), sampling(ECC_SAMPLING_AUTO), incremental(false), m_h(nullptr), m_gh(nullptr), m_ctx(ctx), m_group(nullptr)
     {
     }
     /// ref: MetricRadonIntermediate(Ps, dtrs) (.h:31).  ctx: a context other than the process-wide default one.
     MetricRadonIntermediate(const std::vector<ProjectionMatrix>& _Ps, const std::vector<RadonIntermediate*>& _dtrs,
                             ecc_ctx* ctx = nullptr)
-        : use_corr(false), sampling(ECC_SAMPLING_AUTO), m_h(nullptr), m_gh(nullptr), m_ctx(ctx), m_group(nullptr)
+        : use_corr(false), sampling(ECC_SAMPLING_AUTO), incremental(false), m_h(nullptr), m_gh(nullptr), m_ctx(ctx), m_group(nullptr)
     {
         setProjectionMatrices(_Ps);
         setRadonIntermediates(_dtrs);
@@ -416,7 +419,7 @@ public:
     /// Same over an explicit group of devices (not in the reference): evaluate() is sharded over the group.
     MetricRadonIntermediate(const std::vector<ProjectionMatrix>& _Ps, const std::vector<RadonIntermediate*>& _dtrs,
                             ecc_group* group)
-        : use_corr(false), sampling(ECC_SAMPLING_AUTO), m_h(nullptr), m_gh(nullptr), m_ctx(nullptr), m_group(group)
+        : use_corr(false), sampling(ECC_SAMPLING_AUTO), incremental(false), m_h(nullptr), m_gh(nullptr), m_ctx(nullptr), m_group(group)
     {
         setProjectionMatrices(_Ps);
         setRadonIntermediates(_dtrs);
@@ -427,6 +430,9 @@ public:
     MetricRadonIntermediate& useCorrelation(bool corr = true) { use_corr = corr; push_params(); return *this; }
     /// Not in the reference: ECC_SAMPLING_* of the C ABI (default ECC_SAMPLING_AUTO).
     MetricRadonIntermediate& setSampling(int mode) { sampling = mode; push_params(); return *this; }
+    /// Not in the reference: ecc_metric_set_incremental -- evaluate() re-evaluates only the pairs of views whose matrix
+    /// changed since the last call (Gui/SingleImageMotion.h moves one view per call); bit-identical results.
+    MetricRadonIntermediate& setIncremental(bool on = true) { incremental = on; push_params(); return *this; }
 
     /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
     MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)

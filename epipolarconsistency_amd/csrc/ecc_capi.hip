@@ -173,6 +173,20 @@ struct ecc_metric {
     uint64_t done_generation = 0;  // every e1 launch up to this one is known to have completed
     double* sum_h = nullptr;       // 64-byte slot; [0] = the result, written by sum_pairs_kernel with a system-scope store
     double* sum_h_dev = nullptr;
+    // ecc_metric_set_incremental: the pair values of the last evaluation of one pair range, the matrices and parameters
+    // they belong to, and a pinned, device-mapped list buffer (4 indices + 1 slot per re-evaluated pair)
+    int incremental = 0;
+    bool cache_valid = false;
+    int64_t cache_first = 0, cache_count = 0;
+    int cache_n_views = 0, cache_use_corr = 0, cache_sampling = 0;
+    double cache_radius = 0, cache_dkappa = 0;
+    std::vector<double> cache_Ps;
+    float* cache_values_d = nullptr;
+    int64_t cache_capacity = 0;
+    int32_t* list_h = nullptr;
+    int32_t* list_h_dev = nullptr;
+    int64_t list_capacity = 0;  // pairs
+    int64_t last_evaluated_pairs = 0;
 };
 
 namespace {
@@ -849,6 +863,7 @@ ECC_EXPORT int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count)
     const int n = (int)m->dtrs.size();
     if (first < 0 || count < 0 || first > n || count > n - first) return fail(ECC_ERR_INVALID_ARGUMENT, "dtr range outside the metric's list");
     if (count == 0) return ECC_OK;
+    m->cache_valid = false;
     int rc = set_device(m->ctx);
     if (rc) return rc;
     const int64_t paired_floats = (int64_t)(m->n_alpha + 1) * m->pitch * 2;
@@ -884,6 +899,8 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     for (double* b : m->Ps_h)
         if (b) (void)hipHostFree(b);
     if (m->sum_h) (void)hipHostFree(m->sum_h);
+    if (m->cache_values_d) (void)hipFree(m->cache_values_d);
+    if (m->list_h) (void)hipHostFree(m->list_h);
     delete m;
     return ECC_OK;
 }
@@ -955,6 +972,7 @@ ECC_EXPORT int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, dou
     m->object_radius_mm = object_radius_mm;
     m->dkappa = dkappa;
     m->use_corr = use_corr;
+    m->cache_valid = false;
     return ECC_OK;
 }
 
@@ -963,6 +981,22 @@ ECC_EXPORT int ecc_metric_set_sampling(ecc_metric* m, int mode)
     if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
     if (mode < ECC_SAMPLING_AUTO || mode > ECC_SAMPLING_REFERENCE) return fail(ECC_ERR_INVALID_ARGUMENT, "unknown sampling mode");
     m->sampling = mode;
+    m->cache_valid = false;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_set_incremental(ecc_metric* m, int enable)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    m->incremental = enable ? 1 : 0;
+    m->cache_valid = false;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs)
+{
+    if (!m || !pairs) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    *pairs = m->last_evaluated_pairs;
     return ECC_OK;
 }
 
@@ -1067,6 +1101,101 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     return ECC_OK;
 }
 
+// Pair values of [first, first + count) into a device array the metric keeps, their float64 sum to sum_d.
+// With ecc_metric_set_incremental: when this range was evaluated before with the same parameters and few matrices have
+// changed since, only the pairs that contain a changed view are re-evaluated (index-list launch that writes each value
+// into its slot) and the sum kernel runs over the kept array -- every value, and therefore the sum, is bit-identical to
+// a full evaluation: a pair's value depends only on its two matrices, its two dtrs and the parameters, the sampling mode
+// is the one the full range resolves to, and the sum's order is fixed.
+int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, float** vals_out)
+{
+    ecc_ctx* ctx = m->ctx;
+    const int64_t n = m->n_views;
+    if (n < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
+    if ((int64_t)m->dtrs.size() < n) return fail(ECC_ERR_INVALID_ARGUMENT, "fewer Radon intermediates than projection matrices");
+    if (first < 0 || count < 0 || first + count > n * (n - 1) / 2)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "pair range outside [0, n(n-1)/2)");
+    int rc = ensure_capacity(&m->cache_values_d, &m->cache_capacity, count > 0 ? count : 1, ctx->stream);
+    if (rc) return rc;
+    *vals_out = m->cache_values_d;
+    const double* Pcur = m->Ps_h[m->set_generation & 1];
+    double radius = 0;
+    ecc_metric_get_object_radius(m, &radius);  // the automatic radius follows the first matrix
+    const bool same = m->cache_valid && m->cache_first == first && m->cache_count == count && m->cache_n_views == (int)n &&
+                      m->cache_use_corr == m->use_corr && m->cache_sampling == m->sampling && m->cache_radius == radius &&
+                      m->cache_dkappa == m->dkappa && (int64_t)m->cache_Ps.size() == 12 * n;
+    m->cache_valid = false;  // until everything below is enqueued
+    if (same && count > 0) {
+        std::vector<int> changed;
+        for (int64_t v = 0; v < n; ++v)
+            if (std::memcmp(Pcur + 12 * v, m->cache_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
+        if ((int64_t)changed.size() * 4 <= n) {  // c of n views changed: 1 - (1 - c/n)^2 of the pairs, at most 44 %
+            std::vector<char> is_changed((size_t)n, 0);
+            for (int v : changed) is_changed[v] = 1;
+            std::vector<int32_t> idx, slots;
+            for (int v : changed)
+                for (int64_t u = 0; u < n; ++u) {
+                    if (u == v || (is_changed[u] && u < v)) continue;  // a pair of two changed views once
+                    const int64_t i = u < v ? u : v, j = u < v ? v : u;
+                    const int64_t ij = i * n - i * (i + 1) / 2 + (j - i - 1);  // get_ij order
+                    if (ij < first || ij >= first + count) continue;
+                    idx.insert(idx.end(), {(int32_t)i, (int32_t)j, (int32_t)i, (int32_t)j});
+                    slots.push_back((int32_t)(ij - first));
+                }
+            const int64_t L = (int64_t)slots.size();
+            if (L > 0) {
+                if (m->list_capacity < L) {
+                    if (m->list_h) HIP_TRY(hipHostFree(m->list_h));  // the stream is idle: evaluations are synchronous
+                    m->list_h = nullptr;
+                    m->list_capacity = 0;
+                    const int64_t cap = std::max<int64_t>(2 * L, 1024);
+                    HIP_TRY(hipHostMalloc((void**)&m->list_h, sizeof(int32_t) * 5 * cap, hipHostMallocMapped));
+                    HIP_TRY(hipHostGetDevicePointer((void**)&m->list_h_dev, m->list_h, 0));
+                    m->list_capacity = cap;
+                }
+                std::memcpy(m->list_h, idx.data(), sizeof(int32_t) * 4 * L);
+                std::memcpy(m->list_h + 4 * L, slots.data(), sizeof(int32_t) * L);
+                EccPairParams p;
+                rc = fill_pair_params(m, &p, count);  // the sampling mode of the full range
+                if (rc) return rc;
+                rc = ensure_capacity(&m->records_d, &m->records_capacity, L, ctx->stream);
+                if (rc) return rc;
+                p.indices = m->list_h_dev;  // read over PCIe inside k01_kernel: 20 bytes per pair, no copy command
+                p.value_slots = m->list_h_dev + 4 * L;
+                p.first = 0;
+                p.count = L;
+                p.pair_values = m->cache_values_d;
+                p.records = m->records_d;
+                HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+                if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+                HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+                if (ctx->timing) {
+                    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+                    ctx->ev_valid[0] = true;
+                }
+            }
+            HIP_TRY(ecc_launch_sum_pairs(m->cache_values_d, count, sum_d, m->sum_scratch_d, ctx->stream));
+            for (int v : changed) std::memcpy(m->cache_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
+            m->last_evaluated_pairs = L;
+            m->cache_valid = true;
+            return ECC_OK;
+        }
+    }
+    rc = launch_range(m, first, count, m->cache_values_d, nullptr, nullptr, sum_d);
+    if (rc) return rc;
+    m->cache_Ps.assign(Pcur, Pcur + 12 * n);
+    m->cache_first = first;
+    m->cache_count = count;
+    m->cache_n_views = (int)n;
+    m->cache_use_corr = m->use_corr;
+    m->cache_sampling = m->sampling;
+    m->cache_radius = radius;
+    m->cache_dkappa = m->dkappa;
+    m->last_evaluated_pairs = count;
+    m->cache_valid = true;
+    return ECC_OK;
+}
+
 }  // namespace
 
 ECC_EXPORT int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d,
@@ -1094,10 +1223,15 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
     rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count > 0 ? count : 1, ctx->stream);
     if (rc) return rc;
     arm_result(m);
-    rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_h_dev);
+    float* vals_d = m->pair_values_d;
+    if (m->incremental) rc = evaluate_cached(m, first, count, m->sum_h_dev, &vals_d);
+    else {
+        rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_h_dev);
+        m->last_evaluated_pairs = count;
+    }
     if (rc) return rc;
     if (pair_values && count > 0) {
-        HIP_TRY(hipMemcpyAsync(pair_values, m->pair_values_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(pair_values, vals_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(wait_stream_spin(ctx->stream));  // the copy has to land too
     }
     HIP_TRY(wait_result(m, ctx->stream, partial_sum));
@@ -1132,7 +1266,13 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
         HIP_TRY(hipMemcpyAsync(cost_d, cost_nxn, sizeof(float) * n * n, hipMemcpyHostToDevice, ctx->stream));
     }
     arm_result(m);
-    rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_h_dev);  // the sum lands in pinned host memory
+    if (m->incremental && !cost_nxn) {  // with a cost image every pair is written anyway
+        float* vals_d = nullptr;
+        rc = evaluate_cached(m, 0, n_pairs, m->sum_h_dev, &vals_d);
+    } else {
+        rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_h_dev);  // the sum lands in pinned host memory
+        m->last_evaluated_pairs = n_pairs;
+    }
     if (rc) return rc;
     if (cost_nxn) {
         HIP_TRY(hipMemcpyAsync(cost_nxn, cost_d, sizeof(float) * n * n, hipMemcpyDeviceToHost, ctx->stream));

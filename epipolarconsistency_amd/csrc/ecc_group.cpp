@@ -406,6 +406,16 @@ ECC_EXPORT int ecc_group_metric_set_sampling(ecc_group_metric* gm, int mode)
     return ECC_OK;
 }
 
+ECC_EXPORT int ecc_group_metric_set_incremental(ecc_group_metric* gm, int enable)
+{
+    if (!gm) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "group metric is null");
+    for (ecc_metric* m : gm->metrics) {
+        const int rc = ecc_metric_set_incremental(m, enable);
+        if (rc != ECC_OK) return rc;
+    }
+    return ECC_OK;
+}
+
 namespace {
 int flush_projections(ecc_group_metric* gm)
 {

@@ -958,7 +958,7 @@ __global__ __launch_bounds__(PK_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairP
         val = (1.0f - corr) * 1.0f;
     }
     if (lane == 0) {
-        if (p.pair_values) p.pair_values[local] = val;
+        if (p.pair_values) p.pair_values[p.value_slots ? (long long)p.value_slots[local] : local] = val;
         if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
 #if defined(PK_EXP_STAMPS)
         if (p.K01_out) {
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairPara
         val = (1.0f - corr) * 1.0f;
     }
     if (lane == 0) {
-        if (p.pair_values) p.pair_values[local] = val;
+        if (p.pair_values) p.pair_values[p.value_slots ? (long long)p.value_slots[local] : local] = val;
         if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
     }
 }

@@ -196,6 +196,19 @@ int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa,
 enum { ECC_SAMPLING_AUTO = 0, ECC_SAMPLING_POLYNOMIAL = 1, ECC_SAMPLING_PER_SAMPLE = 2, ECC_SAMPLING_REFERENCE = 3 };
 #define ECC_SAMPLING_AUTO_REFERENCE_PAIRS 512
 int ecc_metric_set_sampling(ecc_metric* m, int mode);
+/* Opt-in pose-delta evaluation (default off; not in the reference).  The reference's optimisation problems change ONE
+ * view's matrix per cost-function call and call setProjectionMatrices + evaluate() over all pairs
+ * (ref: Gui/SingleImageMotion.h:84-90, Gui/Visualization.h:78-98).  When enabled, ecc_metric_evaluate_all (without a cost
+ * image) and ecc_metric_evaluate_range keep the pair values of their last evaluation on the device; the next call with
+ * the same range and parameters compares the new matrices with the ones those values belong to and re-evaluates only
+ * the pairs that contain a changed view (when at most a quarter of the views changed, otherwise everything), then sums
+ * the whole array again.  The result is BIT-IDENTICAL to a full evaluation: a pair's value is a function of its two
+ * matrices, its two Radon intermediates and the parameters only, the sampling mode is the one the full range resolves
+ * to, and the float64 sum has a fixed order.  Changing parameters, sampling mode, the range, the number of views or
+ * calling ecc_metric_refresh_dtrs drops the kept values.  ecc_metric_last_evaluated_pairs reports how many pairs the
+ * last evaluate_all / evaluate_range recomputed. */
+int ecc_metric_set_incremental(ecc_metric* m, int enable);
+int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
 int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);
@@ -358,6 +371,7 @@ int ecc_group_metric_destroy(ecc_group_metric* gm);
  * evaluation (one hand-off to the rank threads per optimiser step). */
 int ecc_group_metric_set_projections(ecc_group_metric* gm, const double* Ps, int n_views);
 int ecc_group_metric_set_params(ecc_group_metric* gm, double object_radius_mm, double dkappa, int use_corr);
+int ecc_group_metric_set_incremental(ecc_group_metric* gm, int enable);  /* every rank keeps its own shard's values */
 int ecc_group_metric_set_sampling(ecc_group_metric* gm, int mode);
 int ecc_group_metric_get_object_radius(ecc_group_metric* gm, double* radius_mm);
 /* ref: double MetricRadonIntermediate::evaluate(float* out): all pairs, sharded over the group; *mean = sum/n_pairs.

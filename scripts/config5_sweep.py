@@ -8,7 +8,9 @@ One GPU:   python scripts/config5_sweep.py [n size bins]
 N GPUs:    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 scripts/config5_sweep.py
            -- the 600 sweep points are independent evaluations: rank r takes every N-th point, every rank holds the
            whole dtr stack, nothing is exchanged inside the timed loop ("shard the sweep points"); the
-           values are gathered afterwards (gloo).  ECC_SWEEP_SINGLE_DEVICE=1 puts all ranks on cuda:0 (rehearsal)."""
+           values are gathered afterwards (gloo).  ECC_SWEEP_SINGLE_DEVICE=1 puts all ranks on cuda:0 (rehearsal).
+ECC_SWEEP_INCREMENTAL=1 (one GPU): the sweep is run a second time with ecc_metric_set_incremental -- only the 399 pairs of
+the moving view are re-evaluated per point -- and the 600 values are compared bit for bit with the full evaluations'."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -64,6 +66,25 @@ out = {"config": "config 5: %d views %dx%d, view %d swept over 6 rigid parameter
        "evaluations": 600, "seconds": elapsed, "evaluations_per_s": 600 / elapsed, "n_gpus": world,
        "decomposition": "sweep points round-robin over ranks, no exchange in the timed loop" if world > 1 else "one GPU",
        "min_at_step": [int(np.argmin(values[p])) for p in range(6)]}
+if world == 1 and os.environ.get("ECC_SWEEP_INCREMENTAL"):
+    m.setIncremental(True)
+    packed[moving] = P0.T.reshape(12)
+    m.setProjectionMatrices(packed).evaluate()  # the kept values: one full evaluation, outside the timed loop like the warm-up
+    inc_values = np.zeros(600)
+    recomputed = set()
+    t0 = time.perf_counter()
+    for q in range(600):
+        p, k = divmod(q, 100)
+        x = -ranges[p] + 2 * ranges[p] * k / 99.0
+        packed[moving] = (P0 @ geometry.rigid_transform(**{names[p]: x})).T.reshape(12)
+        m.setProjectionMatrices(packed)
+        inc_values[q] = m.evaluate()
+        recomputed.add(m.last_evaluated_pairs())
+    inc_elapsed = time.perf_counter() - t0
+    m.setIncremental(False)
+    out["incremental"] = {"seconds": inc_elapsed, "evaluations_per_s": 600 / inc_elapsed,
+                          "pairs_recomputed_per_evaluation": sorted(recomputed),
+                          "values_bit_identical_to_full_evaluations": bool(np.array_equal(inc_values.reshape(6, 100), values))}
 if rank == 0:
     # oracle spot checks (6 of the 600 points)
     import oracle

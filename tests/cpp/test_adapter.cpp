@@ -56,6 +56,27 @@ int main(int argc, char** argv)
         printf("pair02 %.17g %zu %zu %zu %.9g %.9g\n", pair_ecc, rs0.size(), kappas.size(), loc1.size(), kappas[0], loc0[0].first);
         ecc.setObjectRadius(50.0);
         printf("mean_r50 %.17g\n", ecc.evaluate());
+        {   // the optimiser pattern (Gui/SingleImageMotion.h:84-90): one matrix overwritten per call, with and without the
+            // pose-delta mode -- the same bits
+            ecc.setObjectRadius(0.0);
+            std::vector<ProjectionMatrix> moved = Ps;
+            double full_values[3], inc_values[3];
+            for (int pass = 0; pass < 2; ++pass) {
+                ecc.setIncremental(pass == 1);
+                ecc.setProjectionMatrices(Ps);
+                ecc.evaluate();
+                for (int step = 0; step < 3; ++step) {
+                    moved = Ps;
+                    moved[2].data()[9] += 0.25 * (step + 1);  // the translation column of view 2
+                    ecc.setProjectionMatrices(moved);
+                    (pass ? inc_values : full_values)[step] = ecc.evaluate();
+                }
+            }
+            ecc.setIncremental(false);
+            ecc.setProjectionMatrices(Ps);
+            printf("incremental %d %.17g %.17g\n", (full_values[0] == inc_values[0] && full_values[1] == inc_values[1] &&
+                   full_values[2] == inc_values[2] && full_values[0] != full_values[1]) ? 1 : 0, full_values[2], inc_values[2]);
+        }
         {
             MetricDirect direct(Ps, imgs.data(), n, n_u, n_v);
             std::vector<float> d0, d1, dk;

@@ -141,6 +141,8 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     assert int(f[2]) == len(dpair["kappas"])
     r50 = oracle_mod.evaluate_all(Ps, dtrs, s["n_u"], s["n_v"], object_radius_mm=50.0)
     assert abs(float(val["mean_r50"]) - r50["mean"]) < 1e-5 * r50["mean"]
+    # setIncremental (pose-delta evaluation): the optimiser pattern gives the same bits with and without it
+    assert val["incremental"].split()[0] == "1", val["incremental"]
     # the same program, unchanged, over a default group of two ranks (ECC_HIP_DEVICES; both on device 0 here): evaluate()
     # is sharded inside the library, everything else is served by rank 0
     out2 = subprocess.run([exe, ipath, str(n), str(s["n_u"]), str(s["n_v"]), str(s["n_alpha"]), str(s["n_t"]), ppath],
@@ -148,5 +150,6 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     val2 = {k: v for k, v in re.findall(r"^(\w+) (.*)$", out2, flags=re.M)}
     assert abs(float(val2["mean"]) - float(val["mean"])) <= 1e-13 * float(val["mean"])
     assert abs(float(val2["mean_r50"]) - float(val["mean_r50"])) <= 1e-13 * float(val["mean_r50"])
+    assert val2["incremental"].split()[0] == "1", val2["incremental"]
     for key in ("radius", "cost10", "subset", "dtr1", "hostsample", "pair02"):
         assert val2[key] == val[key], key
