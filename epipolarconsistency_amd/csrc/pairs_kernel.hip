@@ -278,8 +278,8 @@ __device__ __forceinline__ LineTap sample_line_prep(float l0, float l1, float l2
 template <bool DERIV>
 __device__ __forceinline__ float line_tap_finish(const F4 q, const LineTap t)
 {
-    const float r0 = fmaf(t.fx, q.y - q.x, q.x);
-    const float r1 = fmaf(t.fx, q.w - q.z, q.z);
+    const float r0 = fmaf(t.fx, q.y, q.x);  // q.y, q.w: the row differences, formed when the copy is built
+    const float r1 = fmaf(t.fx, q.w, q.z);
     const float v = fmaf(t.fy, r1 - r0, r0);
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ t.m) : v;
 }
@@ -376,8 +376,8 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
 #else
     const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
 #endif
-    const float r0 = fmaf(fx, q.y - q.x, q.x);
-    const float r1 = fmaf(fx, q.w - q.z, q.z);
+    const float r0 = fmaf(fx, q.y, q.x);  // q.y, q.w: the row differences, formed when the copy is built
+    const float r1 = fmaf(fx, q.w, q.z);
     const float v = fmaf(fy, r1 - r0, r0);
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ fold) : v;
 }
@@ -1227,7 +1227,12 @@ __global__ __launch_bounds__(256) void build_paired_kernel(const float* const* _
     float* __restrict__ d = paired + (int64_t)blockIdx.z * paired_stride;
     const int r = blockIdx.y;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < pitch; j += gridDim.x * blockDim.x) {
-        F2 v = {s[(size_t)r * pitch + j], s[(size_t)(r + 1) * pitch + j]};
+        // (value of row r, row r+1 minus row r): the fp32 difference the bilinear rule needs is formed here once instead
+        // of in every sample -- the same rounded number, so results do not change (scripts/pair_values_digest.py: the
+        // SHA-256 of all 79 800 pair values is the same in both modes); two vector instructions less per sample,
+        // 0.339 -> 0.333 ms A/B on one box
+        const float a = s[(size_t)r * pitch + j];
+        F2 v = {a, s[(size_t)(r + 1) * pitch + j] - a};
         *reinterpret_cast<F2*>(d + ((size_t)r * pitch + j) * 2) = v;
     }
 }
@@ -1249,8 +1254,8 @@ __global__ __launch_bounds__(256) void build_quad_kernel(const float* const* __r
         const int j = e >> 2, q = e & 3;
         const int r = min(4 * g + q, rows - 1);
         const int j1 = min(j + 1, pitch - 1);
-        const F4 v = {s[(size_t)r * pitch + j], s[(size_t)(r + 1) * pitch + j], s[(size_t)r * pitch + j1],
-                      s[(size_t)(r + 1) * pitch + j1]};
+        const float a = s[(size_t)r * pitch + j], b = s[(size_t)r * pitch + j1];
+        const F4 v = {a, s[(size_t)(r + 1) * pitch + j] - a, b, s[(size_t)(r + 1) * pitch + j1] - b};  // value, row difference
         d[(size_t)g * pitch * 4 + e] = v;
     }
 }
