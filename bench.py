@@ -422,7 +422,10 @@ def main():
         "config": {"workload": "%d-projection %dx%d circular short scan, %dx%d Radon bins, all %d pairs"
                                % (n, S, S, B, B, n_pairs),
                    "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d (contiguous, cost-balanced)" % world,
-                   "sum_exchange": exch_name[best]},
+                   "sum_exchange": exch_name[best],
+                   # the step moves one view like the reference's optimiser loop does; the library's opt-in pose-delta mode
+                   # (ecc_metric_set_incremental) would re-evaluate 399 pairs instead of all -- it is NOT used here
+                   "pose_delta_evaluation": "off: every step evaluates all %d pairs" % n_pairs},
         "timing": {"value_is": "median of %d blocks of %d steps" % (len(res["blocks"]), args.steps),
                    "blocks_ms_per_step": [1e3 * b / args.steps for b in res["blocks"]],
                    "cold": {"ms_per_step": 1e3 * res["cold"] / args.steps, "value": args.steps / res["cold"],
