@@ -438,6 +438,7 @@ def main():
         "pairs_per_s": n_pairs * args.steps / elapsed,
         "kappa_samples_per_s": n_pairs * n_kappa * args.steps / elapsed,
         "non_pair_kernel_us_per_step": 1e3 * (1e3 * elapsed / args.steps - pair_ms),
+        "pairs_evaluated_last_step": metric.last_evaluated_pairs(),  # the library's own count: this rank's whole shard
         "last_value": last,
     }
     for m in modes:

@@ -10,8 +10,10 @@ from ._lib import (EccError, FILTER_DERIVATIVE, FILTER_NONE, FILTER_RAMP, POST_I
                    POST_SQUARE_ROOT)
 from . import geometry
 from .api import (Context, Group, GroupMetricRadonIntermediate, MetricDirect, MetricRadonIntermediate, pair_shard, pair_shards_balanced, PreProccess, RadonIntermediate, get_ij, host_object_radius, host_pinvT,
-                  host_source_position, pack_projection_matrices, slab_floats)
+                  host_source_position, pack_projection_matrices, slab_floats, estimateAngularRange, estimateAngularStep,
+                  estimateIsoCenter, estimateObjectRadius)
 
 __all__ = ["Context", "Group", "GroupMetricRadonIntermediate", "pair_shard", "pair_shards_balanced", "MetricDirect", "PreProccess", "RadonIntermediate", "MetricRadonIntermediate", "EccError", "get_ij", "slab_floats", "pack_projection_matrices", "host_pinvT",
            "host_source_position", "host_object_radius", "FILTER_DERIVATIVE", "FILTER_RAMP", "FILTER_NONE",
-           "POST_IDENTITY", "POST_SQUARE_ROOT", "POST_LOGARITHM"]
+           "POST_IDENTITY", "POST_SQUARE_ROOT", "POST_LOGARITHM", "estimateAngularRange", "estimateAngularStep",
+           "estimateIsoCenter", "estimateObjectRadius"]

@@ -5,6 +5,8 @@
 //   EpipolarConsistency::Metric                   ref: LibEpipolarConsistency/EpipolarConsistency.h:49-94
 //   EpipolarConsistency::MetricRadonIntermediate  ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.h:21-106
 //   EpipolarConsistency::MetricDirect             ref: LibEpipolarConsistency/EpipolarConsistencyDirect.h:28-60
+//   estimateIsoCenter / estimateObjectRadius / estimateAngularRange / estimateAngularStep
+//                                                 ref: LibEpipolarConsistency/EpipolarConsistency.h:36-46
 //
 // A caller such as Gui/SingleImageMotion.h (:37,72,88), Gui/Registration.h (:34,67,80) or
 // tools/Registration/Registration3D3D.hxx (:66-67,95) compiles against this header instead of the
@@ -337,6 +339,29 @@ private:
     size_t host_length() const { return m_raw_cpu.size(); }
 #endif
 };
+
+/// ref: EpipolarConsistency.h:36-46 (free functions).  estimateIsoCenter returns the point as (x, y, z, 1);
+/// estimateAngularRange takes the two matrices whose baseline the reference's RP3Line argument is
+/// (join_pluecker of their source positions, ref: EpipolarConsistencyDirect.cpp:88-92).
+inline std::vector<double> estimateIsoCenter(const std::vector<ProjectionMatrix>& Ps)
+{
+    std::vector<double> flat(12 * Ps.size()), O(4, 0.0);
+    for (size_t i = 0; i < Ps.size(); ++i)
+        for (int k = 0; k < 12; ++k) flat[12 * i + k] = Ps[i].data()[k];
+    ecc_host_iso_center(flat.data(), (int)Ps.size(), O.data());
+    return O;
+}
+inline double estimateObjectRadius(const ProjectionMatrix& P, int n_u, int n_v) { return ecc_host_object_radius(P.data(), n_u, n_v); }
+inline std::pair<double, double> estimateAngularRange(const ProjectionMatrix& P0, const ProjectionMatrix& P1, double object_radius_mm)
+{
+    std::pair<double, double> r(0.0, 0.0);
+    ecc_host_angular_range(P0.data(), P1.data(), object_radius_mm, &r.first, &r.second);
+    return r;
+}
+inline double estimateAngularStep(const ProjectionMatrix& P0, const ProjectionMatrix& P1, int n_u, int n_v)
+{
+    return ecc_host_angular_step(P0.data(), P1.data(), n_u, n_v);
+}
 
 /// ref: class Metric (interface)
 class Metric {

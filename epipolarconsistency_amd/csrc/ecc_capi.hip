@@ -1084,6 +1084,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     p.cost = cost_d;
     p.K01_out = K01_d;
     p.records = m->records_d;
+    m->last_evaluated_pairs = count;
     // (Replaying the three launches below as an instantiated hipGraph was measured on ROCm 7.2: 6-9 us SLOWER per
     // evaluation than launching them on the stream, at 79 800 pairs and at a 9 975-pair shard.)
     HIP_TRY(ecc_launch_k01(&p, ctx->stream));

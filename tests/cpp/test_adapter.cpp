@@ -35,6 +35,12 @@ int main(int argc, char** argv)
         MetricRadonIntermediate ecc(Ps, dtrs);
         std::vector<float> cost((size_t)n * n, -1.f);
         printf("radius %.17g\n", ecc.getObjectRadius());
+        {   // the free functions of EpipolarConsistency.h:36-46
+            const std::vector<double> O = estimateIsoCenter(Ps);
+            const std::pair<double, double> range = estimateAngularRange(Ps[0], Ps[2], 50.0);
+            printf("freefn %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", estimateObjectRadius(Ps[0], n_u, n_v),
+                   estimateAngularStep(Ps[0], Ps[2], n_u, n_v), range.first, range.second, O[0], O[1], O[2], O[3]);
+        }
         printf("mean %.17g\n", ecc.evaluate(cost.data()));
         printf("cost10 %.9g cost01 %.9g\n", cost[0 + 1 * n], cost[1 + 0 * n]);
         std::set<int> views;

@@ -141,6 +141,12 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     assert int(f[2]) == len(dpair["kappas"])
     r50 = oracle_mod.evaluate_all(Ps, dtrs, s["n_u"], s["n_v"], object_radius_mm=50.0)
     assert abs(float(val["mean_r50"]) - r50["mean"]) < 1e-5 * r50["mean"]
+    # the free functions of EpipolarConsistency.h:36-46 as the adapter exposes them = the C ABI's host functions
+    f = [float(x) for x in val["freefn"].split()]
+    lo, hi = E.estimateAngularRange(Ps[0], Ps[2], 50.0)
+    assert f[0] == E.estimateObjectRadius(Ps[0], s["n_u"], s["n_v"]) == oracle_mod.object_radius(Ps[0], s["n_u"], s["n_v"])
+    assert f[1] == E.estimateAngularStep(Ps[0], Ps[2], s["n_u"], s["n_v"]) and (f[2], f[3]) == (lo, hi) and lo < 0 < hi
+    assert np.array_equal(np.array(f[4:8]), E.estimateIsoCenter(Ps)) and f[7] == 1.0
     # setIncremental (pose-delta evaluation): the optimiser pattern gives the same bits with and without it
     assert val["incremental"].split()[0] == "1", val["incremental"]
     # the same program, unchanged, over a default group of two ranks (ECC_HIP_DEVICES; both on device 0 here): evaluate()
