@@ -27,7 +27,7 @@
 //
 // Error behaviour: the reference prints and exit()s on any CUDA error (LibUtilsCuda/UtilsCuda.hxx:14-28);
 // the adapter throws std::runtime_error with ecc_last_error() instead.
-// Not carried over: getTexture()/BindlessTexture2D (there are no textures),
+// Not carried over: BindlessTexture2D (there are no textures; getTexture() returns null),
 // setProjectionImages (a stub in the reference, ...RadonIntermediate.cpp:121-125).
 #ifndef ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
 #define ECC_EPIPOLAR_CONSISTENCY_HIP_HXX
@@ -230,6 +230,10 @@ public:
     const std::vector<float>& data() const { return m_raw_cpu; }
 #endif
     void clearRawData() { host_resize(0, 0); }
+    /// ref: getTexture() (RadonIntermediate.h:76, .cpp:188-196) uploads host data that is not on the device yet and
+    /// returns the bindless texture.  Here the device copy is always current and there are no textures: returns null.
+    /// Kept because a caller uses it for the upload alone (Gui/InputDataRadonIntermediate.cpp:78).
+    void* getTexture() { return nullptr; }
 
     /// ref: replaceRadonIntermediateData(image) (RadonIntermediate.cpp:105-123): new data from host memory, n_t rows x
     /// n_alpha columns; original image size and filter are kept.  A metric that already holds this object must be
