@@ -5,6 +5,7 @@
 //   EpipolarConsistency::Metric                   ref: LibEpipolarConsistency/EpipolarConsistency.h:49-94
 //   EpipolarConsistency::MetricRadonIntermediate  ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.h:21-106
 //   EpipolarConsistency::MetricDirect             ref: LibEpipolarConsistency/EpipolarConsistencyDirect.h:28-60
+//   EpipolarConsistency::PreProccess              ref: LibEpipolarConsistency/Gui/PreProccess.h:13-50 (fields and the two image calls)
 //   estimateIsoCenter / estimateObjectRadius / estimateAngularRange / estimateAngularStep
 //                                                 ref: LibEpipolarConsistency/EpipolarConsistency.h:36-46
 //
@@ -342,6 +343,92 @@ private:
     float* host_ptr() const { return const_cast<float*>(m_raw_cpu.data()); }
     size_t host_length() const { return m_raw_cpu.size(); }
 #endif
+};
+
+/// ref: struct PreProccess (Gui/PreProccess.h:13-50) without the GetSet GUI glue: the same fields and defaults; the two
+/// image calls run as one device kernel each (ecc_preprocess of the C ABI, bit-identical to the reference's host loops).
+/// The reference's order is process(image); apply_weight_cos_principal_ray(image, P) (Gui/InputDataDirect.cpp:85-86);
+/// process_and_weight does both in ONE pass over a whole stack.
+struct PreProccess {
+#ifdef ECC_ADAPTER_HAVE_EIGEN
+    typedef Eigen::Vector4i Vector4i;
+    static Vector4i constant4(int v) { return Vector4i::Constant(v); }
+#else
+    struct Vector4i {
+        int v[4];
+        int& operator[](int i) { return v[i]; }
+        int operator[](int i) const { return v[i]; }
+    };
+    static Vector4i constant4(int x) { Vector4i r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = x; return r; }
+#endif
+    struct Intensity {
+        bool normalize; double bias; double scale; bool apply_log;
+        Intensity() : normalize(false), bias(0.0), scale(1.0), apply_log(false) {}
+    } intensity;
+    struct Lowpass {
+        double gaussian_sigma; int half_kernel_width;
+        Lowpass() : gaussian_sigma(1.84), half_kernel_width(5) {}
+    } lowpass;
+    struct ImageGeometry {
+        bool flip_u, flip_v;
+        ImageGeometry() : flip_u(false), flip_v(false) {}
+    } image_geometry;
+    /// Offsets are left, right, bottom, top; blanks are rectangles (x0, y0, x1, y1).
+    struct Border {
+        Vector4i zero, feather;
+        std::vector<Vector4i> blanks;
+        Border() : zero(constant4(1)), feather(constant4(16)) {}
+    } border;
+
+    /// ref: process(NRRD::ImageView<float>& image) (Gui/PreProccess.cpp:57-144), in place on a host image
+    void process(float* image, int n_u, int n_v, ecc_ctx* ctx = nullptr) const { run(image, 1, n_u, n_v, true, nullptr, ctx); }
+    /// ref: apply_weight_cos_principal_ray(image, P) (Gui/PreProccess.cpp:146-166), in place on a host image
+    void apply_weight_cos_principal_ray(float* image, int n_u, int n_v, const ProjectionMatrix& P, ecc_ctx* ctx = nullptr) const
+    {
+        run(image, 1, n_u, n_v, false, P.data(), ctx);
+    }
+    /// Both steps for a stack of n host images (n x 12 doubles of matrices), one kernel launch.
+    void process_and_weight(float* images, int n, int n_u, int n_v, const std::vector<ProjectionMatrix>& Ps, ecc_ctx* ctx = nullptr) const
+    {
+        std::vector<double> flat(12 * Ps.size());
+        for (size_t i = 0; i < Ps.size(); ++i)
+            for (int k = 0; k < 12; ++k) flat[12 * i + k] = Ps[i].data()[k];
+        if ((int)Ps.size() != n) throw std::runtime_error("PreProccess::process_and_weight: one matrix per image");
+        run(images, n, n_u, n_v, true, flat.data(), ctx);
+    }
+#ifdef ECC_ADAPTER_HAVE_NRRD
+    void process(NRRD::ImageView<float>& image) const { process((float*)image, image.size(0), image.size(1)); }
+    void apply_weight_cos_principal_ray(NRRD::ImageView<float>& image, const ProjectionMatrix& P) const
+    {
+        apply_weight_cos_principal_ray((float*)image, image.size(0), image.size(1), P);
+    }
+#endif
+
+private:
+    void run(float* images, int n, int n_u, int n_v, bool do_process, const double* Ps, ecc_ctx* ctx) const
+    {
+        ecc_preprocess_config cfg;
+        ecc_preprocess_defaults(&cfg);
+        cfg.process = do_process ? 1 : 0;
+        cfg.normalize = intensity.normalize ? 1 : 0;
+        cfg.bias = intensity.bias;
+        cfg.scale = intensity.scale;
+        cfg.apply_log = intensity.apply_log ? 1 : 0;
+        cfg.gaussian_sigma = lowpass.gaussian_sigma;
+        cfg.half_kernel_width = lowpass.half_kernel_width;
+        cfg.flip_u = image_geometry.flip_u ? 1 : 0;
+        cfg.flip_v = image_geometry.flip_v ? 1 : 0;
+        std::vector<int32_t> blanks(4 * border.blanks.size());
+        for (int k = 0; k < 4; ++k) {
+            cfg.zero[k] = border.zero[k];
+            cfg.feather[k] = border.feather[k];
+        }
+        for (size_t b = 0; b < border.blanks.size(); ++b)
+            for (int k = 0; k < 4; ++k) blanks[4 * b + k] = border.blanks[b][k];
+        cfg.n_blanks = (int32_t)border.blanks.size();
+        cfg.blanks = blanks.empty() ? nullptr : blanks.data();
+        detail::check(ecc_preprocess(ctx ? ctx : detail::default_context(), images, 0, images, n, n_u, n_v, &cfg, Ps));
+    }
 };
 
 /// ref: EpipolarConsistency.h:36-46 (free functions).  estimateIsoCenter returns the point as (x, y, z, 1);

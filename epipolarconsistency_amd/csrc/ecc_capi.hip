@@ -1627,8 +1627,10 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
     p.bias = (float)cfg->bias;
     p.max_d = max_d;
     p.apply_log = cfg->apply_log ? 1 : 0;
-    p.flip_u = cfg->flip_u ? 1 : 0;
-    p.flip_v = cfg->flip_v ? 1 : 0;
+    // the flips belong to PreProccess::process (ref: Gui/PreProccess.cpp:123-136); the cosine weighting alone leaves the
+    // image where it is
+    p.flip_u = (cfg->process && cfg->flip_u) ? 1 : 0;
+    p.flip_v = (cfg->process && cfg->flip_v) ? 1 : 0;
     for (int s = 0; s < 4; ++s) {
         p.zero[s] = cfg->zero[s];
         p.feather[s] = cfg->feather[s];

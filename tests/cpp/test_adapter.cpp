@@ -3,6 +3,8 @@
 // Reads a raw float32 image stack + matrices written by the pytest driver, prints results as text.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <set>
 #include <vector>
 
@@ -82,6 +84,23 @@ int main(int argc, char** argv)
             ecc.setProjectionMatrices(Ps);
             printf("incremental %d %.17g %.17g\n", (full_values[0] == inc_values[0] && full_values[1] == inc_values[1] &&
                    full_values[2] == inc_values[2] && full_values[0] != full_values[1]) ? 1 : 0, full_values[2], inc_values[2]);
+        }
+        {   // PreProccess (Gui/PreProccess.h): the two image calls one after the other on image 1, the fused stack call on
+            // all images -- results written next to the input file for the driver to compare
+            PreProccess pre;
+            pre.intensity.scale = 0.5;
+            pre.intensity.bias = 0.125;
+            pre.border.zero[0] = 3;
+            pre.image_geometry.flip_u = true;
+            std::vector<float> one(imgs.begin() + (size_t)n_u * n_v, imgs.begin() + 2 * (size_t)n_u * n_v), all(imgs);
+            pre.process(one.data(), n_u, n_v);
+            pre.apply_weight_cos_principal_ray(one.data(), n_u, n_v, Ps[1]);
+            pre.process_and_weight(all.data(), n, n_u, n_v, Ps);
+            const bool same = std::memcmp(one.data(), all.data() + (size_t)n_u * n_v, sizeof(float) * n_u * n_v) == 0;
+            FILE* o = fopen((std::string(path) + ".pre").c_str(), "wb");
+            if (!o || fwrite(all.data(), sizeof(float), all.size(), o) != all.size()) return 3;
+            fclose(o);
+            printf("preprocess %d\n", same ? 1 : 0);
         }
         {
             MetricDirect direct(Ps, imgs.data(), n, n_u, n_v);

@@ -147,6 +147,17 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
     assert f[0] == E.estimateObjectRadius(Ps[0], s["n_u"], s["n_v"]) == oracle_mod.object_radius(Ps[0], s["n_u"], s["n_v"])
     assert f[1] == E.estimateAngularStep(Ps[0], Ps[2], s["n_u"], s["n_v"]) and (f[2], f[3]) == (lo, hi) and lo < 0 < hi
     assert np.array_equal(np.array(f[4:8]), E.estimateIsoCenter(Ps)) and f[7] == 1.0
+    # PreProccess of the adapter: two separate calls == the fused stack call == the Python mirror (same C ABI), and the
+    # oracle's statement of the reference's host loops, bit for bit
+    assert val["preprocess"] == "1"
+    got_pre = np.fromfile(ipath + ".pre", np.float32).reshape(imgs.shape)
+    pp = E.PreProccess()
+    pp.intensity.scale, pp.intensity.bias, pp.border.zero, pp.image_geometry.flip_u = 0.5, 0.125, [3, 1, 1, 1], True
+    ctx = E.Context(0)
+    assert np.array_equal(got_pre, pp.process(ctx, imgs, Ps))
+    ctx.close()
+    for k in (0, 3):
+        assert np.array_equal(got_pre[k], oracle_mod.preprocess(imgs[k], Ps[k], scale=0.5, bias=0.125, zero=(3, 1, 1, 1), flip_u=True))
     # setIncremental (pose-delta evaluation): the optimiser pattern gives the same bits with and without it
     assert val["incremental"].split()[0] == "1", val["incremental"]
     # the same program, unchanged, over a default group of two ranks (ECC_HIP_DEVICES; both on device 0 here): evaluate()

@@ -69,6 +69,12 @@ def test_cosine_weight_and_in_place_on_device(gpu_ctx, oracle_mod, small_scan):
     w = pp.apply_weight_cos_principal_ray(gpu_ctx, imgs, Ps)
     want_w = np.stack([oracle_mod.preprocess(imgs[k], Ps[k], process=False) for k in range(4)])
     assert np.abs(w - want_w).max() <= 2e-7 * np.abs(want_w).max()
+    # ... is not affected by the fields of process(): the flips in particular belong to process() alone
+    # (ref: Gui/PreProccess.cpp:123-136 against :146-166)
+    pf = E.PreProccess()
+    pf.image_geometry.flip_u = pf.image_geometry.flip_v = True
+    pf.intensity.scale, pf.border.zero = 3.0, [9, 9, 9, 9]
+    assert np.array_equal(pf.apply_weight_cos_principal_ray(gpu_ctx, imgs, Ps), w)
     # intrinsics agree with the oracle's
     a = np.array(oracle_mod.intrinsics(Ps[0]))
     from epipolarconsistency_amd.api import host_intrinsics
