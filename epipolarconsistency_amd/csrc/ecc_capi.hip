@@ -1050,6 +1050,8 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t count)
     p->poly = resolve_sampling(m, count) == ECC_SAMPLING_POLYNOMIAL ? m->ctx->poly_d : nullptr;
     p->slabs = m->dtr_table_d;  // ECC_SAMPLING_REFERENCE samples the dtrs themselves (clamped taps), not the paired copies
     p->reference_arithmetic = resolve_sampling(m, count) == ECC_SAMPLING_REFERENCE ? 1 : 0;
+    // few pairs: all four waves of a workgroup on one pair (a function of the FULL range's size, like the mode itself)
+    p->reference_split = (p->reference_arithmetic && count <= 2048) ? 4 : 1;
     p->wide_offsets = ((int64_t)(m->n_alpha + 1) * m->pitch * 8 >= (int64_t)1 << 24) ? 1 : 0;
     p->quads = m->quads_table_d;
     p->quad_group_bytes = (unsigned)m->pitch * 64u;

@@ -101,6 +101,7 @@ struct EccPairParams {
     const int32_t* indices;    // optional n_pairs x 4 (P0, P1, dtr0, dtr1); null = all pairs
     float* pair_values;        // optional, `count` floats (local pair order)
     const int32_t* value_slots;  // optional, `count` entries: pair_values[value_slots[k]] instead of pair_values[k]
+    int reference_split;       // reference arithmetic: waves per pair, 1 or 4 (4: one pair per workgroup, for few pairs)
     float* cost;               // optional n x n cost image (index i + j*n)
     float* K01_out;            // optional debug output, 16 floats per pair
     EccPairRecord* records;    // `count` records, written by k01_kernel, read by pairs_kernel

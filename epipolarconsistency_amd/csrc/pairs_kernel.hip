@@ -1141,12 +1141,19 @@ __global__ __launch_bounds__(256) void pair_samples_kernel(EccPairSamplesParams 
 // the polynomial path per sample -- meant for evaluations of few pairs, where a single pair's value has to agree with
 // the CPU path (include/ecc_hip.h, ecc_metric_set_sampling).
 // -------------------------------------------------------------------------------------------------
-template <bool CORR>
+// SPLIT = 4: the four waves of a workgroup share ONE pair (thread T takes k = T, T + 256, ...; the wave sums are added in
+// wave order through LDS) -- a launch of at most a few hundred pairs leaves most of the 1024 SIMDs idle, and the time of
+// the evaluation is the time of one pair: 81 -> ~50 us for a single-pair evaluation.  The float64 partial sums are
+// grouped differently from SPLIT = 1, so the mode of a metric is fixed by the size of the FULL range it evaluates
+// (fill_pair_params), not by the launch: pose-delta launches reproduce the full evaluation's bits.
+template <bool CORR, int SPLIT>
 __global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairParams p)
 {
+    static_assert(SPLIT == 1 || SPLIT == PK_THREADS / 64, "one pair per wave or per workgroup");
+    __shared__ double part[3][PK_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long local = (long long)blockIdx.x * 4 + wave;
-    if (local >= p.count) return;
+    long long local = SPLIT == 1 ? (long long)blockIdx.x * 4 + wave : (long long)blockIdx.x;
+    if (local >= p.count) return;  // SPLIT > 1: uniform over the workgroup
     local = ((long long)__builtin_amdgcn_readfirstlane((int)(local >> 32)) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane((int)local);
     const EccPairRecord* __restrict__ rec = p.records + local;
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairPara
     const float dkappa = K1[6], kappa_max = K1[7];
     const bool deriv = p.is_derivative != 0;
     double acc = 0.0, mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;
-    for (int k = lane; k < p.k_limit; k += 64) {
+    for (int k = SPLIT == 1 ? lane : (int)threadIdx.x; k < p.k_limit; k += 64 * SPLIT) {
         const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259
         if (kappa >= kappa_max) break;
         float x0 = (float)cos((double)kappa);
@@ -1185,16 +1192,38 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairPara
             mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
         }
     }
-    float val;
     if (!CORR) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        val = (float)acc;
     } else {
         for (int off = 32; off > 0; off >>= 1) {
             mom2 += __shfl_down(mom2, off);
             mom3 += __shfl_down(mom3, off);
             mom4 += __shfl_down(mom4, off);
         }
+    }
+    if (SPLIT > 1) {  // wave sums -> wave 0, added in wave order
+        if (lane == 0) {
+            part[0][wave] = CORR ? mom2 : acc;
+            part[1][wave] = mom3;
+            part[2][wave] = mom4;
+        }
+        __syncthreads();
+        if (wave != 0) return;
+        acc = mom2 = part[0][0];
+        mom3 = part[1][0];
+        mom4 = part[2][0];
+#pragma unroll
+        for (int w = 1; w < PK_THREADS / 64; ++w) {
+            acc += part[0][w];
+            mom2 += part[0][w];
+            mom3 += part[1][w];
+            mom4 += part[2][w];
+        }
+    }
+    float val;
+    if (!CORR) {
+        val = (float)acc;
+    } else {
         const float xx = (float)mom2, yy = (float)mom3, xy = (float)mom4;
         const float corr = (float)((double)xy / (sqrt((double)xx) * sqrt((double)yy)));
         val = (1.0f - corr) * 1.0f;
@@ -1293,8 +1322,13 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
     if (p->count <= 0) return hipSuccess;
     long long nblk = (p->count + 3) / 4;
     if (p->reference_arithmetic) {
-        if (p->use_corr) hipLaunchKernelGGL((pairs_reference_kernel<true>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
-        else hipLaunchKernelGGL((pairs_reference_kernel<false>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
+        if (p->reference_split > 1) {
+            if (p->use_corr) hipLaunchKernelGGL((pairs_reference_kernel<true, 4>), dim3((unsigned)p->count), dim3(PK_THREADS), 0, stream, *p);
+            else hipLaunchKernelGGL((pairs_reference_kernel<false, 4>), dim3((unsigned)p->count), dim3(PK_THREADS), 0, stream, *p);
+        } else {
+            if (p->use_corr) hipLaunchKernelGGL((pairs_reference_kernel<true, 1>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
+            else hipLaunchKernelGGL((pairs_reference_kernel<false, 1>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
+        }
         return hipGetLastError();
     }
     long long per_xcd = (nblk + 7) / 8;
