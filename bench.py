@@ -124,6 +124,10 @@ def live_pmc(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    # already running under a profiler (scripts/pmc_pass.sh, profile_round.sh): its preloaded tool library would be
+    # inherited by the child pass, whose launcher then execs from a GPU-initialised process -- do not nest
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None
     out_dir = tempfile.mkdtemp(prefix="ecc_pmc_", dir="/tmp")
     try:
         cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "--output-format", "csv",

@@ -5,7 +5,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
 rows=[]
@@ -14,7 +14,7 @@ for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k=r["Kernel_Name"]
-    m=re.search(r"(pairs_kernel<[\w, ]+>|k01_kernel|radon_kernel<\w+>|sum_pairs_kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w]+>)", k)
+    m=re.search(r"(pairs_kernel<[\w, ]+>|k01_kernel|radon_kernel<\w+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w, ]+>)", k)
     if m:
         acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.summary.txt","w") as f:

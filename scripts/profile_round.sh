@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/stats_$tag
 rm -rf $out
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $R/gpurun_out/stats_$tag.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-live-pmc > $R/gpurun_out/stats_$tag.log 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 head -1 "$f" > $R/gpurun_out/${tag}_kernel_stats.csv
 grep -E "pairs_kernel|k01_kernel|radon_kernel|sum_pairs|e1_kernel|dtr_border|preprocess_kernel|ramp_kernel" "$f" >> $R/gpurun_out/${tag}_kernel_stats.csv || true
