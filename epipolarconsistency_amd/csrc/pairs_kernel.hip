@@ -754,6 +754,73 @@ __device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, doubl
     return ok;
 }
 
+// The same fit with the nodes and the checks spread over the LANES = 8 adjacent lanes a pair has in k01_kernel<8> (small
+// launches: the kernel's time is the length of one thread's chain of dependent float64 operations).  Lane j < H evaluates
+// node j (both signs), lane H the centre node; the even / odd node values are then exchanged inside the group and EVERY
+// lane accumulates the coefficients in the order fit_coordinate does (j = 0 .. H-1, then the centre), so c -- and with it
+// every pair value -- is bit-identical to the one-thread fit; check q runs on lane q.  The verdict is the AND over the group.
+template <bool ANGLE, int LANES>
+__device__ bool fit_coordinate_wide(const EccPolyTables& T, const CurveGeom& g, double km, bool& fold0, double* c, int j)
+{
+    constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
+    static_assert(LANES >= H + 1 && LANES >= ECC_POLY_CHECKS && (LANES & (LANES - 1)) == 0, "one lane per node and per check");
+    const int lane = threadIdx.x & 63, base = lane & ~(LANES - 1);
+    bool ok = true, f1 = false;
+    double fe = 0.0, fo = 0.0;
+    if (j < H) {
+        const double xj = T.nodes[j];
+        double sn, cs;
+        sincos_table(T, xj * km, sn, cs);
+        double fp, fm;
+        if (ANGLE) {
+            bool f2 = false, v1 = true, v2 = true;
+            fp = exact_angle_coord(T, g, cs, sn, f1, v1);
+            fm = exact_angle_coord(T, g, cs, -sn, f2, v2);
+            ok = v1 && v2 && f1 == f2;  // both against node 0's state below
+        } else {
+            fp = exact_distance_coord(g, cs, sn, false);
+            fm = exact_distance_coord(g, cs, -sn, false);
+        }
+        fe = 0.5 * (fp + fm);
+        fo = (fp - fm) * (0.5 / xj);
+    } else if (j == H) {
+        bool v1 = true;
+        fe = ANGLE ? exact_angle_coord(T, g, 1.0, 0.0, f1, v1) : exact_distance_coord(g, 1.0, 0.0, false);
+        ok = v1;
+    }
+    fold0 = __shfl((int)f1, base) != 0;  // the state at node 0, +kappa (what fit_coordinate takes)
+    if (ANGLE && j <= H) ok = ok && f1 == fold0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) {
+        const double fej = __shfl(fe, base + jj), foj = __shfl(fo, base + jj);
+#pragma unroll
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + jj], fej, c[2 * k]);
+#pragma unroll
+        for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.Ao[k * H + jj], foj, c[2 * k + 1]);
+    }
+    {
+        const double f0 = __shfl(fe, base + H);
+#pragma unroll
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + H], f0, c[2 * k]);
+    }
+    if (j < ECC_POLY_CHECKS) {
+        const double x = T.checks[j];
+        double sn, cs;
+        sincos_table(T, fabs(x) * km, sn, cs);
+        if (x < 0) sn = -sn;
+        bool f = fold0, v = true;
+        const double q = ANGLE ? exact_angle_coord(T, g, cs, sn, f, v) : exact_distance_coord(g, cs, sn, false);
+        double pq = c[N - 1];
+#pragma unroll
+        for (int k = N - 2; k >= 0; --k) pq = fma(pq, x, c[k]);
+        ok = ok && v && f == fold0 && fabs(pq - q) <= 1e-5;  // NaN fails
+    }
+    const unsigned long long all = __ballot(ok);
+    return ((all >> base) & ((1ull << LANES) - 1)) == ((1ull << LANES) - 1);
+}
+
 // Chebyshev economisation of the fitted polynomial: x^n = (T_n(x) + lower powers) / 2^(n-1) on [-1, 1], so the two top
 // monomials can be folded into the lower ones at an error of at most |c_n| / 2^(n-1) + |c_(n-1)| / 2^(n-2) -- two to
 // three orders of magnitude less than dropping them.  Lowers the degree two at a time while the accumulated bound
@@ -800,12 +867,21 @@ __device__ __forceinline__ int economise(double* c, double tol)
 // wave per SIMD -- the chain length is the kernel time there.  Measured: 79 800 pairs 35 us with float64 libm-style
 // series and divisions, 22 us with sincos_table / angle_table and explicit fma (both two threads per pair), 23 us
 // with four; a 9 975-pair shard (8 GPUs) 13 us with two threads per pair, 11 us with four.
-constexpr int K01_PAIRS = 64;
 
+// LANES: threads per (pair, role) -- 1: one thread does the whole fit (throughput form, 64 pairs per workgroup); 8: the
+// nodes and checks of a fit are spread over 8 adjacent lanes (fit_coordinate_wide, 8 pairs per workgroup) and everything
+// else is done redundantly by all of them: 2.6x the instructions in total, a third of the chain length -- the form for
+// launches of a few thousand pairs (index lists, pose-delta launches, the shard of one of 8 GPUs), where the kernel's
+// time IS the chain length.  Identical records either way.
+#ifndef ECC_K01_WIDE_MAX_PAIRS
+#define ECC_K01_WIDE_MAX_PAIRS 4096
+#endif
+template <int LANES>
 __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 {
     constexpr int N = ECC_POLY_DEG + 1;
-    const int role = threadIdx.x >> 6, v = role & 1, slot = threadIdx.x & 63;
+    constexpr int K01_PAIRS = 64 / LANES;
+    const int role = threadIdx.x >> 6, v = role & 1, slot = (threadIdx.x & 63) / LANES, jl = threadIdx.x & (LANES - 1);
     const bool angle_role = role < 2;
     const long long local = (long long)blockIdx.x * K01_PAIRS + slot;
     const bool live = local < p.count;
@@ -851,19 +927,44 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
         g.n_alpha = (double)p.n_alpha;
         g.n_t = (double)p.n_t;
         curve_geometry(Kv, g);
-        if (angle_role) ok = fit_coordinate<true>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;  // wave-uniform branch
-        else ok = fit_coordinate<false>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;
+        if (LANES == 1) {
+            if (angle_role) ok = fit_coordinate<true>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;  // wave-uniform branch
+            else ok = fit_coordinate<false>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < N; ++k) c[k] = 0.0;
+    }
+    if constexpr (LANES > 1) if (p.poly) {  // uniform over the launch
+        // every lane takes part in the exchanges of the wide fit; a group without a fit (dead slot, empty kappa range --
+        // the same for all its lanes) discards the result
+        const bool fit = live && kappa_max > 0.f && dkappa > 0.f;
+        CurveGeom g;
+        g.theta_ref = (fit && angle_role) ? angle_table(*p.poly, (double)Kv[0], (double)Kv[1]) : 0.0;
+        g.inv_range_t = 1.0 / (double)p.range_t;
+        g.n_alpha = (double)p.n_alpha;
+        g.n_t = (double)p.n_t;
+        curve_geometry(Kv, g);
+        double cw[N];
+        bool fw = false;
+        const EccPolyTables& T = *p.poly;
+        const bool okw = angle_role ? fit_coordinate_wide<true, LANES>(T, g, fit ? (double)kappa_max : 0.0, fw, cw, jl)
+                                    : fit_coordinate_wide<false, LANES>(T, g, fit ? (double)kappa_max : 0.0, fw, cw, jl);
+        if (fit) {
+            ok = okw ? 1 : 0;
+            fold0 = fw;
+#pragma unroll
+            for (int k = 0; k < N; ++k) c[k] = cw[k];
+        }
     }
 #if defined(PK_EXP_NO_ECONOMISE)
     if (ok) ok = ECC_POLY_DEG;
 #else
     if (ok) ok = economise(c, (double)p.economise_tol);
 #endif
-    ok_flags[role][slot] = ok;
-    if (angle_role) {
+    const bool writer = jl == 0;  // LANES > 1: the lanes of a group hold identical results
+    if (writer) ok_flags[role][slot] = ok;
+    if (angle_role && writer) {
         r->fold[v] = fold0 ? 0x80000000u : 0u;
 #pragma unroll
         for (int k = 0; k < N; ++k) r->ca[v][k] = (float)c[k];
@@ -882,7 +983,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
             for (int i = 0; i < 8; i++) p.K01_out[16 * local + 8 * v + i] = Kv[i];
     }
     __syncthreads();
-    if (!angle_role) {
+    if (!angle_role && writer) {
         if (r->fold[v]) {  // this view's fold, decided by the angle's thread: yd -> n_t + 1 - yd
             c[0] = (double)p.n_t + 1.0 - c[0];
 #pragma unroll
@@ -892,7 +993,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
         for (int k = 0; k < N; ++k) r->cd[v][k] = (float)c[k];
         r->cd[v][N] = (float)(c[0] - (double)(float)c[0]);
     }
-    if (role == 0) {
+    if (role == 0 && writer) {
         r->iD0 = iD0;
         r->iD1 = iD1;
         r->ci = ci;
@@ -1430,7 +1531,9 @@ extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, f
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k01_kernel, dim3((unsigned)((p->count + K01_PAIRS - 1) / K01_PAIRS)), dim3(256), 0, stream, *p);
+    // small launches: 8 lanes per fit (the kernel's time is one thread's chain there); the records are identical
+    if (p->count <= ECC_K01_WIDE_MAX_PAIRS) hipLaunchKernelGGL(k01_kernel<8>, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(k01_kernel<1>, dim3((unsigned)((p->count + 63) / 64)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 

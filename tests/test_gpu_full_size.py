@@ -46,6 +46,11 @@ def test_shards_cost_image_and_determinism(full_scan):
     assert total / n_pairs == mean
     parts = [m.evaluate_range(*sharding.pair_range(r, 8, n_pairs)) for r in range(8)]
     assert abs(sum(parts) - total) <= 1e-12 * total
+    # small launches run the pair-geometry kernel in its 8-lanes-per-fit form (k01_kernel<8>, at most 4096 pairs): every
+    # pair value is the one of the 79 800-pair launch, bit for bit
+    for first, count in ((0, 4096), (20000, 3000), (75704, 4096), (399, 399), (12345, 7)):
+        t, v = m.evaluate_range(first, count, want_pairs=True)
+        assert np.array_equal(v, vals[first:first + count]), (first, count)
     # cost image: entry [j, i] for i < j, everything else untouched (ref: ...RadonIntermediate.cu:250,269)
     iu = np.triu_indices(N, 1)  # (i, j) with i < j in get_ij order
     assert np.array_equal(cost[iu[1], iu[0]], vals)
