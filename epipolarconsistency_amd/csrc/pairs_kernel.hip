@@ -668,6 +668,14 @@ __device__ __forceinline__ double exact_angle_coord(const EccPolyTables& T, cons
     const double pi = 3.14159265358979323846, inv_Pi_f = 1.0 / (double)3.14159265359f;
     const double dot = fma(g.nn, c, g.alpha * s);  // l . A
     const double cross = g.beta * s;               // A x l
+#if defined(PK_EXP_UNFOLDED_FIT)  // feasibility experiment (wrong results): fit the UNFOLDED angle, no fold / quarter-turn conditions
+    {
+        const double inv_Pi_f = 1.0 / (double)3.14159265359f;
+        valid = fabs(cross) < 1e30 && fabs(dot) < 1e30;
+        fold = false;
+        return fma((g.theta_ref + angle_table(T, dot, cross)) * inv_Pi_f, g.n_alpha, 0.5);
+    }
+#endif
     valid = dot > 0.0 && fabs(cross) < 1e30 && dot < 1e30;
     const double D = angle_table(T, dot, cross);
     double theta = g.theta_ref + D;     // in (-3pi/2, 3pi/2): bring back to atan2's range (-pi, pi]

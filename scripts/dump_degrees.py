@@ -17,3 +17,6 @@ os.makedirs("gpurun_out", exist_ok=True)
 np.save("gpurun_out/degrees.npy", deg.astype(np.int8))
 np.save("gpurun_out/kappa_max.npy", K.astype(np.float32))
 print(np.bincount(deg, minlength=11))
+heavy = K > np.pi / 4
+print("kappa_max > pi/4:", int(heavy.sum()), "pairs; degree histogram", np.bincount(deg[heavy], minlength=11))
+print("others:", int((~heavy).sum()), "pairs; degree histogram", np.bincount(deg[~heavy], minlength=11))
