@@ -79,7 +79,8 @@ __device__ __forceinline__ float tex_lds(const float* tile_shifted, float x, flo
     float fx = xb - fi, fy = yb - fj;
     // fj*TILE_S + fi is an exact small integer in fp32 (|.| < 2^24) whether or not it is fused;
     // tile_shifted = tile - tile_off folds the tile origin into the base (one v_lshl_add per sample).
-    const float* tp = tile_shifted + (TRANSP ? (int)(fi * (float)TILE_S + fj) : (int)(fj * (float)TILE_S + fi));
+    // (an explicit fma: the build runs with -ffp-contract=off, and product and sum are exact integers either way)
+    const float* tp = tile_shifted + (TRANSP ? (int)__builtin_fmaf(fi, (float)TILE_S, fj) : (int)__builtin_fmaf(fj, (float)TILE_S, fi));
     float T00 = tp[0], T10 = tp[TRANSP ? TILE_S : 1];
     float T01 = tp[TRANSP ? 1 : TILE_S], T11 = tp[TILE_S + 1];
     float r0 = (1.f - fx) * T00 + fx * T10;
