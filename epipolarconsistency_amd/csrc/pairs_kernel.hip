@@ -284,11 +284,20 @@ __device__ __forceinline__ float line_tap_finish(const F4 q, const LineTap t)
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ t.m) : v;
 }
 
-template <bool DERIV, int PITCH4>
+template <bool DERIV, int PITCH4, bool NT = false>
 __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
                                              float n_t_f, float dist_scale, float dist_bias, float pitch4_f)
 {
     const LineTap t = sample_line_prep<PITCH4>(l0, l1, l2, sv, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    if (NT) {  // experiment (-DPK_EXP_HEAVY_NT): non-temporal gathers for the kappa_max > pi/4 pairs, whose lines nobody
+               // re-uses -- inside the benchmark's mixed launch 0.344 vs 0.333 ms (A/B/A/B): they lose their own L1 hits
+        F4 q;
+        q.x = __builtin_nontemporal_load(&t.ptr->x);
+        q.y = __builtin_nontemporal_load(&t.ptr->y);
+        q.z = __builtin_nontemporal_load(&t.ptr->z);
+        q.w = __builtin_nontemporal_load(&t.ptr->w);
+        return line_tap_finish<DERIV>(q, t);
+    }
 #if defined(PK_EXP_NO_LOAD)
     return line_tap_finish<DERIV>(F4{t.fx, t.fy, __uint_as_float((unsigned)(size_t)t.ptr), 1.f}, t);
 #else
@@ -313,10 +322,15 @@ __device__ __forceinline__ bool kappa_step(int k, const float (&K0)[8], const fl
     // view 1
     const float a10 = K1[0] * cs, a11 = K1[1] * cs, a12 = K1[2] * cs;
     const float b10 = K1[3] * sn, b11 = K1[4] * sn, b12 = K1[5] * sn;
-    const float v0p = sample_line<DERIV, PITCH4>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    const float v1p = sample_line<DERIV, PITCH4>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    const float v0m = sample_line<DERIV, PITCH4>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    const float v1m = sample_line<DERIV, PITCH4>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+#if defined(PK_EXP_HEAVY_NT)
+    constexpr bool NT = REDUCE;
+#else
+    constexpr bool NT = false;
+#endif
+    const float v0p = sample_line<DERIV, PITCH4, NT>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v1p = sample_line<DERIV, PITCH4, NT>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v0m = sample_line<DERIV, PITCH4, NT>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v1m = sample_line<DERIV, PITCH4, NT>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
     if (!CORR) {
         const float vp = v0p - v1p, vm = v0m - v1m;
         const float consistency = (vp * vp + vm * vm) * K0[6];  // ref: ...RadonIntermediate.cu:112
