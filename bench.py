@@ -409,6 +409,18 @@ def main():
     if rp and rp.get("SQ_LDS_IDX_ACTIVE"):
         roofline_radon["lds_bank_conflict_ratio"] = rp["SQ_LDS_BANK_CONFLICT"] / rp["SQ_LDS_IDX_ACTIVE"]
         roofline_radon["pmc_source"] = "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/pmc_current.json (%s)" % rp["_tag"]
+        # the committed passes profile this bench, whose Radon launches are `sub` = 50 images each
+        img_s = ms_per_radon * 1e-3
+        roofs_r = {"lds_algorithmic": {"frac": roofline_radon["frac"], "note": "conflict-free 16 B per fetch"},
+                   "lds_pipe_active": {"frac": rp["SQ_LDS_IDX_ACTIVE"] / sub / (N_CU * ENGINE_CLOCK_GHZ * 1e9 * img_s),
+                                       "note": "SQ_LDS_IDX_ACTIVE cycles per image / (256 CUs x 2.4 GHz x seconds per image): "
+                                               "bank conflicts included"}}
+        if rp.get("SQ_INSTS_VALU"):
+            valu_peak = N_CU * SIMD_PER_CU * ENGINE_CLOCK_GHZ * 1e9 / VALU_CYCLES_PER_WAVE_INSTR
+            roofs_r["valu"] = {"frac": rp["SQ_INSTS_VALU"] / sub / img_s / valu_peak,
+                               "note": "SQ_INSTS_VALU per image at 2 cycles per wave64 instruction on 1024 SIMDs"}
+        roofline_radon["roofs"] = roofs_r
+        roofline_radon["binding"] = max(roofs_r, key=lambda r: roofs_r[r]["frac"])
 
     out = {
         "metric": "ECC evaluations/sec (N=%d, %d^2 projections)" % (n, S),
