@@ -12,7 +12,7 @@
 //     contiguous vector: a workgroup owns a row, stages it in LDS (x[s] is then a broadcast read),
 //     and every thread produces outputs t, t+256, ... of that row;
 //   * h comes from the host as a doubled table h2[m] = h[m mod n_t], m < 2 n_t, in binary64, so
-//     h2[t - s + n_t] needs no modulo and consecutive lanes read consecutive doubles (L1-resident, 12 KB);
+//     h2[t - s + n_t] needs no modulo and consecutive lanes read consecutive doubles (staged in LDS, 12 KB);
 //   * products and the sum over s = 0..n_t-1 run in binary64 in the oracle's order (mul, add; no
 //     contraction), rounded once to float -- bit-identical to oracle/ecc_oracle.c (eccor_ramp_filter);
 //     MI355X runs vector fp64 at half the fp32 rate, so exactness is free at this size;
@@ -24,33 +24,42 @@
 namespace {
 
 constexpr int RAMP_THREADS = 256;
-constexpr int RAMP_OUT = 4;  // outputs per thread per pass
 
+// OUT: outputs per thread per pass (t, t + 256, ...): 3 covers n_t <= 768 in one pass without idle slots (the default
+// 768 bins), 4 is the general form.  h2 is staged in LDS next to the row: read from global memory, the four 512-byte
+// loads per wave and step made the kernel L1-bound at 3.5x its float64 issue time (126 us per 768^2 dtr; now LDS-bound
+// at 1.7x).
+// H_LDS = false (more than 3276 distance bins: table + row above 64 KB): the table is read from global memory.
+template <int OUT, bool H_LDS>
 __global__ __launch_bounds__(RAMP_THREADS) void ramp_kernel(float* __restrict__ slabs, int64_t slab_stride,
                                                              int n_alpha, int n_t, int pitch,
                                                              const double* __restrict__ h2)
 {
-    extern __shared__ float xs[];  // n_t floats
+    extern __shared__ double lds_ramp[];  // [2 n_t doubles (h2),] then n_t floats (the row)
+    const double* hs = H_LDS ? lds_ramp : h2;
+    float* xs = reinterpret_cast<float*>(lds_ramp + (H_LDS ? 2 * n_t : 0));
     float* row = slabs + (int64_t)blockIdx.y * slab_stride + (size_t)(blockIdx.x + 1) * pitch + 1;
     for (int s = threadIdx.x; s < n_t; s += RAMP_THREADS) xs[s] = row[s];
+    if (H_LDS)
+        for (int s = threadIdx.x; s < 2 * n_t; s += RAMP_THREADS) lds_ramp[s] = h2[s];
     __syncthreads();
-    for (int t0 = threadIdx.x; t0 < n_t; t0 += RAMP_THREADS * RAMP_OUT) {
-        double acc[RAMP_OUT];
-        const double* hp[RAMP_OUT];
+    for (int t0 = threadIdx.x; t0 < n_t; t0 += RAMP_THREADS * OUT) {
+        double acc[OUT];
+        const double* hp[OUT];
 #pragma unroll
-        for (int j = 0; j < RAMP_OUT; ++j) {
+        for (int j = 0; j < OUT; ++j) {
             acc[j] = 0.0;
             // outputs past the end of the row read a valid (clamped) part of h2 and are not stored
             const int t = min(t0 + j * RAMP_THREADS, n_t - 1);
-            hp[j] = h2 + t + n_t;
+            hp[j] = hs + t + n_t;
         }
         for (int s = 0; s < n_t; ++s) {
             const double x = (double)xs[s];
 #pragma unroll
-            for (int j = 0; j < RAMP_OUT; ++j) acc[j] += x * hp[j][-s];
+            for (int j = 0; j < OUT; ++j) acc[j] += x * hp[j][-s];
         }
 #pragma unroll
-        for (int j = 0; j < RAMP_OUT; ++j) {
+        for (int j = 0; j < OUT; ++j) {
             const int t = t0 + j * RAMP_THREADS;
             if (t < n_t) row[t] = (float)acc[j];
         }
@@ -65,7 +74,13 @@ extern "C" hipError_t ecc_launch_ramp(float* slabs, int64_t slab_stride, int n_i
                                       const double* h2_d, hipStream_t stream)
 {
     dim3 grid(n_alpha, n_img), block(RAMP_THREADS);
-    hipLaunchKernelGGL(ramp_kernel, grid, block, sizeof(float) * (size_t)n_t, stream, slabs, slab_stride, n_alpha, n_t,
-                       pitch, h2_d);
+    const size_t lds_all = sizeof(double) * 2 * (size_t)n_t + sizeof(float) * (size_t)n_t;  // 15 KB at 768 bins
+    if (n_t <= 3 * RAMP_THREADS)
+        hipLaunchKernelGGL((ramp_kernel<3, true>), grid, block, lds_all, stream, slabs, slab_stride, n_alpha, n_t, pitch, h2_d);
+    else if (lds_all <= 64 * 1024)
+        hipLaunchKernelGGL((ramp_kernel<4, true>), grid, block, lds_all, stream, slabs, slab_stride, n_alpha, n_t, pitch, h2_d);
+    else
+        hipLaunchKernelGGL((ramp_kernel<4, false>), grid, block, sizeof(float) * (size_t)n_t, stream, slabs, slab_stride,
+                           n_alpha, n_t, pitch, h2_d);
     return hipGetLastError();
 }

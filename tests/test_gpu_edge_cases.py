@@ -205,7 +205,9 @@ def test_use_correlation(gpu_ctx, oracle_mod, small_scan):
     assert abs(m.evaluate() - ssd["mean"]) < 1e-5 * ssd["mean"]
 
 
-@pytest.mark.parametrize("shape,bins", [((96, 128), (96, 80)), ((61, 47), (33, 29)), ((40, 40), (8, 300))])
+@pytest.mark.parametrize("shape,bins", [((96, 128), (96, 80)), ((61, 47), (33, 29)), ((40, 40), (8, 300)),
+                                        ((40, 40), (6, 1000)),    # more than 768 distance bins: four outputs per thread
+                                        ((24, 24), (3, 3400))])   # table + row above 64 KB of LDS: table from global memory
 def test_ramp_filtered_radon(gpu_ctx, oracle_mod, shape, bins):
     """Filter::Ramp: line integrals + ramp filter along t (ref: RadonIntermediate.cu:166-167,173-237) --
     same binary64 circular convolution as the oracle, rounded once."""
