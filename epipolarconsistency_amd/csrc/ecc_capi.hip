@@ -1541,7 +1541,7 @@ ECC_EXPORT int ecc_preprocess(ecc_ctx* ctx, const float* images, int on_device, 
     const size_t kernel_b = sizeof(double) * kernel.size();
     const size_t blanks_b = sizeof(int32_t) * 4 * (size_t)cfg->n_blanks;
     const size_t cosw_b = sizeof(float) * cosw.size(), valid_b = sizeof(int) * valid.size();
-    const size_t max_b = sizeof(float) * (size_t)n;
+    const size_t max_b = sizeof(float) * (size_t)n * ECC_PRE_MAX_CHUNKS;
     auto up8 = [](size_t b) { return (b + 7) / 8 * 8; };
     const size_t upload_b = up8(kernel_b) + up8(blanks_b) + up8(cosw_b) + up8(valid_b) + up8(border_b);
     const size_t table_b = upload_b + up8(max_b);

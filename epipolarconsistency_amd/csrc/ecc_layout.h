@@ -127,6 +127,7 @@ struct EccPairParams {
 };
 
 // ---- projection pre-processing ------------------------------------------------
+#define ECC_PRE_MAX_CHUNKS 32  // workgroups per image of the maximum search in front of PreProccess::process (normalize)
 struct EccPreprocessParams {
     const float* in;          // n_img images, n_v x n_u, u fastest
     float* out;               // same shape; must not alias `in` (tiles read halos of their neighbours)
@@ -135,7 +136,7 @@ struct EccPreprocessParams {
     int process;              // 0: skip PreProccess::process, cosine weighting only
     int normalize;
     float scale, bias;
-    float* max_d;             // n_img floats (normalize)
+    float* max_d;             // n_img x ECC_PRE_MAX_CHUNKS partial maxima (normalize)
     int apply_log;
     int flip_u, flip_v;
     int zero[4], feather[4];  // left, right, bottom, top

@@ -14,7 +14,8 @@ out = torch.empty_like(imgs)
 ctx = E.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 ctx.enable_timing(True)
 for name, setup in (("defaults+cos", lambda p: None), ("no lowpass", lambda p: setattr(p.lowpass, "gaussian_sigma", 0.0)),
-                    ("log+flip", lambda p: (setattr(p.intensity, "apply_log", True), setattr(p.image_geometry, "flip_u", True)))):
+                    ("log+flip", lambda p: (setattr(p.intensity, "apply_log", True), setattr(p.image_geometry, "flip_u", True))),
+                    ("normalize", lambda p: setattr(p.intensity, "normalize", True))):
     pp = E.PreProccess()
     setup(pp)
     for r in range(3):
