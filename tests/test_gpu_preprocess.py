@@ -129,3 +129,32 @@ def test_preprocess_overlap_rejected_and_arena_reused(gpu_ctx, oracle_mod):
         gpu_ctx.synchronize()
         assert np.array_equal(t.cpu().numpy(), want)
         assert np.array_equal(pp.process(gpu_ctx, imgs), want)  # host form
+
+
+def test_normalize_maximum_and_nans(gpu_ctx, oracle_mod):
+    """Intensity/Normalize: the maximum is found by several workgroups per image; NaNs never win the search and a NaN
+    FIRST pixel stays the 'maximum' (ref: Gui/PreProccess.cpp:68-71) -- bit-identical to the oracle, sizes that do not
+    divide into the 32 parts evenly included."""
+    import epipolarconsistency_amd as E
+    rng = np.random.default_rng(5)
+    for shape in ((3, 70, 90), (2, 5, 7), (1, 1, 33)):
+        imgs = rng.uniform(0.0, 9.0, size=shape).astype(np.float32)
+        imgs[0, shape[1] // 2, shape[2] // 3] = 40.0     # the maximum somewhere inside
+        imgs[-1, shape[1] - 1, shape[2] - 1] = 77.0      # ... and in the very last pixel
+        if shape[0] > 1:
+            imgs[1, 0, 1 % shape[2]] = np.nan             # ignored by the search
+        if shape[0] > 2:
+            imgs[2, 0, 0] = np.nan                        # first pixel: everything becomes NaN -> 0
+        pp = E.PreProccess()
+        pp.intensity.normalize = True
+        pp.intensity.scale = 3.0
+        pp.lowpass.half_kernel_width = 0
+        pp.border.zero, pp.border.feather = [0, 0, 0, 0], [0, 0, 0, 0]
+        got = pp.process(gpu_ctx, imgs)
+        for k in range(shape[0]):
+            want = oracle_mod.preprocess(imgs[k], normalize=True, scale=3.0, half_kernel_width=0, zero=(0, 0, 0, 0),
+                                         feather=(0, 0, 0, 0))
+            assert np.array_equal(got[k], want), (shape, k)
+        assert got[0].max() == np.float32(3.0) or shape[0] == 1
+        if shape[0] > 2:
+            assert not got[2].any()
