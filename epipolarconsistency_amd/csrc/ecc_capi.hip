@@ -186,6 +186,9 @@ struct ecc_metric {
     int32_t* list_h = nullptr;
     int32_t* list_h_dev = nullptr;
     int64_t list_capacity = 0;  // pairs
+    std::vector<int> scratch_changed;        // reused between evaluations (no heap traffic on the optimiser's path)
+    std::vector<char> scratch_is_changed;
+    std::vector<int32_t> scratch_idx, scratch_slots;
     int64_t last_evaluated_pairs = 0;
 };
 
@@ -1129,13 +1132,17 @@ int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, 
                       m->cache_dkappa == m->dkappa && (int64_t)m->cache_Ps.size() == 12 * n;
     m->cache_valid = false;  // until everything below is enqueued
     if (same && count > 0) {
-        std::vector<int> changed;
+        std::vector<int>& changed = m->scratch_changed;
+        changed.clear();
         for (int64_t v = 0; v < n; ++v)
             if (std::memcmp(Pcur + 12 * v, m->cache_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
         if ((int64_t)changed.size() * 4 <= n) {  // c of n views changed: 1 - (1 - c/n)^2 of the pairs, at most 44 %
-            std::vector<char> is_changed((size_t)n, 0);
+            std::vector<char>& is_changed = m->scratch_is_changed;
+            is_changed.assign((size_t)n, 0);
             for (int v : changed) is_changed[v] = 1;
-            std::vector<int32_t> idx, slots;
+            std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots;
+            idx.clear();
+            slots.clear();
             for (int v : changed)
                 for (int64_t u = 0; u < n; ++u) {
                     if (u == v || (is_changed[u] && u < v)) continue;  // a pair of two changed views once
