@@ -5,7 +5,7 @@ Repeated device ids put several ranks (stream + thread each) on one GPU: a rehea
 scaling number."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import epipolarconsistency_amd as E
 from epipolarconsistency_amd import geometry, synthetic
 

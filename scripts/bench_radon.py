@@ -1,5 +1,5 @@
 """Radon-intermediate micro-bench (GPU box): ms per 1024^2 -> 768^2 derivative dtr, HIP-event timed."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import epipolarconsistency_amd as E

@@ -1,5 +1,5 @@
 """Diagnostic (GPU box): per-pair parity of both kernel variants against the oracle at a chosen size."""
-import sys, os, time, json
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import epipolarconsistency_amd as E

@@ -1,6 +1,6 @@
 """Pair-kernel time per pair class on the BASELINE workload: index-list evaluations of (a) the pairs on the exact path,
 (b) an equal number of degree-8 pairs, (c) degree-10 pairs.  python scripts/exp_pair_classes.py"""
-import json, os, sys, time
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import epipolarconsistency_amd as E

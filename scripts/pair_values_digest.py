@@ -2,7 +2,7 @@
 per-sample mode: a refactoring that must not change results is checked by running this before and after (GPU box)."""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import epipolarconsistency_amd as E
 from epipolarconsistency_amd import synthetic
 

@@ -1,9 +1,8 @@
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import subprocess
 from epipolarconsistency_amd import build
 build.build_library(force=True, extra_flags=["-DECC_RADON_STATS"])
-import torch, numpy as np
+import torch
 import epipolarconsistency_amd as E
 from epipolarconsistency_amd import synthetic, _lib
 dev = torch.device("cuda", 0)

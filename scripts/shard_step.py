@@ -3,7 +3,6 @@
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel durations at shard size."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 import epipolarconsistency_amd as E
 from epipolarconsistency_amd import sharding, synthetic

@@ -1,7 +1,7 @@
 """Where one optimiser step's wall time goes (GPU box): host-side timing of the two API calls vs kernel time."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import epipolarconsistency_amd as E
 from epipolarconsistency_amd import synthetic
 

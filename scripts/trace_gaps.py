@@ -1,4 +1,4 @@
-import csv, glob, sys
+import csv, glob
 rows=[]
 for f in glob.glob("/tmp/kt/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
