@@ -465,106 +465,8 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
 #endif
 }
 
-#if defined(PK_EXP_LDS_STAGE)
-// EXPERIMENT, not part of the default build (-DPK_EXP_LDS_STAGE): the LDS-staged sampling north_star sketches, built to be
-// measured against the L1 gather.  Per 64-sample trip and per stream (view 0 / 1, +kappa / -kappa) the wave stages a window
-// of the row-paired copy -- LS_ROWS rows x LS_BINS bins x 8 B = ONE coalesced 512-byte load, origin from the first and the
-// last live lane (SALU) -- into its private LDS region and reads every footprint back with a 16-byte LDS read; a trip in
-// which some footprint falls outside its window (wave-uniform test) takes the gathers instead, so results are the default
-// kernel's bit for bit.  768-bin copies, squared-difference metric only.  Measured: see DESIGN.md 4.2.
-constexpr int LS_ROWS = 4, LS_BINS = 16;
-template <bool DERIV, int DEG>
-__device__ __forceinline__ void kappa_loop_poly_lds(int lane, int wave, int k_limit, const EccPairRecord* __restrict__ rec,
-                                                    float dkappa, float kappa_max, float w06, const SlabView sv0,
-                                                    const SlabView sv1, float n_t_f, int last_row, int last_bin, double& acc,
-                                                    unsigned& trips_lds, unsigned& trips_all,
-                                                    F2 (*stage)[4][LS_ROWS * LS_BINS + 1])
-{
-    constexpr int PITCH4 = 6400;
-    float ca[2][ECC_POLY_DEG + 3], cd[2][ECC_POLY_DEG + 2];
-    unsigned fold[2];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-        fold[v] = (unsigned)__builtin_amdgcn_readfirstlane((int)rec->fold[v]);
-#pragma unroll
-        for (int k = 0; k <= ECC_POLY_DEG + 1; ++k) {
-            if (k > DEG && k <= ECC_POLY_DEG) continue;
-            ca[v][k] = uniformf(rec->ca[v][k]);
-            cd[v][k] = uniformf(rec->cd[v][k]);
-        }
-        ca[v][ECC_POLY_DEG + 2] = uniformf(rec->ca[v][ECC_POLY_DEG + 2]);
-    }
-    const float xs = uniformf(rec->x_scale);
-    const int lr = lane >> 4, lb = lane & 15;
-    for (int k0 = 0; k0 < k_limit; k0 += 64) {
-        const int k = k0 + lane;
-        const float kappa = dkappa * 0.5f + dkappa * k;
-        const bool live = k < k_limit && kappa < kappa_max;
-        const unsigned long long lm = __ballot(live);
-        if (lm == 0ull) break;
-        const int last = 63 - __builtin_clzll(lm);  // live lanes are a prefix of the wave
-        const float x = kappa * xs, z = x * x;
-        float xa[4], yd[4];  // streams: view 0 +, view 1 +, view 0 -, view 1 -
-        poly_pm<DEG>(ca[0], ca[0][ECC_POLY_DEG + 1], ca[0][ECC_POLY_DEG + 2], false, x, z, xa[0], xa[2]);
-        poly_pm<DEG>(cd[0], cd[0][ECC_POLY_DEG + 1], 0.f, true, x, z, yd[0], yd[2]);
-        poly_pm<DEG>(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa[1], xa[3]);
-        poly_pm<DEG>(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd[1], yd[3]);
-        float fx[4], fy[4];
-        int ia[4], ib[4], R0[4], B0[4];
-        bool inside = true;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            yd[s] = __builtin_amdgcn_fmed3f(yd[s], 0.f, n_t_f);
-            fx[s] = __builtin_amdgcn_fractf(xa[s]);
-            fy[s] = __builtin_amdgcn_fractf(yd[s]);
-            ia[s] = (int)(xa[s] - fx[s]);
-            ib[s] = (int)(yd[s] - fy[s]);
-            R0[s] = min(__builtin_amdgcn_readlane(ia[s], 0), __builtin_amdgcn_readlane(ia[s], last));
-            B0[s] = min(__builtin_amdgcn_readlane(ib[s], 0), __builtin_amdgcn_readlane(ib[s], last));
-            inside = inside && (!live || ((unsigned)(ia[s] - R0[s]) < (unsigned)LS_ROWS && (unsigned)(ib[s] - B0[s]) < (unsigned)(LS_BINS - 1)));
-        }
-        ++trips_all;
-        float val[4];
-        if (__ballot(!inside) == 0ull) {
-            ++trips_lds;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const SlabView sv = (s & 1) ? sv1 : sv0;
-                const int row = min(R0[s] + lr, last_row), bin = min(B0[s] + lb, last_bin);
-                stage[wave][s][lane] = *reinterpret_cast<const F2*>(sv.origin + (unsigned)(row * PITCH4 + bin * 8));
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int idx = live ? (ia[s] - R0[s]) * LS_BINS + (ib[s] - B0[s]) : 0;
-                const F2 e0 = stage[wave][s][idx], e1 = stage[wave][s][idx + 1];
-                const float r0 = fmaf(fx[s], e0.y, e0.x);
-                const float r1 = fmaf(fx[s], e1.y, e1.x);
-                val[s] = fmaf(fy[s], r1 - r0, r0);
-            }
-            __builtin_amdgcn_wave_barrier();  // the next trip overwrites the windows
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const SlabView sv = (s & 1) ? sv1 : sv0;
-                F4 q = {0.f, 0.f, 0.f, 0.f};
-                if (live) q = *reinterpret_cast<const F4*>(sv.origin + footprint_offset<PITCH4>(xa[s] - fx[s], yd[s] - fy[s], sv.pitch4, 0.f));
-                const float r0 = fmaf(fx[s], q.y, q.x);
-                const float r1 = fmaf(fx[s], q.w, q.z);
-                val[s] = fmaf(fy[s], r1 - r0, r0);
-            }
-        }
-        if (DERIV) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) val[s] = __uint_as_float(__float_as_uint(val[s]) ^ fold[s & 1] ^ (s >= 2 ? 0x80000000u : 0u));
-        }
-        if (live) {
-            const float vp = val[0] - val[1], vm = val[2] - val[3];
-            const float consistency = (vp * vp + vm * vm) * w06;
-            acc += (double)(consistency * dkappa);
-        }
-    }
-}
+#if defined(PK_EXP_LDS_STAGE)  // the LDS-staged sampling north_star sketches, built to be measured: 0.547 vs 0.329 ms
+#include "pairs_lds_stage_experiment.inc"
 #endif
 
 // The kappa loop of one pair, exact per-sample path.
