@@ -85,6 +85,7 @@ __device__ __forceinline__ float pointwise(const EccPreprocessParams& p, float v
 }
 
 // KT: half kernel width known at compile time (taps live in registers, loops unroll), or -1 = runtime k with
+// (k = 0, no low-pass, is preprocess_pointwise_kernel's; the KT == 0 branches below are not instantiated any more)
 // the taps read from an LDS copy (a scalar load per tap inside the loop serialises on its latency: 10.8 -> x us).
 // NT: threads per workgroup -- 512 with the compile-time low-pass (more waves per CU for the same LDS: 5.2 -> 4.7 us per
 // image; 1024: 5.9), 256 without a low-pass (3.2 against 3.5 us).
@@ -320,6 +321,76 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
     }
 }
 
+// Without a low-pass (sigma = 0 or half width <= 1, and the cosine-weighting-only call) nothing couples the pixels: no
+// LDS, no barrier -- every thread loads its 16 pixels of a 64 x 64 tile first (all in flight), applies the pixel-wise
+// stages (the border / blank tests only on tiles that touch a border zone or when blanks exist) and the cosine weight,
+// and stores.  Same arithmetic as preprocess_kernel<0>, which it replaces: 3.3 -> see DESIGN.md 4.5.
+__global__ __launch_bounds__(256) void preprocess_pointwise_kernel(EccPreprocessParams p)
+{
+    constexpr int NP = PP_TH / 4;
+    const int img_i = blockIdx.z;
+    const float* __restrict__ src = p.in + (int64_t)img_i * p.stride;
+    float* __restrict__ dst = p.out + (int64_t)img_i * p.stride;
+    const int W = p.n_u, H = p.n_v;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int gx = blockIdx.x * PP_TW + tx, y0 = blockIdx.y * PP_TH;
+    float scale = p.scale, bias = p.bias;
+    if (p.normalize) {  // ref: :68-76, as in preprocess_kernel
+        bias = 0;
+        float m = -INFINITY;
+        for (int c = 0; c < ECC_PRE_MAX_CHUNKS; ++c) {
+            const float v = p.max_d[img_i * ECC_PRE_MAX_CHUNKS + c];
+            if (v > m) m = v;
+        }
+        const float first = src[0];
+        scale = p.scale / (isnan(first) ? first : m);
+    }
+    const int sx = p.flip_u ? W - 1 - gx : gx;
+    bool interior = p.n_blanks == 0;
+    {
+        const int gx_lo = blockIdx.x * PP_TW, gx_hi = min(gx_lo + PP_TW, W) - 1, gy_lo = y0, gy_hi = min(y0 + PP_TH, H) - 1;
+        const int sx_lo = p.flip_u ? W - 1 - gx_hi : gx_lo, sx_hi = p.flip_u ? W - 1 - gx_lo : gx_hi;
+        const int sy_lo = p.flip_v ? H - 1 - gy_hi : gy_lo, sy_hi = p.flip_v ? H - 1 - gy_lo : gy_hi;
+        interior = interior && sx_lo >= p.zero[0] + p.feather[0] && p.n_u - sx_hi > p.zero[1] + p.feather[1] &&
+                   p.n_v - sy_hi > p.zero[2] + p.feather[2] && sy_lo >= p.zero[3] + p.feather[3];
+    }
+    const float sdd = p.cosw ? p.cosw[3 * img_i] : 0.f;
+    const float ppu = p.cosw ? p.cosw[3 * img_i + 1] : 0.f, ppv = p.cosw ? p.cosw[3 * img_i + 2] : 0.f;
+    const bool weight = p.cosw && p.cosw_valid[img_i];
+    if (p.process && !interior) {  // border tiles: the full pixel-wise chain in a rolled loop (long and rarely needed)
+#pragma unroll 1
+        for (int q = 0; q < NP; ++q) {
+            const int gy = y0 + ty + 4 * q;
+            if (gx >= W || gy >= H) continue;
+            const int sy = p.flip_v ? H - 1 - gy : gy;
+            float pixel = pointwise(p, src[(size_t)sy * W + sx], sx, sy, scale, bias);
+            if (weight) pixel *= cos_weight(gx, gy, ppu, ppv, sdd);
+            dst[(size_t)gy * W + gx] = pixel;
+        }
+        return;
+    }
+    float v[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int gy = y0 + ty + 4 * q;
+        const int sy = p.flip_v ? H - 1 - gy : gy;
+        v[q] = (gx < W && gy < H) ? src[(size_t)sy * W + sx] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int gy = y0 + ty + 4 * q;
+        if (gx >= W || gy >= H) continue;
+        float pixel = v[q];
+        if (p.process) {
+            pixel = pixel * scale + bias;  // ref: Gui/PreProccess.cpp:78-84
+            if (p.apply_log) pixel = (float)-(float)log((double)pixel);
+            if (pixel < 0 || isnan(pixel) || isinf(pixel)) pixel = 0;
+        }
+        if (weight) pixel *= cos_weight(gx, gy, ppu, ppv, sdd);
+        dst[(size_t)gy * W + gx] = pixel;
+    }
+}
+
 // Partial maxima for Intensity/Normalize (ref: Gui/PreProccess.cpp:68-71): ECC_PRE_MAX_CHUNKS workgroups per image, each
 // the maximum of its contiguous part with `if (v > m) m = v` from -inf (NaNs never win); preprocess_kernel combines them.
 // (One workgroup per image read its 4 MB alone: 9 us per image in a 50-image batch, 80 us for a single image.)
@@ -369,7 +440,7 @@ extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStr
     dim3 grid((p->n_u + PP_TW - 1) / PP_TW, (p->n_v + PP_TH - 1) / PP_TH, p->n_img);
     const size_t lds = ecc_preprocess_lds_bytes(p->k);
     if (p->k == 0)
-        hipLaunchKernelGGL((preprocess_kernel<0, 256>), grid, dim3(256), lds, stream, *p);
+        hipLaunchKernelGGL(preprocess_pointwise_kernel, grid, dim3(256), 0, stream, *p);
     else if (p->k == 5)  // the reference's default (Gui/PreProccess.h:28)
         hipLaunchKernelGGL((preprocess_kernel<5, 512>), grid, dim3(512), lds, stream, *p);
     else
