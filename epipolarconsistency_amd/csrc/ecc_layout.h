@@ -64,7 +64,7 @@ struct EccRadonParams {
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
 
-// What k01_kernel hands to pairs_kernel for one pair (312 bytes, read with scalar loads).
+// What k01_kernel hands to pairs_kernel for one pair (296 bytes, read with scalar loads).
 struct EccPairRecord {
     float K0[8];   // ref: computeK01 (EpipolarConsistencyCommon.hxx:93-149): K0[6] baseline distance, K0[7] view angle
     float K1[8];   // K1[6] dkappa, K1[7] kappa_max

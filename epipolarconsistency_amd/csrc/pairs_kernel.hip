@@ -4,7 +4,7 @@
 // float atomics per pair for (ref: LibEpipolarConsistency/EpipolarConsistencyRadonIntermediate.cu):
 //   kernelEpipolarConsistencyComputeK01 (:13-67)  -> k01_kernel: pair geometry plus, per view of the pair, the
 //                                                    sample coordinates as polynomials in kappa (EccPairRecord,
-//                                                    312 bytes), read by the pair kernel with scalar loads;
+//                                                    296 bytes), read by the pair kernel with scalar loads;
 //   kernelEpipolarCosistency<deriv,false> (:152-276) -> pairs_kernel: one wave64 per pair, kappa samples strided
 //                                                    over the lanes, shuffle reduction, ONE plain store.
 // Sampling replaces tex2D on a normalised, clamped, bilinear texture (ref: RadonIntermediate.cpp:192)
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     }
 
     // The records are assembled in LDS and leave the workgroup as one contiguous, coalesced block: written straight
-    // from the threads every store instruction would scatter its 64 lanes over 64 records 312 bytes apart.
+    // from the threads every store instruction would scatter its 64 lanes over 64 records 296 bytes apart.
     __shared__ EccPairRecord recs[K01_PAIRS];
     __shared__ int ok_flags[4][K01_PAIRS];
     static_assert(sizeof(EccPairRecord) % 8 == 0, "record copied as 8-byte words");
