@@ -324,7 +324,8 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
 // Without a low-pass (sigma = 0 or half width <= 1, and the cosine-weighting-only call) nothing couples the pixels: no
 // LDS, no barrier -- every thread loads its 16 pixels of a 64 x 64 tile first (all in flight), applies the pixel-wise
 // stages (the border / blank tests only on tiles that touch a border zone or when blanks exist) and the cosine weight,
-// and stores.  Same arithmetic as preprocess_kernel<0>, which it replaces: 3.3 -> see DESIGN.md 4.5.
+// and stores.  Same arithmetic as preprocess_kernel<0>, which it replaces: 3.3 -> 2.4 us per 1024^2 image.  (A thread owning
+// 4 consecutive pixels of 4 rows with 16-byte loads and stores was measured: 3.1 us -- fewer loads in flight per wave.)
 __global__ __launch_bounds__(256) void preprocess_pointwise_kernel(EccPreprocessParams p)
 {
     constexpr int NP = PP_TH / 4;
