@@ -20,6 +20,11 @@
 namespace {
 
 constexpr int PK_THREADS = 256;
+#ifndef PK_EXP_MAIN_WAVES
+#define PK_EXP_MAIN_WAVES 4  // waves (= pairs) per workgroup of pairs_kernel, wave w taking the pair w * nblk + block.  Measured
+                            // on the benchmark's launch: 1 wave 0.399 ms, 2 0.333, 4 0.326, 8 0.377, 16 0.408
+#endif
+constexpr int PK_MAIN_THREADS = 64 * PK_EXP_MAIN_WAVES;
 
 // ref: EpipolarConsistencyCommon.hxx:82-90 (shiftOriginAndNormlaize)
 __device__ __forceinline__ void shift_origin_and_normalize(float x, float y, float* Ki)
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 #define PK_OCCUPANCY
 #endif
 template <bool DERIV, bool CORR>
-__global__ __launch_bounds__(PK_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairParams p)
+__global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairParams p)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Workgroup -> pairs.  XCD-aware: workgroups b and b+8 share an XCD, and an XCD walks a contiguous part of the
@@ -967,7 +972,7 @@ __global__ __launch_bounds__(PK_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairP
 #if defined(PK_EXP_STAMPS)  // diagnostic build: wave start / end times (100 MHz), XCC id and path -> K01_out[16 * pair + 0..5]
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    const long long nblk = (p.count + 3) / 4;
+    const long long nblk = (p.count + PK_EXP_MAIN_WAVES - 1) / PK_EXP_MAIN_WAVES;
     const long long per_xcd = (nblk + 7) / 8;
 #if defined(PK_XCD_CHUNK)  // experiment: XCD x walks chunks x, x + 8, x + 16, ... of PK_XCD_CHUNK blocks instead of one contiguous eighth
     const long long seq = blockIdx.x >> 3;
@@ -1476,11 +1481,12 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
         }
         return hipGetLastError();
     }
+    nblk = (p->count + PK_EXP_MAIN_WAVES - 1) / PK_EXP_MAIN_WAVES;
     long long per_xcd = (nblk + 7) / 8;
 #if defined(PK_XCD_CHUNK)
     per_xcd = (nblk + 8LL * PK_XCD_CHUNK - 1) / (8LL * PK_XCD_CHUNK) * PK_XCD_CHUNK;
 #endif
-    dim3 grid((unsigned)(per_xcd * 8)), block(PK_THREADS);
+    dim3 grid((unsigned)(per_xcd * 8)), block(PK_MAIN_THREADS);
     if (p->use_corr) {
         if (p->is_derivative)
             hipLaunchKernelGGL((pairs_kernel<true, true>), grid, block, 0, stream, *p);
