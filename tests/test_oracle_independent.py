@@ -32,8 +32,9 @@ def tex(img, x, y):
     return f32(f32((one - fy) * r0) + f32(fy * r1))
 
 
-def radon_bin(img, n_alpha, n_t, ix, iy):
-    """SURVEY.md 8(a) row R1 (derivative filter, identity post-process), fp32 in source order."""
+def radon_bin(img, n_alpha, n_t, ix, iy, derivative=True, post=0):
+    """SURVEY.md 8(a) row R1, fp32 in source order.  derivative=False: the plain line integral (Filter::None and the input
+    of Filter::Ramp); post 1 / 2: sign-preserving square root / log(1 + .) of the derivative (RadonIntermediate.cu:125-138)."""
     H, W = img.shape
     n_u, n_v = f32(W), f32(H)
     D = f32(np.sqrt(f32(f32(n_u * n_u) + f32(n_v * n_v))))
@@ -56,14 +57,24 @@ def radon_bin(img, n_alpha, n_t, ix, iy):
     if not (u <= n_u and v <= n_v and u >= 0 and v >= 0) or t1 <= t:
         return f32(0)
     o0, o1 = f32(o0 + f32(0.5)), f32(o1 + f32(0.5))       # texel centres
-    o0, o1 = f32(o0 - f32(f32(0.5) * d1)), f32(o1 + f32(f32(0.5) * d0))  # + half a pixel along the normal
     s, so, step = f32(0), f32(0), f32(0.66)
+    if not derivative:
+        while t <= t1:
+            s = f32(s + tex(img, f32(o0 + f32(t * d0)), f32(o1 + f32(t * d1))))
+            t = f32(t + step)
+        return f32(s * step)
+    o0, o1 = f32(o0 - f32(f32(0.5) * d1)), f32(o1 + f32(f32(0.5) * d0))  # + half a pixel along the normal
     while t <= t1:
         x, y = f32(o0 + f32(t * d0)), f32(o1 + f32(t * d1))
         s = f32(s + tex(img, x, y))
         so = f32(so + tex(img, f32(x + d1), f32(y - d0)))  # the partner line, one pixel along -normal
         t = f32(t + step)
-    return f32(f32(s - so) * step)
+    r = f32(f32(s - so) * step)
+    if post == 1:
+        return f32(-np.sqrt(f32(-r))) if r < 0 else f32(np.sqrt(r))
+    if post == 2:
+        return f32(-f32(np.log(np.float64(f32(-r + f32(1)))))) if r < 0 else f32(np.log(np.float64(f32(r + f32(1)))))
+    return r
 
 
 def test_radon_bins_second_statement(oracle_mod):
@@ -79,6 +90,22 @@ def test_radon_bins_second_statement(oracle_mod):
             assert got == want[iy, ix], (ix, iy, got, want[iy, ix])
             nonzero += got != 0
         assert nonzero > 30
+
+
+def test_radon_variants_second_statement(oracle_mod):
+    """Filter::None (plain integrals) and the two post-processes of the derivative."""
+    rng = np.random.default_rng(8)
+    img = rng.uniform(0, 3, size=(37, 45)).astype(np.float32)
+    n_alpha, n_t = 24, 28
+    bins = [(int(a), int(t)) for a, t in zip(rng.integers(0, n_alpha, 40), rng.integers(0, n_t, 40))]
+    plain = oracle_mod.radon(img, n_alpha, n_t, filter=2)
+    root = oracle_mod.radon(img, n_alpha, n_t, filter=0, post=1)
+    logd = oracle_mod.radon(img, n_alpha, n_t, filter=0, post=2)
+    for ix, iy in bins:
+        assert radon_bin(img, n_alpha, n_t, ix, iy, derivative=False) == plain[iy, ix]
+        assert radon_bin(img, n_alpha, n_t, ix, iy, post=1) == root[iy, ix]
+        assert radon_bin(img, n_alpha, n_t, ix, iy, post=2) == logd[iy, ix]
+    assert np.count_nonzero(plain) > 100 and (root < 0).any() and (logd < 0).any()
 
 
 def pair_value(K0, K1, dtr0, dtr1, n_u, n_v):
