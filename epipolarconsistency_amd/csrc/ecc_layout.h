@@ -45,7 +45,7 @@ static inline int64_t ecc_layout_floats(int n_alpha, int n_t)
 // ---- Radon-intermediate kernel -------------------------------------------------------------
 struct EccRadonParams {
     const float* images;   // n_img * n_v * n_u floats (row-major, x fastest)
-    const float* imagesT;  // the same images transposed (n_u rows of n_v floats each), or null
+    const float* imagesT;  // the same images transposed (n_u rows of n_v floats each)
     float* out;            // n_img slabs in the private layout
     const float* trig;     // 2 * n_alpha floats: (sinf(alpha), cosf(alpha)), alpha = (ix/n_alpha - .5)*Pi
     int64_t image_stride;  // floats between images

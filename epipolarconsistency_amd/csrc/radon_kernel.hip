@@ -7,19 +7,32 @@
 // Every float expression keeps the reference's source order and is compiled without contraction,
 // so the result is bit-identical to oracle/ecc_oracle.c (or_radon_bin).
 //
-// What is different from the reference is the machine mapping:
-//   * no texture unit: the bilinear filter is the exact fp32 rule of SURVEY.md 8c, evaluated from
-//     an LDS tile (4 taps = 2 x ds_read2_b32) instead of 4 scattered global loads; built without the SLP
-//     vectoriser (build.py): v_pk_*_f32 pairs cost two issue slots each on gfx950 plus operand shuffles;
-//   * a workgroup owns RT_A = 16 adjacent angles x RT_T = 16 adjacent distances (256 threads).  Its lines are
-//     (nearly) parallel, so they sweep a narrow band of the image.  The band is walked in chunks
-//     along the line direction; for every chunk the axis-aligned bounding box of all sample
-//     footprints is staged into LDS with coalesced row reads (border replicated = clamp addressing),
-//     then every thread advances its own t-loop through the chunk.  Each thread still visits its
-//     samples in the reference's order, so sums are unchanged;
+// What is different from the reference is the machine mapping (no texture unit; the bilinear filter is the exact
+// fp32 rule of SURVEY.md 8c, evaluated from LDS):
+//   * a workgroup owns 16 adjacent angles x 16 adjacent distances (256 threads).  Its lines are nearly parallel, so
+//     they sweep a narrow band of the image.  The band is cut into SLABS across the image axis the lines run along
+//     (the "slow" axis s; the other one, closer to the line normal, is the "fast" axis f); every thread walks its
+//     own t-loop through the slab, so each bin still visits its samples in the reference's order;
+//   * the slab lives in LDS as TEXEL PAIRS: element (i, r) = {T(i, r), T(i+1, r)} (float2, clamp addressing
+//     resolved while staging), so one aligned ds_read_b64 fetches a footprint row: 2 x 2 LDS cycles per bilinear
+//     sample where 2 x ds_read2_b32 took 2 x 8 (the two angles that share a 32-lane group are 2-way conflicting
+//     in either form) -- the kernel is bound by vector-ALU issue instead of the LDS pipe;
+//   * the tile is a LINEAR array, address(i, r) = (r - R0) * S + (i - I0), with the row stride S a multiple of 32
+//     pairs (bank = i mod 32, whatever the row).  Row r only ever holds the S - 1 columns from
+//     ws(r) = floor(alpha + beta * r) on, beta = the band's slope df/ds: the window slides with the band, so a
+//     slab stores a parallelogram, not the band's bounding box, and S only has to cover the band's width ALONG f
+//     (64 ... 256, chosen per slab).  A slab is floor(5056 / (S + 1)) rows thick whatever the angle;
+//   * slab geometry is analytic (two corner angles x two corner distances of the workgroup) and identical in
+//     every thread: no reductions, no decisions through LDS.  It does not have to be trusted: every thread checks
+//     the two end points of its own run through the slab against the slab's admissible region (a convex set:
+//     two half-planes in the sheared coordinate f - beta*s, two in s) and samples from global memory when the
+//     check fails (weird proportions only, e.g. 5 angle bins for a 300-pixel image);
+//   * the next slab's texels are loaded into registers BEFORE the current slab is sampled and stored to LDS
+//     after it: two barriers per slab and no exposed global-memory latency;
+//   * the index conversion float -> LDS address is one fp32 add of 2^23 and a shift-add on the bits instead of
+//     v_cvt_i32_f32 (quarter rate);
 //   * sin/cos of the bin angle come from a host table (one entry per angle), not per thread;
-//   * output goes to the transposed, border-padded layout of ecc_layout.h (distance fastest), so
-//     the 32 lanes of a half-wave write one 128-B segment.
+//   * output goes to the transposed, border-padded layout of ecc_layout.h (distance fastest).
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <limits.h>
@@ -28,6 +41,7 @@
 #include "ecc_sampling.h"
 
 #ifdef ECC_RADON_STATS
+// 0: slabs, 1: LDS-path steps, 2: global-path steps inside slabs, 3: steps of the safety net, 4: sum of S, 5: sum of H
 __device__ unsigned long long g_radon_stats[8];
 #define RSTAT(i, v) atomicAdd(&g_radon_stats[i], (unsigned long long)(v))
 #else
@@ -36,68 +50,22 @@ __device__ unsigned long long g_radon_stats[8];
 
 namespace {
 
-#ifndef RT_DIST_BINS
-#define RT_DIST_BINS 16
-#endif
-#ifndef RT_WG_THREADS
-#define RT_WG_THREADS 256
-#endif
-constexpr int RT_T = RT_DIST_BINS;                  // distance bins per workgroup (tid % RT_T)
-constexpr int RT_A = RT_WG_THREADS / RT_DIST_BINS;  // angle bins per workgroup    (tid / RT_T)
-constexpr int RT_THREADS = RT_T * RT_A;             // 256 (512 only in experiments)
+constexpr int RT_T = 16;                   // distance bins per workgroup
+constexpr int RT_A = 16;                   // angle bins per workgroup
+constexpr int RT_THREADS = RT_T * RT_A;    // 256
 constexpr int RT_WAVES = RT_THREADS / 64;
-constexpr int RT_STAGE_ROWS = RT_THREADS / 32;      // tile rows staged per pass (32 texels per row segment)
-// Tile shape: 96 x 96 floats (37 KB, 4 workgroups per CU) measured best; -DRT_TILE_W/H only for experiments
-// (scripts/radon_variants.sh: 64x64 0.97 ms, 96x80 0.79 ms, 96x96 0.76 ms per 1024^2 image).
-#ifndef RT_TILE_W
-#define RT_TILE_W 96
-#endif
-#ifndef RT_TILE_H
-#define RT_TILE_H 96
-#endif
-constexpr int TILE_W = RT_TILE_W;          // usable LDS tile width (texels)
-constexpr int TILE_H = RT_TILE_H;          // LDS tile rows
-constexpr int TILE_S_MAX = TILE_W + 1;     // row stride is TILE_W+1 or TILE_W-1 floats (odd, see radon_kernel)
+constexpr int TILE_CAP = 5056;             // texel pairs per workgroup: 40 448 B, four workgroups per CU
+constexpr int N_PRE = 26;                  // texels a thread stages per slab (registers that live across the sampling loop)
+static_assert(N_PRE <= 32, "stage_regs is a 32-float vector");
+constexpr int S_MIN = 64, S_MAX = 256;     // row stride of the tile in pairs (multiples of 32)
 constexpr float RADON_STEP = .66f;         // ref: RadonIntermediate.cu:102
-constexpr int MAX_CHUNKS = 8192;           // bound on the chunk loop (every spin is bounded)
+constexpr int MAX_SLABS = 8192;            // bound on the slab loop (every loop is bounded)
+constexpr float MAGIC = 8388608.f;         // 2^23: as_uint(k + 2^23) = 0x4B000000 + k for integers 0 <= k < 2^23
 
-// Exact fp32 bilinear rule on global memory with clamp addressing (ecc_sampling.h); slow path used
-// only when a chunk's footprint cannot be made to fit the LDS tile.
-__device__ __forceinline__ float tex_global(const float* __restrict__ img, int W, int H, float x, float y)
-{
-    return ecc_tex_global(img, W, H, x, y);
-}
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2f lds_v2f;
+typedef float stage_regs __attribute__((ext_vector_type(32)));  // a vector value, not an array: never addressed, so never in scratch
 
-// Same rule on the staged tile.  tile_off = by0*TILE_S + bx0 (tile origin in image texels); the
-// tile already holds clamped (replicated) texels, so taps need no index clamps.
-// TRANSP: the tile holds the image transposed (image y is the tile's fast axis; staged from a transposed copy of the image).
-template <int TILE_S, bool TRANSP>
-__device__ __forceinline__ float tex_lds(const float* tile_shifted, float x, float y)
-{
-    float xb = x - 0.5f, yb = y - 0.5f;
-    float fi = floorf(xb), fj = floorf(yb);
-    float fx = xb - fi, fy = yb - fj;
-    // fj*TILE_S + fi is an exact small integer in fp32 (|.| < 2^24) whether or not it is fused;
-    // tile_shifted = tile - tile_off folds the tile origin into the base (one v_lshl_add per sample).
-    // (an explicit fma: the build runs with -ffp-contract=off, and product and sum are exact integers either way)
-    const float* tp = tile_shifted + (TRANSP ? (int)__builtin_fmaf(fi, (float)TILE_S, fj) : (int)__builtin_fmaf(fj, (float)TILE_S, fi));
-    float T00 = tp[0], T10 = tp[TRANSP ? TILE_S : 1];
-    float T01 = tp[TRANSP ? 1 : TILE_S], T11 = tp[TILE_S + 1];
-    float r0 = (1.f - fx) * T00 + fx * T10;
-    float r1 = (1.f - fx) * T01 + fx * T11;
-    return (1.f - fy) * r0 + fy * r1;
-}
-
-__device__ __forceinline__ int wave_min_i(int v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
 __device__ __forceinline__ float wave_min_f(float v)
 {
     for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
@@ -110,34 +78,193 @@ __device__ __forceinline__ float wave_max_f(float v)
 }
 
 struct RadonShared {
-    float tile[TILE_S_MAX * TILE_H];
-    int box[RT_WAVES][4];    // per wave: min x, min y, max x, max y
-    float u[RT_WAVES][2];    // per wave: min/max of the along-line coordinate
-    float geo[6];
-    int pend[RT_WAVES];
+    float2 tile[TILE_CAP];
+    float srange[RT_WAVES][2];
 };
 
-// TILE_S is the LDS row stride.  A half-wave is 16 adjacent distance bins x 2 adjacent angles, i.e.
-// sample points spaced 1.9 px along the line NORMAL (nx, ny).  ds_read2_b32 banks are
-// (j*TILE_S + i) mod 32: with stride 97 the bank advances by 1.9 (nx + ny) per lane, with 95 by
-// 1.9 (nx - ny); the kernel picks the one with the larger advance, so a half-wave never walks along an
-// iso-bank direction.  Measured (profiles/): the LDS pipe is busy ~90 % of the kernel time and bank
-// conflicts are ~55 % of those cycles -- 32 lanes spread over >= 30 px of a line cannot all land on distinct
-// banks of a linear layout.  Tried and rejected: a float2 "texel pair" tile read with ds_read_b64 (256 B/clk,
-// 64 banks) halves the LDS cycles but doubles the tile to 74 KB = 2 workgroups per CU, and this kernel needs
-// >= 4 waves per SIMD to keep the VALU fed (2 WG/CU: 0.96 ms with the plain tile, 1.12 ms with pairs).
-template <bool DERIV, int TILE_S, bool TRANSP = false>
+// The workgroup's band, in (f, s) coordinates (all values identical in every thread).
+// A sample of the line with normal (l0, l1) and offset c (position = c * normal + (.5, .5) + t * direction) at slow
+// coordinate s has fast coordinate f = .5 + (s - .5) * m + c / lf, with lf the normal's f-component and m = -ls / lf.
+struct Band {
+    float beta, abs_beta;  // slope df/ds the row windows follow (middle angle, clamped to [-1, 1])
+    int bstep;             // beta in 1/65536 columns per row: the row windows are placed by integer arithmetic
+    float sigma;           // +1: s grows with t, -1: s falls
+    float mk[2];           // m - beta of the first / last angle
+    float g0[2];           // .5 - .5 m
+    float cl[2], ch[2];    // c / lf at the workgroup's smallest / largest offset (either order)
+    float marg;            // allowance for the angles in between and for rounding
+};
+
+struct SlabPlan {
+    int R0, H, S, I0;      // first staged row, rows, row stride (pairs), column of address 0
+    int acc0;              // row window of tile row rr: ws = (acc0 + rr * bstep) >> 16 = floor(alpha + beta * (R0 + rr)) up to
+                           // 1e-3 columns, S - 1 elements from there
+    float Glo, Ghi;        // admissible f - beta * s of a sample
+    float slo, shi;        // admissible s of a sample
+    float b_next;          // samples with s up to b_next (in walking order) belong to this slab
+};
+
+// values every lane computes identically, moved to scalar registers (branches on them become scalar branches)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Rows of a slab by k = S / 32: the linear tile needs H * (S + 1) pairs (the row windows slide by up to one column per
+// row); wave w stages rows w, w + 4, ..., a row in ceil(S / 64) loads of 64 consecutive texels, N_PRE registers in all.
+constexpr int slab_rows_of(int k)
+{
+    return (TILE_CAP / (32 * k + 1)) < RT_WAVES * (N_PRE / ((k + 1) / 2)) ? (TILE_CAP / (32 * k + 1)) : RT_WAVES * (N_PRE / ((k + 1) / 2));
+}
+constexpr unsigned long long SLAB_ROWS_PACKED = (unsigned long long)slab_rows_of(2) | ((unsigned long long)slab_rows_of(3) << 8) |
+                                                ((unsigned long long)slab_rows_of(4) << 16) | ((unsigned long long)slab_rows_of(5) << 24) |
+                                                ((unsigned long long)slab_rows_of(6) << 32) | ((unsigned long long)slab_rows_of(7) << 40) |
+                                                ((unsigned long long)slab_rows_of(8) << 48);
+__device__ __forceinline__ int slab_rows(int k) { return (int)((SLAB_ROWS_PACKED >> (8 * (k - 2))) & 255ull); }
+static_assert(S_MIN == 64 && S_MAX == 256 && slab_rows_of(2) < 256, "slab_rows covers k = 2 .. 8");
+
+// Slab that starts at slow coordinate b (walking order).  Every thread computes the same plan.
+__device__ __forceinline__ SlabPlan plan_slab(const Band& bd, float b)
+{
+    SlabPlan sp;
+    constexpr int HMAX = slab_rows_of(S_MIN / 32);
+    const float span = (float)(HMAX - 5);
+    const float sa = (bd.sigma > 0.f ? b : b - span) - 1.f, sb = sa + span + 2.f;
+    float gmin = FLT_MAX, gmax = -FLT_MAX;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float u0 = bd.mk[e] * sa, u1 = bd.mk[e] * sb;
+        gmin = fminf(gmin, bd.g0[e] + fminf(u0, u1) + fminf(bd.cl[e], bd.ch[e]));
+        gmax = fmaxf(gmax, bd.g0[e] + fmaxf(u0, u1) + fmaxf(bd.cl[e], bd.ch[e]));
+    }
+    const float need = (gmax - gmin) + 2.f * bd.marg + 2.f + 3.f * bd.abs_beta + .25f;
+    const int S = uni(min(max(((int)ceilf(fminf(need, 4096.f)) + 31) & ~31, S_MIN), S_MAX));
+    const int H = slab_rows(S >> 5);
+    const float delta = (float)(H - 5);
+    const float slack = (float)S - need;  // negative: the band does not fit, the per-thread checks decide
+    sp.S = S;
+    sp.H = H;
+    const float alpha = gmin - bd.marg - .5f - 1.5f * bd.abs_beta - .125f - .5f * slack;
+    sp.Glo = alpha + .5f + 1.5f * bd.abs_beta + .03f;
+    sp.Ghi = alpha + (float)S - 1.5f - 1.5f * bd.abs_beta - .03f;
+    const float lo = bd.sigma > 0.f ? b : b - delta;
+    sp.R0 = uni((int)floorf(lo - 1.75f));
+    sp.slo = (float)sp.R0 + .51f;
+    sp.shi = (float)(sp.R0 + H) - .51f;
+    sp.b_next = uni(b + bd.sigma * delta);
+    sp.acc0 = uni((int)floorf(__builtin_fmaf(bd.beta, (float)sp.R0, alpha) * 65536.f));
+    sp.I0 = min(sp.acc0 >> 16, (sp.acc0 + (H - 1) * bd.bstep) >> 16);
+    return sp;
+}
+
+// Staging, first half: this thread's texels of the slab into registers.  Wave w owns rows w, w + 4, ...; a row is
+// K = ceil(S / 64) loads of 64 consecutive texels (256 contiguous bytes per load); register j * K + seg holds load seg of
+// the wave's j-th row.  Everything but the lane's column is wave-uniform and stays in scalar registers.  src is the
+// image with f as its fast axis (the image itself, or its transposed copy), Nf x Ns texels.
+// rows a wave stages when a row takes K loads: ceil(rows of the smallest such stride / 4)
+constexpr int stage_rows_of(int K) { return (slab_rows_of(K == 1 ? 2 : 2 * K - 1) + RT_WAVES - 1) / RT_WAVES; }
+static_assert(stage_rows_of(1) * 1 <= N_PRE && stage_rows_of(2) * 2 <= N_PRE && stage_rows_of(3) * 3 <= N_PRE && stage_rows_of(4) * 4 <= N_PRE, "N_PRE");
+
+template <int K>
+__device__ __forceinline__ void stage_load_k(const SlabPlan& sp, int bstep, const float* __restrict__ src, int Nf, int Ns,
+                                             stage_regs& reg)
+{
+    const int w = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int acc = sp.acc0 + w * bstep, r = sp.R0 + w;  // uniform
+#pragma unroll
+    for (int j = 0; j < stage_rows_of(K); ++j) {
+        // rows past the slab's last one (and columns past a row's window) are loaded and never stored
+        const int rowoff = min(max(r, 0), Ns - 1) * Nf;
+        const int col0 = (acc >> 16) + lane;
+#pragma unroll
+        for (int seg = 0; seg < K; ++seg) {
+            const int ic = min(max(col0 + seg * 64, 0), Nf - 1);
+            reg[j * K + seg] = src[(unsigned)(rowoff + ic)];
+        }
+        acc += RT_WAVES * bstep;
+        r += RT_WAVES;
+    }
+}
+
+// Staging, second half: texel c of a row is the .x of pair c and the .y of pair c - 1; texel S - 1 has no pair of its
+// own (the next row's window may start one column earlier), texel 0 no left neighbour.
+template <int K>
+__device__ __forceinline__ void stage_store_k(const SlabPlan& sp, int bstep, unsigned tile_addr, const stage_regs& reg)
+{
+    typedef __attribute__((address_space(3))) float lds_float;
+    const int w = uni((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    int acc = sp.acc0 + w * bstep, rr = w;  // uniform
+    const unsigned lane8 = 8u * (unsigned)lane;
+    const int last = sp.S - 64 * (K - 1);  // columns of the row's last load
+#pragma unroll
+    for (int j = 0; j < stage_rows_of(K); ++j) {
+        if (rr < sp.H) {
+            // byte address of the .y of pair (c - 1) for this lane's c of load 0
+            const unsigned a = tile_addr + 8u * (unsigned)(rr * sp.S + ((acc >> 16) - sp.I0)) - 4u + lane8;
+#pragma unroll
+            for (int seg = 0; seg < K; ++seg) {
+                const float v = reg[j * K + seg];
+                const bool px = seg < K - 1 || lane < last - 1;  // c < S - 1
+                const bool py = (seg > 0 || lane > 0) && (seg < K - 1 || lane < last);  // 0 < c < S
+                if (px) *(lds_float*)(size_t)(a + 512u * seg + 4u) = v;
+                if (py) *(lds_float*)(size_t)(a + 512u * seg) = v;
+            }
+        }
+        acc += RT_WAVES * bstep;
+        rr += RT_WAVES;
+    }
+}
+
+__device__ __forceinline__ void stage_load(const SlabPlan& sp, int bstep, const float* __restrict__ src, int Nf, int Ns,
+                                           stage_regs& reg)
+{
+    switch ((sp.S + 63) >> 6) {  // uniform
+    case 1: stage_load_k<1>(sp, bstep, src, Nf, Ns, reg); break;
+    case 2: stage_load_k<2>(sp, bstep, src, Nf, Ns, reg); break;
+    case 3: stage_load_k<3>(sp, bstep, src, Nf, Ns, reg); break;
+    default: stage_load_k<4>(sp, bstep, src, Nf, Ns, reg); break;
+    }
+}
+__device__ __forceinline__ void stage_store(const SlabPlan& sp, int bstep, unsigned tile_addr, const stage_regs& reg)
+{
+    switch ((sp.S + 63) >> 6) {
+    case 1: stage_store_k<1>(sp, bstep, tile_addr, reg); break;
+    case 2: stage_store_k<2>(sp, bstep, tile_addr, reg); break;
+    case 3: stage_store_k<3>(sp, bstep, tile_addr, reg); break;
+    default: stage_store_k<4>(sp, bstep, tile_addr, reg); break;
+    }
+}
+static_assert(S_MAX <= 256, "stage_load / stage_store dispatch on ceil(S / 64) = 1 .. 4");
+
+// The exact bilinear rule (ecc_sampling.h) on the pair tile.  base = LDS byte address of the tile, minus
+// 8 * (R0 * S + I0) (tile origin), minus (0x4B000000 << 3) (the 2^23 trick), all modulo 2^32.
+// TRANSP: f is the image's y axis: pair (j, i) = {T(i, j), T(i, j+1)}, the next row is i + 1.
+template <bool TRANSP>
+__device__ __forceinline__ float tex_pairs(unsigned base, float Sf, unsigned S8, float x, float y)
+{
+    float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float fx = xb - fi, fy = yb - fj;
+    // row * S + column: an exact small non-negative integer in fp32 whether or not it is fused (an explicit fma: the
+    // build runs with -ffp-contract=off); adding 2^23 leaves it in the low mantissa bits
+    const float idx = TRANSP ? __builtin_fmaf(fi, Sf, fj) : __builtin_fmaf(fj, Sf, fi);
+    const unsigned a0 = (__float_as_uint(idx + MAGIC) << 3) + base;
+    const unsigned a1 = a0 + S8;  // a run-time stride: two ds_read_b64 (256 B/clk each), never one ds_read2_b64 (128 B/clk)
+    const v2f pa = *(const lds_v2f*)(size_t)a0;
+    const v2f pb = *(const lds_v2f*)(size_t)a1;
+    const float T00 = pa.x, T10 = TRANSP ? pb.x : pa.y;
+    const float T01 = TRANSP ? pa.y : pb.x, T11 = pb.y;
+    float r0 = (1.f - fx) * T00 + fx * T10;
+    float r1 = (1.f - fx) * T01 + fx * T11;
+    return (1.f - fy) * r0 + fy * r1;
+}
+
+template <bool DERIV, bool TRANSP>
 __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared& sh)
 {
-    float* tile = sh.tile;
-    auto& s_box = sh.box;
-    auto& s_u = sh.u;
-    auto& s_pend = sh.pend;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int ix = blockIdx.x * RT_A + (tid / RT_T);
-    const int iy = blockIdx.y * RT_T + (tid % RT_T);
+    // a 32-lane group (what an LDS read is serviced in) is 16 adjacent distances x 2 adjacent angles
+    const int ix = blockIdx.x * RT_A + ((tid >> 4) & (RT_A - 1));
+    const int iy = blockIdx.y * RT_T + (tid & 15);
     const float* __restrict__ img = p.images + (int64_t)blockIdx.z * p.image_stride;
     const int W = p.n_u, H = p.n_v;
     const float n_u = (float)W, n_v = (float)H;
@@ -183,185 +310,137 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, RadonShared&
         }
     }
 
-    // ---- chunking coordinate: position along the line direction relative to the image centre ----
-    const float tc = (0.5f * n_u) * d0 + (0.5f * n_v) * d1;
+    // ---- the workgroup's band (identical in every thread) ----
+    const int Nf = TRANSP ? H : W, Ns = TRANSP ? W : H;
+    const float* __restrict__ src = TRANSP ? (p.imagesT + (int64_t)blockIdx.z * p.image_stride) : img;
+    const int ixA = blockIdx.x * RT_A, ixB = min(ixA + RT_A - 1, p.n_alpha - 1), ixM = (ixA + ixB) >> 1;
+    const int iyA = blockIdx.y * RT_T, iyB = min(iyA + RT_T - 1, p.n_t - 1);
+    Band bd;
     {
-        float umin = active ? t - tc : FLT_MAX;
-        float umax = active ? t_max - tc : -FLT_MAX;
-        umin = wave_min_f(umin);
-        umax = wave_max_f(umax);
+        const float lfM = TRANSP ? p.trig[2 * ixM + 1] : -p.trig[2 * ixM];
+        const float lsM = TRANSP ? -p.trig[2 * ixM] : p.trig[2 * ixM + 1];
+        // direction (d0, d1) = (l1, -l0): its s-component is -l0 (plain) or l1 (transposed)
+        const float dsM = TRANSP ? lfM : -lfM;
+        bd.sigma = dsM >= 0.f ? 1.f : -1.f;
+        bd.beta = uni(fminf(fmaxf(-lsM / lfM, -1.f), 1.f));
+        bd.abs_beta = fabsf(bd.beta);
+        bd.bstep = uni((int)rintf(bd.beta * 65536.f));
+        const float tauA = ((float)iyA / (float)p.n_t - 0.5f) * diag, tauB = ((float)iyB / (float)p.n_t - 0.5f) * diag;
+        const float Pi = 3.14159265359f;
+        const float da = (float)(ixB - ixA) * (Pi / (float)p.n_alpha);
+        bd.marg = uni(.75f + .6f * diag * da * da);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ixe = e ? ixB : ixA;
+            const float l0 = -p.trig[2 * ixe], l1 = p.trig[2 * ixe + 1];
+            const float lf = TRANSP ? l1 : l0, ls = TRANSP ? l0 : l1;
+            const float inv = 1.f / lf, m = -ls * inv;
+            const float kc = 0.5f * n_u * l0 + 0.5f * n_v * l1;
+            bd.mk[e] = uni(m - bd.beta);
+            bd.g0[e] = uni(.5f - .5f * m);
+            bd.cl[e] = uni((tauA + kc - .5f) * inv);
+            bd.ch[e] = uni((tauB + kc + .5f) * inv);
+        }
+    }
+
+    // ---- this thread in (f, s) coordinates ----
+    const float of = TRANSP ? o1 : o0, os = TRANSP ? o0 : o1;
+    const float df = TRANSP ? d1 : d0, ds = TRANSP ? d0 : d1;
+    const float ef = TRANSP ? -d0 : d1, es = TRANSP ? d1 : -d0;  // second sample of the derivative pair: (x + d1, y - d0)
+    // threads whose line does not run with the band (few angle bins for the image size) never use the tile
+    const bool with_band = active && ds * bd.sigma > .3f;
+    const float inv_ds = with_band ? 1.f / ds : 0.f;
+
+    // ---- extent of the workgroup's samples along s ----
+    {
+        const float sA = os + t * ds, sB = os + t_max * ds;
+        float smin = with_band ? fminf(sA, sB) : FLT_MAX;
+        float smax = with_band ? fmaxf(sA, sB) : -FLT_MAX;
+        smin = wave_min_f(smin);
+        smax = wave_max_f(smax);
         if (lane == 0) {
-            s_u[wave][0] = umin;
-            s_u[wave][1] = umax;
+            sh.srange[wave][0] = smin;
+            sh.srange[wave][1] = smax;
         }
     }
     __syncthreads();
-    float U0 = s_u[0][0], U1 = s_u[0][1];
+    float s_first = sh.srange[0][0], s_last = sh.srange[0][1];
 #pragma unroll
     for (int q = 1; q < RT_WAVES; ++q) {
-        U0 = fminf(U0, s_u[q][0]);
-        U1 = fmaxf(U1, s_u[q][1]);
+        s_first = fminf(s_first, sh.srange[q][0]);
+        s_last = fmaxf(s_last, sh.srange[q][1]);
     }
-    if (tid == 0) {
-        // Geometry of this workgroup's band for the chunk-length rule below (uniform via LDS).
-        const float Pi = 3.14159265359f;
-        const float dtau = diag / (float)p.n_t;
-        const int iy0 = blockIdx.y * RT_T;
-        const float tau_a = fabsf(((float)iy0 / (float)p.n_t - 0.5f) * diag);
-        const float tau_b = fabsf(((float)(iy0 + RT_T - 1) / (float)p.n_t - 0.5f) * diag);
-        sh.geo[0] = fabsf(d0);                                    // |cos| of the line direction
-        sh.geo[1] = fabsf(d1);                                    // |sin|
-        sh.geo[2] = (RT_T - 1) * dtau + 2.f;                      // band across the lines (+ derivative pair)
-        sh.geo[3] = (RT_A - 1) * (Pi / (float)p.n_alpha);         // angular spread of the workgroup
-        sh.geo[4] = fmaxf(tau_a, tau_b);                          // largest |distance to centre|
-        sh.geo[5] = fmaxf(fabsf(U0), fabsf(U1));                  // largest |along-line coordinate|
-    }
-    __syncthreads();
-    const float g_cs = sh.geo[0], g_sn = sh.geo[1], g_band = sh.geo[2], g_spread = sh.geo[3];
-    const float g_tau = sh.geo[4], g_far = sh.geo[5];
+    s_first = uni(s_first);
+    s_last = uni(s_last);
 
     float sum = 0.f, sumo = 0.f;
-    float U = U0;
-    for (int it = 0; it < MAX_CHUNKS; ++it) {
-        // Chunk length L: the chunk covers along-line coordinates [U, U+L) of every line of the workgroup.
-        // Seen from the image centre the 8 angles rotate the (L x band) rectangle by up to `spread`, which
-        // widens it by spread*|u| across the lines and lengthens it by spread*|tau| along them; L is the
-        // largest length whose axis-aligned bounding box still fits the LDS tile (identical in all threads).
-        const float reach = fminf(g_far, fabsf(U) + (float)TILE_W);
-        const float band = g_band + g_spread * reach;
-        const float slack = g_spread * g_tau;
-        const float Lw = g_cs > 1e-3f ? ((float)(TILE_W - 3) - band * g_sn) / g_cs : 1e9f;
-        const float Lh = g_sn > 1e-3f ? ((float)(TILE_H - 3) - band * g_cs) / g_sn : 1e9f;
-        float L = fminf(fmaxf(fminf(Lw, Lh) - slack, 4.f), 4096.f);
-        const bool pending = active && (t <= t_max);  // samples left at all
-        const unsigned long long pend = __ballot(pending);
-        // The rule above is an estimate; the exact footprint decides.  If it does not fit, the chunk is halved
-        // (uniform decision, at most 4 times) rather than sampled from global memory, which costs ~200x per
-        // sample.
-        float lim;
-        bool has, fits, any;
-        int bx0, by0, bx1, by1, w, h;
-        for (int attempt = 0;; ++attempt) {
-            lim = (U + L) + tc;
-            has = pending && (t < lim);  // samples inside this chunk
-            bx0 = INT_MAX, by0 = INT_MAX, bx1 = INT_MIN, by1 = INT_MIN;
-            if (has) {
-                // Samples run over t in [t, min(t_max, pred(lim))]; fp32 o + t*d is monotone in t, so the two end
-                // points bound every sample exactly and the texels needed are floor(. - 0.5) of those bounds and
-                // their +1 neighbours.
-                float tb = fminf(t_max, lim);
-                float xa = o0 + t * d0, ya = o1 + t * d1;
-                float xb = o0 + tb * d0, yb = o1 + tb * d1;
-                float xmin = fminf(xa, xb), xmax = fmaxf(xa, xb);
-                float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
-                if (DERIV) {
-                    xmin = fminf(xmin, xmin + d1);
-                    xmax = fmaxf(xmax, xmax + d1);
-                    ymin = fminf(ymin, ymin - d0);
-                    ymax = fmaxf(ymax, ymax - d0);
-                }
-                bx0 = (int)floorf(xmin - 0.5f);
-                bx1 = (int)floorf(xmax - 0.5f) + 1;
-                by0 = (int)floorf(ymin - 0.5f);
-                by1 = (int)floorf(ymax - 0.5f) + 1;
+    if (s_first <= s_last) {  // uniform: somebody samples from slabs
+        const unsigned tile_addr = (unsigned)(size_t)(lds_v2f*)sh.tile;
+        const float b_end = bd.sigma > 0.f ? s_last : s_first;
+        stage_regs reg = {};
+        SlabPlan nxt = plan_slab(bd, bd.sigma > 0.f ? s_first - .01f : s_last + .01f);
+        stage_load(nxt, bd.bstep, src, Nf, Ns, reg);
+        for (int it = 0; it < MAX_SLABS; ++it) {
+            __syncthreads();  // everybody has left the tile
+            stage_store(nxt, bd.bstep, tile_addr, reg);
+            __syncthreads();  // slab complete
+            const SlabPlan cur = nxt;
+            const bool more = bd.sigma > 0.f ? cur.b_next <= b_end : cur.b_next >= b_end;  // uniform
+            if (more) {
+                nxt = plan_slab(bd, cur.b_next);
+                stage_load(nxt, bd.bstep, src, Nf, Ns, reg);  // in flight while this slab is sampled
             }
-            bx0 = wave_min_i(bx0);
-            by0 = wave_min_i(by0);
-            bx1 = wave_max_i(bx1);
-            by1 = wave_max_i(by1);
-            if (lane == 0) {
-                s_box[wave][0] = bx0;
-                s_box[wave][1] = by0;
-                s_box[wave][2] = bx1;
-                s_box[wave][3] = by1;
-                s_pend[wave] = pend != 0ull;
-            }
-            __syncthreads();  // (A) boxes visible; every thread has left the previous chunk's tile
-            bx0 = s_box[0][0], by0 = s_box[0][1], bx1 = s_box[0][2], by1 = s_box[0][3];
+            if (tid == 0) { RSTAT(0, 1); RSTAT(4, cur.S); RSTAT(5, cur.H); }
+            // samples of this slab: t <= lim (any monotone sequence of limits partitions the samples)
+            const float t_end = fminf(t_max, (cur.b_next - os) * inv_ds);
+            if (with_band && t <= t_end) {
+                // Both end points of the run inside the slab's admissible region => every sample's footprint is in the
+                // tile (the region is convex and positions are linear in t; .03 / .01 px cover the fp32 rounding of
+                // o + t * d).  f, s >= .5 keeps the tile index non-negative.
+                bool ok = true;
 #pragma unroll
-            for (int q = 1; q < RT_WAVES; ++q) {
-                bx0 = min(bx0, s_box[q][0]);
-                by0 = min(by0, s_box[q][1]);
-                bx1 = max(bx1, s_box[q][2]);
-                by1 = max(by1, s_box[q][3]);
+                for (int e = 0; e < 2; ++e) {
+                    const float te = e ? t_end : t;
+                    float f = of + te * df, s = os + te * ds;
+                    float g = f - bd.beta * s;
+                    ok = ok && g >= cur.Glo && g <= cur.Ghi && s >= cur.slo && s <= cur.shi && f >= .5f && s >= .5f;
+                    if (DERIV) {
+                        f += ef;
+                        s += es;
+                        g = f - bd.beta * s;
+                        ok = ok && g >= cur.Glo && g <= cur.Ghi && s >= cur.slo && s <= cur.shi && f >= .5f && s >= .5f;
+                    }
+                }
+                if (ok) {
+                    const float Sf = (float)cur.S;
+                    const unsigned S8 = 8u * (unsigned)cur.S;
+                    const unsigned base = tile_addr - 8u * (unsigned)(cur.R0 * cur.S + cur.I0) - (0x4B000000u << 3);
+                    // ref: RadonIntermediate.cu:105-123 (t += step accumulates in fp32)
+                    for (; t <= t_end; t += RADON_STEP) {
+                        RSTAT(1, 1);
+                        float x = o0 + t * d0, y = o1 + t * d1;
+                        sum += tex_pairs<TRANSP>(base, Sf, S8, x, y);
+                        if (DERIV) sumo += tex_pairs<TRANSP>(base, Sf, S8, x + d1, y - d0);
+                    }
+                } else {
+                    for (; t <= t_end; t += RADON_STEP) {
+                        RSTAT(2, 1);
+                        float x = o0 + t * d0, y = o1 + t * d1;
+                        sum += ecc_tex_global(img, W, H, x, y);
+                        if (DERIV) sumo += ecc_tex_global(img, W, H, x + d1, y - d0);
+                    }
+                }
             }
-            any = bx1 >= bx0;
-            w = bx1 - bx0 + 1, h = by1 - by0 + 1;
-            fits = any && (TRANSP ? (h <= (TILE_S < TILE_W ? TILE_S : TILE_W) && w <= TILE_H)
-                                  : (w <= (TILE_S < TILE_W ? TILE_S : TILE_W) && h <= TILE_H));
-            if (fits || !any || attempt == 4) break;
-            L *= 0.5f;
-            __syncthreads();  // everyone has read s_box before it is rewritten
+            if (!more) break;
         }
-        int any_pending = 0;
-#pragma unroll
-        for (int q = 0; q < RT_WAVES; ++q) any_pending |= s_pend[q];
-        if (!any_pending) break;  // uniform: all lines done
-        if (tid == 0) { RSTAT(0, 1); RSTAT(1, fits ? 1 : 0); RSTAT(2, any ? 1 : 0); RSTAT(5, w > 0 ? w : 0); RSTAT(6, h > 0 ? h : 0); }
-        if (fits) {
-            // Stage the footprint: all of a thread's (up to 36) global loads are issued before the first
-            // LDS store so their latencies overlap (a load -> store loop serialises one L2 round trip per
-            // element).  Rows by wave-quarter, 32 consecutive texels per half-wave = one 128-B segment.
-            // TRANSP: the same with the roles of x and y exchanged, reading the transposed copy of the image (rows of
-            // length H), so the loads stay coalesced and the LDS stores conflict-free.
-            const int cx = tid & 31, ry = tid >> 5;
-            const int fast0 = TRANSP ? by0 : bx0, slow0 = TRANSP ? bx0 : by0;
-            const int nfast = TRANSP ? h : w, nslow = TRANSP ? w : h;
-            const int Wf = TRANSP ? H : W, Hs = TRANSP ? W : H;
-            const float* __restrict__ src = TRANSP ? p.imagesT + (int64_t)blockIdx.z * p.image_stride : img;
-            float stage[(TILE_H / RT_STAGE_ROWS) * (TILE_W / 32)];
-#pragma unroll
-            for (int q = 0; q < TILE_H / RT_STAGE_ROWS; ++q) {
-                const int r = ry + RT_STAGE_ROWS * q;
-                const int gs = min(max(slow0 + r, 0), Hs - 1);
-                const float* __restrict__ row = src + (size_t)gs * Wf;
-#pragma unroll
-                for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
-                    const int c = cx + 32 * c3;
-                    const int gf = min(max(fast0 + c, 0), Wf - 1);
-                    stage[q * (TILE_W / 32) + c3] = (r < nslow && c < nfast) ? row[gf] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < TILE_H / RT_STAGE_ROWS; ++q) {
-                const int r = ry + RT_STAGE_ROWS * q;
-#pragma unroll
-                for (int c3 = 0; c3 < TILE_W / 32; ++c3) {
-                    const int c = cx + 32 * c3;
-                    if (r < nslow && c < nfast) tile[r * TILE_S + c] = stage[q * (TILE_W / 32) + c3];
-                }
-            }
-        }
-        __syncthreads();  // (B) tile complete; s_box/s_pend may be rewritten by the next chunk
-        if (has) {
-            if (fits) {
-                const float* tile_shifted = tile - (TRANSP ? (bx0 * TILE_S + by0) : (by0 * TILE_S + bx0));
-                // t <= t_max && t < lim  <=>  t <= min(t_max, pred(lim)): one compare per step
-                const float t_end = fminf(t_max, nextafterf(lim, -FLT_MAX));
-                // ref: RadonIntermediate.cu:105-123 (t += step accumulates in fp32)
-                for (; t <= t_end; t += RADON_STEP) {
-                    RSTAT(4, 1);
-                    float x = o0 + t * d0, y = o1 + t * d1;
-                    sum += tex_lds<TILE_S, TRANSP>(tile_shifted, x, y);
-                    if (DERIV) sumo += tex_lds<TILE_S, TRANSP>(tile_shifted, x + d1, y - d0);
-                }
-            } else {
-                for (; t <= t_max && t < lim; t += RADON_STEP) {
-                    RSTAT(3, 1);
-                    float x = o0 + t * d0, y = o1 + t * d1;
-                    sum += tex_global(img, W, H, x, y);
-                    if (DERIV) sumo += tex_global(img, W, H, x + d1, y - d0);
-                }
-            }
-        }
-        U += L;
     }
-    // Safety net (never taken for sane sizes): finish whatever MAX_CHUNKS did not cover.
+    // Whatever the slabs did not cover: lines that do not run with the band, and the bound on the slab loop.
     if (active)
         for (; t <= t_max; t += RADON_STEP) {
+            RSTAT(3, 1);
             float x = o0 + t * d0, y = o1 + t * d1;
-            sum += tex_global(img, W, H, x, y);
-            if (DERIV) sumo += tex_global(img, W, H, x + d1, y - d0);
+            sum += ecc_tex_global(img, W, H, x, y);
+            if (DERIV) sumo += ecc_tex_global(img, W, H, x + d1, y - d0);
         }
 
     if (in_range) {
@@ -383,33 +462,18 @@ template <bool DERIV>
 __global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
 {
     __shared__ RadonShared sh;
-    // line normal of this workgroup's first angle: (nx, ny) = (-sin a, cos a)
-    const int ix0 = min((int)blockIdx.x * RT_A, p.n_alpha - 1);
-    const float nx = -p.trig[2 * ix0], ny = p.trig[2 * ix0 + 1];
-    // Row stride.  A half-wave is two "combs" (two adjacent angles) of 16 points spaced 1.9 px along the line normal; the
-    // two combs nearly coincide, so any bank function gives at least a 2-way conflict between them (simulation:
-    // scripts/analysis/radon_lds_layouts.py).  With stride 96 the bank is the texel's index along the tile's fast axis
-    // alone: a comb whose normal is closer to that axis than to the other advances >= 1.33 banks per lane over < 32 banks,
-    // conflict-free in itself, and the pass costs exactly two cycles.  So: normal closer to x -> plain tile, stride 96;
-    // normal closer to y -> the tile is staged TRANSPOSED (from the transposed copy of the image stack made by
-    // ecc_launch_radon), stride 96 again.  Without the transposed copy (p.imagesT null) those workgroups keep the
-    // 97 / 95 rule (the bank advances along x+y or x-y, whichever the normal is closer to).
-    // Measured per 1024^2 image: 97/95 rule everywhere 0.771 ms, stride 96 for x-normals only 0.740 ms, with the transposed
-    // tile for y-normals as well 0.699 ms.
-    // (On top of this a texel-pair tile -- element = float2 {T(c), T(c+1)} along the fast axis, one aligned ds_read_b64 per
-    // footprint row at 256 B/clk instead of ds_read2_b32's 128 -- was measured at the same LDS budget, 72 slow x 64 fast
-    // elements = 36.9 KB, 4 workgroups per CU: bit-exact and 1.010 ms.  The chunks get 0.55-0.74x as long and the cost per
-    // chunk -- bounding box, staging, three barriers -- outweighs the halved read cycles; round 1 had found the same for
-    // the full-size pair tile at 2 workgroups per CU, 1.12 ms.  The chunk machinery alone -- the kernel with its sampling
-    // loop skipped -- takes 0.103 ms per image: 15 % of the kernel, and about what separates it from its LDS time.)
+    // Line normal of the workgroup's middle angle: (nx, ny) = (-sin a, cos a).  The tile's fast axis is the image
+    // axis the normal is closer to: a 32-lane group is 16 adjacent distances x 2 adjacent angles, i.e. two nearly
+    // coincident "combs" of 16 points spaced 1.9 px along the normal; with the bank = fast index mod 32 a comb
+    // advances >= 1.33 banks per lane over < 32 banks, conflict-free in itself, and the two combs cost exactly two
+    // passes (scripts/analysis/radon_lds_layouts.py: no bank function of (x, y) separates them).  Normals closer
+    // to y read a transposed copy of the image stack (made by ecc_launch_radon's caller), so staging stays coalesced.
+    const int ixA = blockIdx.x * RT_A, ixB = min(ixA + RT_A - 1, p.n_alpha - 1), ixM = (ixA + ixB) >> 1;
+    const float nx = -p.trig[2 * ixM], ny = p.trig[2 * ixM + 1];
     if (fabsf(nx) >= fabsf(ny))
-        radon_body<DERIV, TILE_W>(p, sh);
-    else if (p.imagesT)
-        radon_body<DERIV, TILE_W, true>(p, sh);
-    else if (fabsf(nx + ny) >= fabsf(nx - ny))
-        radon_body<DERIV, TILE_W + 1>(p, sh);
+        radon_body<DERIV, false>(p, sh);
     else
-        radon_body<DERIV, TILE_W - 1>(p, sh);
+        radon_body<DERIV, true>(p, sh);
 }
 
 // Replicate the border rows/columns of the private layout (clamp addressing, ecc_layout.h).
@@ -466,6 +530,7 @@ __global__ void dtr_export_kernel(const float* __restrict__ slab, float* __restr
 // ---- launchers (host) --------------------------------------------------------------------------
 extern "C" hipError_t ecc_launch_radon(const EccRadonParams* p, int derivative, hipStream_t stream)
 {
+    if (!p->images || !p->imagesT || !p->out || !p->trig) return hipErrorInvalidValue;  // both image copies are read
     dim3 grid((p->n_alpha + RT_A - 1) / RT_A, (p->n_t + RT_T - 1) / RT_T, p->n_img);
     dim3 block(RT_THREADS);
     if (derivative)
