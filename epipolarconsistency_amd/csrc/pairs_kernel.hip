@@ -20,11 +20,9 @@
 namespace {
 
 constexpr int PK_THREADS = 256;
-#ifndef PK_EXP_MAIN_WAVES
-#define PK_EXP_MAIN_WAVES 4  // waves (= pairs) per workgroup of pairs_kernel, wave w taking the pair w * nblk + block.  Measured
-                            // on the benchmark's launch: 1 wave 0.399 ms, 2 0.333, 4 0.326, 8 0.377, 16 0.408
-#endif
-constexpr int PK_MAIN_THREADS = 64 * PK_EXP_MAIN_WAVES;
+constexpr int PK_MAIN_WAVES = 4;  // waves (= pairs) per workgroup of pairs_kernel, wave w taking the pair w * nblk + block.  Measured
+                                  // on the benchmark's launch: 1 wave 0.399 ms, 2 0.333, 4 0.326, 8 0.377, 16 0.408
+constexpr int PK_MAIN_THREADS = 64 * PK_MAIN_WAVES;
 
 // ref: EpipolarConsistencyCommon.hxx:82-90 (shiftOriginAndNormlaize)
 __device__ __forceinline__ void shift_origin_and_normalize(float x, float y, float* Ki)
@@ -267,11 +265,7 @@ __device__ __forceinline__ LineTap sample_line_prep(float l0, float l1, float l2
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
     // byte offset floor(xa)*pitch4 + floor(yd)*8 in the row-paired copy; ONE 16-byte load fetches the whole 2x2 footprint
-#if defined(PK_EXP_ROWQUANT)  // timing experiment: rows quantised to multiples of PK_EXP_ROWQUANT (wrong results): fewer lines per gather
-    const unsigned off = footprint_offset<PITCH4>(floorf((xa - fx) * (1.0f / PK_EXP_ROWQUANT)) * (float)PK_EXP_ROWQUANT, yd - fy, sv.pitch4, pitch4_f);
-#else
     const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
-#endif
     LineTap t;
     t.ptr = reinterpret_cast<const F4*>(sv.origin + off);
     t.fx = fx;
@@ -289,25 +283,14 @@ __device__ __forceinline__ float line_tap_finish(const F4 q, const LineTap t)
     return DERIV ? __uint_as_float(__float_as_uint(v) ^ t.m) : v;
 }
 
-template <bool DERIV, int PITCH4, bool NT = false>
+template <bool DERIV, int PITCH4>
 __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const SlabView sv, float n_alpha_f,
                                              float n_t_f, float dist_scale, float dist_bias, float pitch4_f)
 {
     const LineTap t = sample_line_prep<PITCH4>(l0, l1, l2, sv, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    if (NT) {  // experiment (-DPK_EXP_HEAVY_NT): non-temporal gathers for the kappa_max > pi/4 pairs, whose lines nobody
-               // re-uses -- inside the benchmark's mixed launch 0.344 vs 0.333 ms (A/B/A/B): they lose their own L1 hits
-        F4 q;
-        q.x = __builtin_nontemporal_load(&t.ptr->x);
-        q.y = __builtin_nontemporal_load(&t.ptr->y);
-        q.z = __builtin_nontemporal_load(&t.ptr->z);
-        q.w = __builtin_nontemporal_load(&t.ptr->w);
-        return line_tap_finish<DERIV>(q, t);
-    }
-#if defined(PK_EXP_NO_LOAD)
-    return line_tap_finish<DERIV>(F4{t.fx, t.fy, __uint_as_float((unsigned)(size_t)t.ptr), 1.f}, t);
-#else
+    // (non-temporal gathers for the kappa_max > pi/4 pairs, whose lines nobody re-uses, were measured inside the
+    // benchmark's mixed launch: 0.344 vs 0.333 ms -- they lose their own L1 hits)
     return line_tap_finish<DERIV>(*t.ptr, t);
-#endif
 }
 
 // One kappa sample (four bilinear samples) of the pair loop; returns false when kappa is past kappa_max.
@@ -327,15 +310,10 @@ __device__ __forceinline__ bool kappa_step(int k, const float (&K0)[8], const fl
     // view 1
     const float a10 = K1[0] * cs, a11 = K1[1] * cs, a12 = K1[2] * cs;
     const float b10 = K1[3] * sn, b11 = K1[4] * sn, b12 = K1[5] * sn;
-#if defined(PK_EXP_HEAVY_NT)
-    constexpr bool NT = REDUCE;
-#else
-    constexpr bool NT = false;
-#endif
-    const float v0p = sample_line<DERIV, PITCH4, NT>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    const float v1p = sample_line<DERIV, PITCH4, NT>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    const float v0m = sample_line<DERIV, PITCH4, NT>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
-    const float v1m = sample_line<DERIV, PITCH4, NT>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v0p = sample_line<DERIV, PITCH4>(b00 + a00, b01 + a01, b02 + a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v1p = sample_line<DERIV, PITCH4>(b10 + a10, b11 + a11, b12 + a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v0m = sample_line<DERIV, PITCH4>(b00 - a00, b01 - a01, b02 - a02, sv0, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
+    const float v1m = sample_line<DERIV, PITCH4>(b10 - a10, b11 - a11, b12 - a12, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
     if (!CORR) {
         const float vp = v0p - v1p, vm = v0m - v1m;
         const float consistency = (vp * vp + vm * vm) * K0[6];  // ref: ...RadonIntermediate.cu:112
@@ -361,16 +339,12 @@ __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_
                                         float& plus, float& minus)
 {
     static_assert(DEG % 2 == 0 && DEG >= 4 && DEG <= ECC_POLY_DEG, "even degree");
-#if defined(PK_EXP_CHEAP_POLY)  // timing experiment: degree-2 coordinates (wrong results; sample_at clamps them)
-    float E = c[2], O = c[1];
-#else
     float E = c[DEG], O = c[DEG - 1];
 #pragma unroll
     for (int k = DEG - 2; k >= 2; k -= 2) {
         E = fmaf(E, z, c[k]);
         O = fmaf(O, z, c[k - 1]);
     }
-#endif
     const float Ep = fmaf(E, z, lo_plus);
     const float Em = same_lo ? Ep : fmaf(E, z, lo_minus);
     const float xo = x * O;
@@ -385,16 +359,9 @@ template <bool DERIV, int PITCH4>
 __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f)
 {
     yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
-#if defined(PK_EXP_CHEAP_POLY)
-    xa = __builtin_amdgcn_fmed3f(xa, 1.f, n_t_f);  // square bin grids only
-#endif
     const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
     const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
-#if defined(PK_EXP_NO_LOAD)   // timing experiment: no memory traffic at all (wrong results)
-    const F4 q = {__uint_as_float(off), fx, fy, xa};
-#else
     const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
-#endif
     const float r0 = fmaf(fx, q.y, q.x);  // q.y, q.w: the row differences, formed when the copy is built
     const float r1 = fmaf(fx, q.w, q.z);
     const float v = fmaf(fy, r1 - r0, r0);
@@ -434,9 +401,6 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         ca[v][ECC_POLY_DEG + 2] = uniformf(rec->ca[v][ECC_POLY_DEG + 2]);
     }
     const float xs = uniformf(rec->x_scale);
-#if defined(PK_EXP_F32_ACC)
-    float acc32 = 0.f;
-#endif
     for (int k = lane; k < k_limit; k += 64) {
         const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
         if (kappa >= kappa_max) break;
@@ -453,11 +417,7 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         if (!CORR) {
             const float vp = v0p - v1p, vm = v0m - v1m;
             const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
-#if defined(PK_EXP_F32_ACC)
-            acc32 += consistency * dkappa;
-#else
             acc += (double)(consistency * dkappa);                // ref: ...RadonIntermediate.cu:269
-#endif
         } else {
             const float one_over_n = kappa_max / kappa;
             mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
@@ -465,14 +425,8 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
             mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
         }
     }
-#if defined(PK_EXP_F32_ACC)
-    acc += (double)acc32;
-#endif
 }
 
-#if defined(PK_EXP_LDS_STAGE)  // the LDS-staged sampling north_star sketches, built to be measured: 0.547 vs 0.329 ms
-#include "pairs_lds_stage_experiment.inc"
-#endif
 
 // The kappa loop of one pair, exact per-sample path.
 template <bool DERIV, bool CORR, bool REDUCE, int PITCH4>
@@ -589,14 +543,6 @@ __device__ __forceinline__ double exact_angle_coord(const EccPolyTables& T, cons
     const double pi = 3.14159265358979323846, inv_Pi_f = 1.0 / (double)3.14159265359f;
     const double dot = fma(g.nn, c, g.alpha * s);  // l . A
     const double cross = g.beta * s;               // A x l
-#if defined(PK_EXP_UNFOLDED_FIT)  // feasibility experiment (wrong results): fit the UNFOLDED angle, no fold / quarter-turn conditions
-    {
-        const double inv_Pi_f = 1.0 / (double)3.14159265359f;
-        valid = fabs(cross) < 1e30 && fabs(dot) < 1e30;
-        fold = false;
-        return fma((g.theta_ref + angle_table(T, dot, cross)) * inv_Pi_f, g.n_alpha, 0.5);
-    }
-#endif
     valid = dot > 0.0 && fabs(cross) < 1e30 && dot < 1e30;
     const double D = angle_table(T, dot, cross);
     double theta = g.theta_ref + D;     // in (-3pi/2, 3pi/2): bring back to atan2's range (-pi, pi]
@@ -886,11 +832,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
             for (int k = 0; k < N; ++k) c[k] = cw[k];
         }
     }
-#if defined(PK_EXP_NO_ECONOMISE)
-    if (ok) ok = ECC_POLY_DEG;
-#else
     if (ok) ok = economise(c, (double)p.economise_tol);
-#endif
     const bool writer = jl == 0;  // LANES > 1: the lanes of a group hold identical results
     if (writer) ok_flags[role][slot] = ok;
     if (angle_role && writer) {
@@ -943,11 +885,7 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     }
 }
 
-#if defined(PK_WAVES_PER_EU)  // experiment: cap the scalar registers so that PK_WAVES_PER_EU waves fit a SIMD
-#define PK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PK_WAVES_PER_EU, PK_WAVES_PER_EU)))
-#else
 #define PK_OCCUPANCY
-#endif
 template <bool DERIV, bool CORR>
 __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairParams p)
 {
@@ -969,17 +907,9 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
     // them over the first quarter of every workgroup.)
     // (Persistent waves -- a launch sized to be resident at once, every wave handling several pairs in turn -- were
     // measured too: 79 800 pairs 0.38 / 0.43 ms with 5 / 10 pairs per wave against 0.33 ms, the shard 86 us with two.)
-#if defined(PK_EXP_STAMPS)  // diagnostic build: wave start / end times (100 MHz), XCC id and path -> K01_out[16 * pair + 0..5]
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#endif
-    const long long nblk = (p.count + PK_EXP_MAIN_WAVES - 1) / PK_EXP_MAIN_WAVES;
+    const long long nblk = (p.count + PK_MAIN_WAVES - 1) / PK_MAIN_WAVES;
     const long long per_xcd = (nblk + 7) / 8;
-#if defined(PK_XCD_CHUNK)  // experiment: XCD x walks chunks x, x + 8, x + 16, ... of PK_XCD_CHUNK blocks instead of one contiguous eighth
-    const long long seq = blockIdx.x >> 3;
-    const long long blk = (seq / PK_XCD_CHUNK) * (8LL * PK_XCD_CHUNK) + (long long)(blockIdx.x & 7) * PK_XCD_CHUNK + (seq % PK_XCD_CHUNK);
-#else
     const long long blk = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-#endif
     if (blk >= nblk) return;
     long long local = (long long)wave * nblk + blk;
     if (local >= p.count) return;  // no barriers below: waves leave independently
@@ -993,11 +923,7 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
         K0[i] = uniformf(rec->K0[i]);
         K1[i] = uniformf(rec->K1[i]);
     }
-#if defined(PK_EXP_SAME_VIEWS)  // timing experiment: every pair samples dtrs 0 and 1 (L2-resident; wrong results)
-    const int iD0 = 0, iD1 = 1;
-#else
     const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
-#endif
     const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
 
     const unsigned pitch4 = (unsigned)p.pitch * 8u;  // row pitch of the paired copies in bytes
@@ -1011,20 +937,7 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
     double acc = 0.0;
     double mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;  // CORR: sums of x*x, y*y, x*y (x, y alone are not used by cc())
     const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
-#if defined(PK_EXP_FORCE_DEG)   // timing experiment: every pair on the polynomial path at this degree (wrong results)
-    const int poly_ok = PK_EXP_FORCE_DEG;
-#elif defined(PK_EXP_NO_EXACT)  // timing experiment: pairs of the exact path take degree 8 instead (wrong results for them)
-    const int poly_ok_rec = __builtin_amdgcn_readfirstlane(rec->poly_ok);
-    const int poly_ok = poly_ok_rec ? poly_ok_rec : 8;
-#elif defined(PK_EXP_NO_DEG10)  // timing experiment: degree-10 pairs take degree 8 (slightly wrong results for them)
-    const int poly_ok_rec = __builtin_amdgcn_readfirstlane(rec->poly_ok);
-    const int poly_ok = poly_ok_rec > 8 ? 8 : poly_ok_rec;
-#else
     const int poly_ok = __builtin_amdgcn_readfirstlane(rec->poly_ok);
-#endif
-#if defined(PK_EXP_ONLY_DEG)    // timing experiment: the kernel contains nothing but this one instantiation (wrong results)
-    kappa_loop_poly<DERIV, CORR, 6400, PK_EXP_ONLY_DEG>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4);
-#else
     if (poly_ok) {
 #define ECC_POLY_LOOP(P4, DEG) \
     kappa_loop_poly<DERIV, CORR, P4, DEG>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4)
@@ -1032,22 +945,6 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
             if (poly_ok <= 6) ECC_POLY_LOOP(-1, 6);
             else ECC_POLY_LOOP(-1, ECC_POLY_DEG);
         } else if (pitch4 == 6400u) {
-#if defined(PK_EXP_LDS_STAGE)
-            if (!CORR) {
-                unsigned tl = 0, ta = 0;
-                __shared__ F2 stage[PK_THREADS / 64][4][LS_ROWS * LS_BINS + 1];  // 8.3 KB per workgroup: one region per wave and stream
-#define ECC_LDS_LOOP(DEG) kappa_loop_poly_lds<DERIV, DEG>(lane, wave, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, p.n_alpha, p.pitch - 1, acc, tl, ta, stage)
-                if (poly_ok <= 4) ECC_LDS_LOOP(4);
-                else if (poly_ok <= 6) ECC_LDS_LOOP(6);
-                else if (poly_ok <= 8) ECC_LDS_LOOP(8);
-                else ECC_LDS_LOOP(ECC_POLY_DEG);
-#undef ECC_LDS_LOOP
-                if (p.K01_out && lane == 0) {  // diagnostics through ecc_metric_debug_K01: trips on the LDS path / all trips
-                    p.K01_out[16 * local + 0] = (float)tl;
-                    p.K01_out[16 * local + 1] = (float)ta;
-                }
-            } else
-#endif
             if (poly_ok <= 4) ECC_POLY_LOOP(6400, 4);
             else if (poly_ok <= 6) ECC_POLY_LOOP(6400, 6);
             else if (poly_ok <= 8) ECC_POLY_LOOP(6400, 8);
@@ -1057,9 +954,6 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
             else ECC_POLY_LOOP(0, ECC_POLY_DEG);
         }
 #undef ECC_POLY_LOOP
-#if defined(PK_EXP_SKIP_HEAVY)   // timing experiment: the pairs with kappa_max > pi/4 do nothing (wrong results)
-    } else if (reduce) {
-#endif
     } else if (reduce && p.quads) {
         // kappa_max > pi/4: in practice the pairs whose baseline passes through the object (kappa_max = pi/2).  Their
         // sampling curve crosses the whole Radon intermediate diagonally -- the 64 samples of a gather sit in ~17
@@ -1088,7 +982,6 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
         kappa_loop<DERIV, CORR, true, 0>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
                                          pitch4_f, acc, mom2, mom3, mom4);
     }
-#endif
     float val;
     if (!CORR) {
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
@@ -1108,15 +1001,6 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
     if (lane == 0) {
         if (p.pair_values) p.pair_values[p.value_slots ? (long long)p.value_slots[local] : local] = val;
         if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
-#if defined(PK_EXP_STAMPS)
-        if (p.K01_out) {
-            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-            unsigned* o = reinterpret_cast<unsigned*>(p.K01_out + 16 * local);
-            o[0] = (unsigned)t_start; o[1] = (unsigned)(t_start >> 32); o[2] = (unsigned)t_end; o[3] = (unsigned)(t_end >> 32);
-            o[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
-            o[5] = (unsigned)poly_ok | (reduce ? 0x100u : 0u);
-        }
-#endif
     }
     // (Fusing the final float64 sum in here -- last-ticket wave reduces -- was measured and dropped: one
     // device-scope atomic per wave on a single counter serialises, 0.51 -> 1.05 ms, and with acquire/release
@@ -1481,11 +1365,8 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
         }
         return hipGetLastError();
     }
-    nblk = (p->count + PK_EXP_MAIN_WAVES - 1) / PK_EXP_MAIN_WAVES;
+    nblk = (p->count + PK_MAIN_WAVES - 1) / PK_MAIN_WAVES;
     long long per_xcd = (nblk + 7) / 8;
-#if defined(PK_XCD_CHUNK)
-    per_xcd = (nblk + 8LL * PK_XCD_CHUNK - 1) / (8LL * PK_XCD_CHUNK) * PK_XCD_CHUNK;
-#endif
     dim3 grid((unsigned)(per_xcd * 8)), block(PK_MAIN_THREADS);
     if (p->use_corr) {
         if (p->is_derivative)

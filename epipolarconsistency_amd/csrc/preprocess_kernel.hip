@@ -185,16 +185,13 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
             const int ly = e / AWc, lx = e - ly * AWc;
             if (e < AHc * AWc) {
                 float val = v[q];
-#if !defined(PP_EXP_NO_POINTWISE)  // timing experiment
                 if (p.process) {
                     val = val * scale + bias;  // ref: Gui/PreProccess.cpp:78-84, continued below when apply_log
                     if (!p.apply_log && (val < 0 || isnan(val) || isinf(val))) val = 0;
                 }
-#endif
                 A[ly * AS + lx] = val;
             }
         }
-#if !defined(PP_EXP_NO_POINTWISE)
         if (p.process && !interior) __syncthreads();  // T (uniform per workgroup)
         if (p.process && (p.apply_log || !interior)) {
 #pragma unroll 1
@@ -218,7 +215,6 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
                 A[ly * AS + lx] = val;
             }
         }
-#endif
     } else {
         for (int ly = ty; ly < AH; ly += PP_THREADS / 64) {
             const int gy = min(max(y0 + ly - k, 0), H - 1);
@@ -252,11 +248,7 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
                     const double d = a[j];
 #pragma unroll
                     for (int s = 0; s < PP_SEG; ++s)
-#if defined(PP_EXP_NO_H)  // timing experiment: one tap (wrong results)
-                        if (j - s == 0) sum[s] += d * taps[j - s];
-#else
                         if (j - s >= 0 && j - s < 2 * KK) sum[s] += d * taps[j - s];
-#endif
                 }
 #pragma unroll
                 for (int s = 0; s < PP_SEG; ++s) B[row * BS + seg * PP_SEG + s] = (float)sum[s];
@@ -288,11 +280,7 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
             const double d = b[j * BS];
 #pragma unroll
             for (int s = 0; s < PP_SEG; ++s)
-#if defined(PP_EXP_NO_V)  // timing experiment: one tap (wrong results)
-                if (j - s == 0) sum[s] += d * taps[j - s];
-#else
                 if (j - s >= 0 && j - s < 2 * KK) sum[s] += d * taps[j - s];
-#endif
         }
 #pragma unroll
         for (int s = 0; s < PP_SEG; ++s) {
