@@ -67,6 +67,10 @@ def parse():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
                     help="CPU baseline evaluates all pairs among every k-th view")
+    ap.add_argument("--sweep-poses", action="store_true",
+                    help="BASELINE config 5 instead of the per-step bench: the 600-point 6-DoF sweep of one view "
+                         "(ref: Gui/Visualization.h:78-98), the POSES sharded round-robin over the ranks, every rank "
+                         "evaluating all pairs of its poses, no exchange inside the timed loop; --steps / --warmup are ignored")
     return ap.parse_args()
 
 
@@ -165,6 +169,83 @@ def n_kappa_auto(n_u, n_v, n_t):
     return int(np.ceil(D - 0.5))
 
 
+def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, dtrs, n, S, B, rank, world, dev, ranks_seen, devices_seen):
+    """BASELINE config 5 (ref: Gui/Visualization.h:78-98 plotCostFunction over the "3D Rigid" parameters of
+    LibProjectiveGeometry/Models/ModelSimilarity3D.hxx:64-88, P' = P T): view n/2 swept over 6 parameters x 100 steps
+    in [-5, 5] mm / [-2, 2] deg = 600 all-pairs evaluations.  The POSES are the independent units here: rank r takes
+    poses r, r + N, ...; every rank holds the whole Radon-intermediate stack and evaluates all pairs of its poses;
+    nothing is exchanged inside the timed loop; the 600 values are gathered afterwards."""
+    moving = n // 2
+    names = ["tx", "ty", "tz", "rx", "ry", "rz"]
+    ranges = [5.0, 5.0, 5.0] + [float(np.deg2rad(2.0))] * 3
+    packed = E.pack_projection_matrices(Ps)
+    P0 = Ps[moving].copy()
+
+    def pose(q):
+        p, k = divmod(q, 100)
+        x = -ranges[p] + 2 * ranges[p] * k / 99.0
+        out = packed.copy()
+        out[moving] = (P0 @ geometry.rigid_transform(**{names[p]: x})).T.reshape(12)
+        return out
+
+    mine = list(range(rank, 600, world))
+    poses = [pose(q) for q in mine]  # producing a pose is the optimiser's work, not the metric's
+    for q in range(3):
+        metric.setProjectionMatrices(poses[q % len(poses)]).evaluate()  # warm-up
+    values = np.zeros(600)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for q, Pq in zip(mine, poses):
+        values[q] = metric.setProjectionMatrices(Pq).evaluate()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        on = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=on)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.from_numpy(values).to(on)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)  # every pose was evaluated by exactly one rank
+        values = v.cpu().numpy()
+    values = values.reshape(6, 100)
+    out = {"metric": "ECC evaluations/sec (6-DoF sweep of one view, N=%d, %d^2 projections)" % (n, S),
+           "value": 600 / elapsed, "unit": "evaluations/s", "n_gpus": world, "steps": 600, "warmup": 3,
+           "ms_per_step": 1e3 * elapsed / 600 * world, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE config 5: %d-projection %dx%d scan, %dx%d Radon bins, view %d swept over 6 rigid "
+                                  "parameters x 100 steps, all %d pairs per pose" % (n, S, S, B, B, moving, n * (n - 1) // 2),
+                      "parallelism": "poses round-robin over %d ranks, whole Radon-intermediate stack on every rank, no exchange "
+                                     "in the timed loop" % world,
+                      "k01_record_reuse": "on (library default)", "ranks_seen_by_collective_backend": ranks_seen,
+                      "devices": devices_seen},
+           "ms_per_step_note": "per rank: each rank evaluates %d poses" % len(mine),
+           "min_at_step": [int(np.argmin(values[p])) for p in range(6)],
+           "values_checksum": float(values.sum())}
+    if rank == 0 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build(native=True)
+        host = [d.readback() for d in dtrs]
+        errs = []
+        for p, k in ((0, 10), (4, 70), (5, 99)):
+            x = -ranges[p] + 2 * ranges[p] * k / 99.0
+            Pk = [q.copy() for q in Ps]
+            Pk[moving] = P0 @ geometry.rigid_transform(**{names[p]: x})
+            ref = oracle.evaluate_all(Pk, host, S, S, native=True)["mean"]
+            errs.append(abs(values[p, k] - ref) / abs(ref))
+        out["parity_rel_err_vs_oracle_at_3_points"] = errs
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import numpy as np
@@ -190,6 +271,26 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+
+    ranks_seen, devices_seen = 1, [torch.cuda.get_device_properties(dev).name + " #%d" % local_rank]
+    if world > 1:
+        # the collective backend must see exactly the ranks the driver asked for, one device each
+        if dist.get_world_size() != args.gpus or dist.get_rank() != rank:
+            raise SystemExit("process group has %d ranks (this one %d), --gpus %d RANK %d" % (dist.get_world_size(), dist.get_rank(), args.gpus, rank))
+        probe = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if abs(probe.item() - world * (world + 1) / 2.0) > 0:
+            raise SystemExit("all-reduce over %d ranks returned %r" % (world, probe.item()))
+        ranks_seen = dist.get_world_size()
+        ids = [None] * world
+        try:
+            uuid = str(torch.cuda.get_device_properties(dev).uuid)
+        except Exception:
+            uuid = "cuda:%d" % local_rank
+        dist.all_gather_object(ids, "%s (local rank %d)" % (uuid, local_rank))
+        devices_seen = ids
+        if not args.single_device and len(set(ids)) != world:
+            raise SystemExit("ranks share devices: %r" % (ids,))
 
     n, S, B = args.views, args.size, args.bins
     pixel_mm = 0.308 * 1024.0 / S
@@ -238,11 +339,24 @@ def main():
             dist.all_gather(parts, local.cpu())
             gathered = torch.cat(parts).to(dev)
         slabs_all = gathered
+        # the gathered stack must be what this rank would have computed itself: recompute one view of the next rank
+        probe_view = min(((rank + 1) % world) * chunk, n - 1)
+        pimg = synthetic.projections_torch(Ps[probe_view:probe_view + 1], S, S, phantom, dev)
+        pslab = torch.zeros((1, slab), dtype=torch.float32, device=dev)
+        keep = E.RadonIntermediate.compute_into(ctx, pimg, pslab, B, B)
+        ctx.synchronize()
+        if not torch.equal(pslab[0], slabs_all[probe_view]):
+            raise SystemExit("rank %d: gathered Radon intermediate of view %d differs from a local recomputation" % (rank, probe_view))
+        del keep, pimg, pslab
     dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
     metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
 
-    # ---- shard of the pair range --------------------------------------------------------------
     n_pairs = n * (n - 1) // 2
+    if args.sweep_poses:
+        sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, dtrs, n, S, B, rank, world, dev, ranks_seen, devices_seen)
+        return
+
+    # ---- shard of the pair range --------------------------------------------------------------
     # cost-balanced contiguous shards (equal-count shards leave rank 0 the straggler: the expensive pairs of a circular
     # scan sit in the first rows of the pair triangle); the same boundaries on every rank, fixed for the whole run
     first, count = sharding.balanced_pair_range(metric, rank, world) if world > 1 else (0, n_pairs)
@@ -334,7 +448,9 @@ def main():
         [m for m in ("shm", "collective") if (m != "shm" or exchange is not None)] if args.exchange == "both"
         else (["shm"] if args.exchange == "shm" and exchange is not None else ["collective"]))
     results = {m: measure(m) for m in modes}
-    best = min(modes, key=lambda m: results[m]["steady"])
+    # N > 1: the headline is the step with the all-reduce of the partial sums (RCCL with --backend nccl), the exchange
+    # north_star names; the shared-memory exchange is reported next to it under timing.other_exchange
+    best = "collective" if "collective" in modes else modes[0]
     res = results[best]
     elapsed, last, step = res["steady"], res["last"], res["step"]
     # pair-kernel duration: HIP events on the context's stream around the pair kernel alone, averaged over a
@@ -347,6 +463,23 @@ def main():
     fence()
     pair_ms /= n_timed
     pair_s = pair_ms * 1e-3
+
+    # the same steps with the record reuse switched off (every step refits all pairs and launches e1_kernel): the
+    # results are bit-identical, only the fixed cost per step differs
+    ctx.enable_timing(False)
+    metric.setRecordReuse(False)
+    for k in range(args.warmup):
+        step(k)
+    off_blocks = []
+    for b in range(3):
+        el_off, last_off = timed_block(step, b * args.steps)
+        off_blocks.append(el_off)
+    v_off = [step(k) for k in (3, 4, 4, 11)]
+    metric.setRecordReuse(True)
+    v_on = [step(k) for k in (3, 4, 4, 11)]
+    reuse_off_s = sorted(off_blocks)[1]
+    if v_on != v_off:
+        raise SystemExit("record reuse changed the results: %r vs %r" % (v_on, v_off))
 
     n_kappa = n_kappa_auto(S, S, B)
     bytes_per_pair = 64 * n_kappa + 68            # 2 views x 2 signs x 4 taps x 4 B + K01 + result
@@ -441,11 +574,20 @@ def main():
                    "sum_exchange": exch_name[best],
                    # the step moves one view like the reference's optimiser loop does; the library's opt-in pose-delta mode
                    # (ecc_metric_set_incremental) would re-evaluate 399 pairs instead of all -- it is NOT used here
-                   "pose_delta_evaluation": "off: every step evaluates all %d pairs" % n_pairs},
+                   "pose_delta_evaluation": "off: every step evaluates all %d pairs" % n_pairs,
+                   # library default: the per-pair geometry records of pairs whose two matrices did not change since the
+                   # last step are kept (one view moves per step: 399 of 79 800 pairs are refitted, E1 of the moved view
+                   # on the host, no e1_kernel launch); every pair is sampled; bit-identical results
+                   "k01_record_reuse": "on (library default); the same run with it off under timing.record_reuse_off",
+                   "ranks_seen_by_collective_backend": ranks_seen, "devices": devices_seen},
         "timing": {"value_is": "median of %d blocks of %d steps" % (len(res["blocks"]), args.steps),
                    "blocks_ms_per_step": [1e3 * b / args.steps for b in res["blocks"]],
                    "cold": {"ms_per_step": 1e3 * res["cold"] / args.steps, "value": args.steps / res["cold"],
-                            "note": "first block after the %d warm-up steps" % args.warmup}},
+                            "note": "first block after the %d warm-up steps" % args.warmup},
+                   "record_reuse_off": {"ms_per_step": 1e3 * reuse_off_s / args.steps, "value": args.steps / reuse_off_s,
+                                        "non_pair_kernel_us_per_step": 1e3 * (1e3 * reuse_off_s / args.steps - pair_ms),
+                                        "note": "median of 3 blocks with ecc_metric_set_record_reuse(0): e1_kernel + k01_kernel "
+                                                "over all pairs every step; same result bits"}},
         "roofline": roofline,
         "roofline_radon": roofline_radon,
         "ms_per_radon_intermediate": ms_per_radon,
@@ -507,4 +649,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:  # a failing rank must take the job down with a non-zero status, never hang the others
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

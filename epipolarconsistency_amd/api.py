@@ -339,6 +339,7 @@ class MetricRadonIntermediate:
         d = type(self).default_sampling
         self._sampling = 0 if d is None else (self._SAMPLING[d] if isinstance(d, str) else int(d))
         self._incremental = False
+        self._record_reuse = None  # library default (on unless ECC_RECORD_REUSE=0)
         if dtrs is not None:
             self.setRadonIntermediates(dtrs)
         if Ps is not None:
@@ -354,6 +355,8 @@ class MetricRadonIntermediate:
         check(_lib.lib().ecc_metric_set_params(self._h, *self._params))
         check(_lib.lib().ecc_metric_set_sampling(self._h, self._sampling))
         check(_lib.lib().ecc_metric_set_incremental(self._h, int(self._incremental)))
+        if self._record_reuse is not None:
+            check(_lib.lib().ecc_metric_set_record_reuse(self._h, int(self._record_reuse)))
         if self._Ps is not None:
             self.setProjectionMatrices(self._Ps)
         return self
@@ -431,6 +434,15 @@ class MetricRadonIntermediate:
         self._incremental = bool(enable)
         if self._h:
             check(_lib.lib().ecc_metric_set_incremental(self._h, int(self._incremental)))
+        return self
+
+    def setRecordReuse(self, on=True):
+        """Not in the reference (ecc_metric_set_record_reuse, default on): keep the per-pair geometry records of the last
+        all-pairs / range evaluation and refit only the pairs whose matrices changed; every pair is still sampled and
+        results are bit-identical either way."""
+        self._record_reuse = bool(on)
+        if self._h:
+            check(_lib.lib().ecc_metric_set_record_reuse(self._h, int(self._record_reuse)))
         return self
 
     def last_evaluated_pairs(self):

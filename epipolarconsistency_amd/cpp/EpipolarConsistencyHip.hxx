@@ -479,6 +479,7 @@ class MetricRadonIntermediate : public Metric {
     bool use_corr;
     int sampling;
     bool incremental;
+    int record_reuse = -1;    // -1: the library's default
     ecc_metric* m_h;          // single-device metric, or the group's rank-0 metric (borrowed) when m_gh is set
     ecc_group_metric* m_gh;   // sharded over a group of devices (ecc_group_*), else null
     ecc_ctx* m_ctx;
@@ -494,6 +495,7 @@ class MetricRadonIntermediate : public Metric {
             detail::check(ecc_metric_set_params(m_h, object_radius_mm, dkappa, use_corr ? 1 : 0));
             detail::check(ecc_metric_set_sampling(m_h, sampling));
             detail::check(ecc_metric_set_incremental(m_h, incremental ? 1 : 0));
+            if (record_reuse >= 0) detail::check(ecc_metric_set_record_reuse(m_h, record_reuse));
         }
     }
     void push_projections()
@@ -549,6 +551,9 @@ public:
     /// Not in the reference: ecc_metric_set_incremental -- evaluate() re-evaluates only the pairs of views whose matrix
     /// changed since the last call (Gui/SingleImageMotion.h moves one view per call); bit-identical results.
     MetricRadonIntermediate& setIncremental(bool on = true) { incremental = on; push_params(); return *this; }
+    /// Not in the reference: ecc_metric_set_record_reuse (library default: on) -- the per-pair geometry of pairs whose
+    /// matrices did not change is kept between evaluate() calls; every pair is still sampled, bit-identical results.
+    MetricRadonIntermediate& setRecordReuse(bool on = true) { record_reuse = on ? 1 : 0; push_params(); return *this; }
 
     /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
     MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)

@@ -190,6 +190,25 @@ struct ecc_metric {
     std::vector<char> scratch_is_changed;
     std::vector<int32_t> scratch_idx, scratch_slots;
     int64_t last_evaluated_pairs = 0;
+    // ecc_metric_set_record_reuse: the per-pair records (k01_kernel's output) of the last all-pairs / range evaluation
+    // stay in records_d together with the matrices and parameters they belong to; the next evaluation of the same range
+    // refits only the pairs with a changed matrix.  E1 is deferred to the evaluation for the same reason.
+    int record_reuse = 1;
+    bool e1_pending = false;   // matrices of set_generation are staged, e1_kernel has not been launched for them
+    bool rec_valid = false;
+    int64_t rec_first = 0, rec_count = 0;
+    int rec_n_views = 0, rec_mode = 0;
+    float rec_radius = 0, rec_dkappa = 0, rec_tol = 0;
+    std::vector<double> rec_Ps;
+    // pinned, device-mapped lists of the reuse path, two used alternately: per pair 4 indices + slot + 2 patch refs,
+    // per changed view 16 floats + its index
+    int32_t* reuse_h[2] = {nullptr, nullptr};
+    int32_t* reuse_h_dev[2] = {nullptr, nullptr};
+    int64_t reuse_words[2] = {0, 0};
+    hipEvent_t reuse_ev[2] = {nullptr, nullptr};  // recorded after the k01 launch that read list b (asynchronous callers)
+    bool reuse_ev_used[2] = {false, false};
+    uint64_t reuse_gen = 0;
+    std::vector<int32_t> scratch_refs;
 };
 
 namespace {
@@ -791,6 +810,10 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     ecc_metric* m = new (std::nothrow) ecc_metric();
     if (!m) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
     m->ctx = ctx;
+    {
+        const char* e = std::getenv("ECC_RECORD_REUSE");
+        if (e && e[0] == '0') m->record_reuse = 0;
+    }
     m->dtrs.assign(dtrs, dtrs + n_dtrs);
     // sizes come from dtrs[0] only, ref: ...RadonIntermediate.cpp:92-98
     const ecc_dtr* d0 = dtrs[0];
@@ -841,7 +864,7 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     if (e == hipSuccess) e = hipMalloc(&m->sum_scratch_d, ecc_sum_scratch_bytes());
     if (e == hipSuccess) e = hipMemsetAsync(m->sum_scratch_d, 0, ecc_sum_scratch_bytes(), ctx->stream);
 
-    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, 64, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&m->sum_h, 64, hipHostMallocMapped | hipHostMallocCoherent);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&m->sum_h_dev, m->sum_h, 0);
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->dtr_table_d, table.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
@@ -879,6 +902,33 @@ ECC_EXPORT int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count)
     return ECC_OK;
 }
 
+namespace {
+// E1 on the device for the matrices of the last ecc_metric_set_projections, if nobody has run it yet: one thread per
+// view reads its 12 doubles straight from the pinned staging buffer and does the reference's binary64 Householder-QR
+// arithmetic (geometry_kernel.hip); nothing else crosses PCIe.
+int ensure_e1(ecc_metric* m)
+{
+    if (!m->e1_pending) return ECC_OK;
+    const int slot = (int)(m->set_generation & 1);
+    HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], m->n_views, m->PinvTs_d, m->Cs_d, m->ctx->stream));
+    m->e1_pending = false;
+    return ECC_OK;
+}
+}  // namespace
+
+ECC_EXPORT int ecc_metric_set_record_reuse(ecc_metric* m, int on)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    m->record_reuse = on ? 1 : 0;
+    m->rec_valid = false;
+    if (!m->record_reuse && m->n_views > 0) {
+        const int rc = set_device(m->ctx);
+        if (rc) return rc;
+        return ensure_e1(m);
+    }
+    return ECC_OK;
+}
+
 ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
 {
     if (!m) return ECC_OK;
@@ -904,6 +954,10 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->sum_h) (void)hipHostFree(m->sum_h);
     if (m->cache_values_d) (void)hipFree(m->cache_values_d);
     if (m->list_h) (void)hipHostFree(m->list_h);
+    for (int b = 0; b < 2; ++b) {
+        if (m->reuse_h[b]) (void)hipHostFree(m->reuse_h[b]);
+        if (m->reuse_ev[b]) (void)hipEventDestroy(m->reuse_ev[b]);
+    }
     delete m;
     return ECC_OK;
 }
@@ -946,13 +1000,14 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
         m->done_generation = m->set_generation;
     }
     const int slot = (int)(g & 1);
-    // E1 on the device: one thread per view reads its 12 doubles straight from the pinned staging buffer and
-    // does the reference's binary64 Householder-QR arithmetic (geometry_kernel.hip); nothing else crosses PCIe.
     std::memcpy(m->Ps_h[slot], Ps, sizeof(double) * 12 * (size_t)n_views);
-    HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], n_views, m->PinvTs_d, m->Cs_d, ctx->stream));
     m->set_generation = g;
     m->n_views = n_views;
     m->P_first.assign(Ps, Ps + 12);
+    // E1 itself is launched by whoever needs PinvTs / Cs next (ensure_e1): an evaluation that finds most matrices
+    // unchanged computes the few changed views on the host and never launches it.
+    m->e1_pending = true;
+    if (!m->record_reuse) return ensure_e1(m);
     return ECC_OK;
 }
 
@@ -963,6 +1018,10 @@ ECC_EXPORT int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     int rc = set_device(m->ctx);
     if (rc) return rc;
+    {
+        const int rc1 = ensure_e1(m);
+        if (rc1) return rc1;
+    }
     HIP_TRY(hipMemcpyAsync(PinvTs, m->PinvTs_d, sizeof(float) * 12 * m->n_views, hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_TRY(hipMemcpyAsync(Cs, m->Cs_d, sizeof(float) * 4 * m->n_views, hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
@@ -1021,9 +1080,18 @@ int resolve_sampling(const ecc_metric* m, int64_t count)
     return count <= ECC_SAMPLING_AUTO_REFERENCE_PAIRS ? ECC_SAMPLING_REFERENCE : ECC_SAMPLING_POLYNOMIAL;
 }
 
-int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t count)
+// mode_count: the size of the EVALUATION the launch belongs to -- n (n - 1) / 2 for all-pairs evaluations and every shard
+// (range) of one, the list length for index lists -- which is what ECC_SAMPLING_AUTO resolves from: a shard of an
+// evaluation runs in the mode of the whole, whatever its own size, so the sum of G shard sums is the one-device sum's
+// arithmetic and a re-balanced shard does not change mode.
+int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool need_e1 = true)
 {
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
+    if (need_e1) {
+        const int rc1 = ensure_e1(m);
+        if (rc1) return rc1;
+    }
+    const int64_t count = mode_count;
     double radius = 0;
     ecc_metric_get_object_radius(m, &radius);
     std::memset(p, 0, sizeof(*p));
@@ -1068,8 +1136,32 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t count)
     return ECC_OK;
 }
 
+// The pinned list buffer b of the reuse path with room for `words` 32-bit words.
+int ensure_reuse_list(ecc_metric* m, int b, int64_t words)
+{
+    if (m->reuse_words[b] >= words) return ECC_OK;
+    HIP_TRY(wait_stream_spin(m->ctx->stream));  // a launch may still be reading the old buffer
+    if (m->reuse_h[b]) HIP_TRY(hipHostFree(m->reuse_h[b]));
+    m->reuse_h[b] = nullptr;
+    m->reuse_words[b] = 0;
+    const int64_t cap = std::max<int64_t>(2 * words, 16384);
+    HIP_TRY(hipHostMalloc((void**)&m->reuse_h[b], sizeof(int32_t) * cap, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&m->reuse_h_dev[b], m->reuse_h[b], 0));
+    m->reuse_words[b] = cap;
+    return ECC_OK;
+}
+
+// k01_kernel + pairs_kernel (+ sum) over the pair range [first, first + count).
+// Record reuse (default on, ecc_metric_set_record_reuse): a pair's record is a function of its two matrices and the
+// parameters only.  When this range was evaluated before with the same parameters and at most a quarter of the matrices
+// differ from the ones its records were made from, k01_kernel runs over an index list of the pairs that contain a
+// changed view (8 lanes per fit up to 4096 pairs) and writes each record into its slot of the kept array; E1 of the
+// changed views is done on the host with the device's own code (ecc_host_geometry.h, bit-identical) and reaches the
+// kernel through pinned memory, so e1_kernel is not launched at all.  pairs_kernel then samples EVERY pair as always:
+// the evaluation's result is bit-identical to one that refits everything (tests/test_gpu_record_reuse.py).
+// synchronous: the caller waits for the result before it returns (the list buffers need no event then).
 int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d, float* cost_d, float* K01_d,
-                 double* sum_d)
+                 double* sum_d, bool synchronous = false)
 {
     ecc_ctx* ctx = m->ctx;
     const int64_t n = m->n_views;
@@ -1079,7 +1171,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     if (first < 0 || count < 0 || first + count > n_pairs)
         return fail(ECC_ERR_INVALID_ARGUMENT, "pair range outside [0, n(n-1)/2)");
     EccPairParams p;
-    int rc = fill_pair_params(m, &p, count);
+    int rc = fill_pair_params(m, &p, n_pairs, /*need_e1=*/false);
     if (rc) return rc;
     rc = ensure_capacity(&m->records_d, &m->records_capacity, count > 0 ? count : 1, ctx->stream);
     if (rc) return rc;
@@ -1090,9 +1182,104 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     p.K01_out = K01_d;
     p.records = m->records_d;
     m->last_evaluated_pairs = count;
-    // (Replaying the three launches below as an instantiated hipGraph was measured on ROCm 7.2: 6-9 us SLOWER per
-    // evaluation than launching them on the stream, at 79 800 pairs and at a 9 975-pair shard.)
-    HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+
+    const int mode = p.reference_arithmetic ? ECC_SAMPLING_REFERENCE : (p.poly ? ECC_SAMPLING_POLYNOMIAL : ECC_SAMPLING_PER_SAMPLE);
+    const double* Pcur = m->Ps_h[m->set_generation & 1];
+    bool reused = false;
+    const bool rec_match = m->record_reuse && m->rec_valid && !K01_d && count > 0 && m->rec_first == first && m->rec_count == count &&
+                           m->rec_n_views == (int)n && m->rec_mode == mode && m->rec_radius == p.object_radius_mm &&
+                           m->rec_dkappa == p.dkappa_user && m->rec_tol == p.economise_tol && (int64_t)m->rec_Ps.size() == 12 * n;
+    m->rec_valid = false;  // until everything below is enqueued
+    if (rec_match) {
+        std::vector<int>& changed = m->scratch_changed;
+        changed.clear();
+        for (int64_t v = 0; v < n; ++v)
+            if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
+        if ((int64_t)changed.size() * 4 <= n) {
+            std::vector<char>& is_changed = m->scratch_is_changed;
+            std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots, &refs = m->scratch_refs;
+            is_changed.assign((size_t)n, 0);
+            std::vector<int32_t> patch_of((size_t)n, -1);
+            for (size_t e = 0; e < changed.size(); ++e) {
+                is_changed[changed[e]] = 1;
+                patch_of[changed[e]] = (int32_t)e;
+            }
+            idx.clear();
+            slots.clear();
+            refs.clear();
+            for (int v : changed)
+                for (int64_t u = 0; u < n; ++u) {
+                    if (u == v || (is_changed[u] && u < v)) continue;  // a pair of two changed views once
+                    const int64_t i = u < v ? u : v, j = u < v ? v : u;
+                    const int64_t ij = i * n - i * (i + 1) / 2 + (j - i - 1);  // get_ij order
+                    if (ij < first || ij >= first + count) continue;
+                    idx.insert(idx.end(), {(int32_t)i, (int32_t)j, (int32_t)i, (int32_t)j});
+                    slots.push_back((int32_t)(ij - first));
+                    refs.push_back(patch_of[i]);
+                    refs.push_back(patch_of[j]);
+                }
+            const int64_t L = (int64_t)slots.size(), C = (int64_t)changed.size();
+            const int b = (int)(m->reuse_gen++ & 1);
+            // L = 0 (no pair of this range contains a changed view): nothing to refit and nothing launched; rec_Ps keeps
+            // the old matrices of those views, which is what PinvTs / Cs on the device still correspond to
+            if (L > 0) {
+                rc = ensure_reuse_list(m, b, 7 * L + 17 * C);
+                if (rc) return rc;
+                if (m->reuse_ev_used[b]) {  // an asynchronous caller: the launch that read this buffer two calls ago
+                    HIP_TRY(hipEventSynchronize(m->reuse_ev[b]));
+                    m->reuse_ev_used[b] = false;
+                }
+                int32_t* h = m->reuse_h[b];
+                std::memcpy(h, idx.data(), sizeof(int32_t) * 4 * L);
+                std::memcpy(h + 4 * L, slots.data(), sizeof(int32_t) * L);
+                std::memcpy(h + 5 * L, refs.data(), sizeof(int32_t) * 2 * L);
+                float* geo = reinterpret_cast<float*>(h + 7 * L);
+                int32_t* views = h + 7 * L + 16 * C;
+                for (int64_t e = 0; e < C; ++e) {  // E1 of the changed views (ref: ...RadonIntermediate.cpp:134-163)
+                    ecc_host::pinv_transpose(Pcur + 12 * changed[e], geo + 16 * e);
+                    ecc_host::source_position(Pcur + 12 * changed[e], geo + 16 * e + 12);
+                    views[e] = changed[e];
+                }
+                EccPairParams q = p;  // k01_kernel over the list
+                q.indices = m->reuse_h_dev[b];
+                q.record_slots = m->reuse_h_dev[b] + 4 * L;
+                q.patch_ref = m->reuse_h_dev[b] + 5 * L;
+                q.patch_geo = reinterpret_cast<const float*>(m->reuse_h_dev[b] + 7 * L);
+                q.patch_views = m->reuse_h_dev[b] + 7 * L + 16 * C;
+                q.patch_count = (int)C;
+                q.first = 0;
+                q.count = L;
+                q.cost = nullptr;
+                q.pair_values = nullptr;
+                HIP_TRY(ecc_launch_k01(&q, ctx->stream));
+                if (!synchronous) {
+                    if (!m->reuse_ev[b]) HIP_TRY(hipEventCreateWithFlags(&m->reuse_ev[b], hipEventDisableTiming));
+                    HIP_TRY(hipEventRecord(m->reuse_ev[b], ctx->stream));
+                    m->reuse_ev_used[b] = true;
+                }
+                for (int v : changed) std::memcpy(m->rec_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
+            }
+            if (L > 0 || C == 0) m->e1_pending = false;  // PinvTs / Cs are those of the current matrices again
+            reused = true;
+        }
+    }
+    if (!reused) {
+        rc = ensure_e1(m);
+        if (rc) return rc;
+        // (Replaying the three launches below as an instantiated hipGraph was measured on ROCm 7.2: 6-9 us SLOWER per
+        // evaluation than launching them on the stream, at 79 800 pairs and at a 9 975-pair shard.)
+        HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+        if (m->record_reuse && !K01_d && count > 0) {
+            m->rec_Ps.assign(Pcur, Pcur + 12 * n);
+            m->rec_first = first;
+            m->rec_count = count;
+            m->rec_n_views = (int)n;
+            m->rec_mode = mode;
+            m->rec_radius = p.object_radius_mm;
+            m->rec_dkappa = p.dkappa_user;
+            m->rec_tol = p.economise_tol;
+        }
+    }
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
     if (ctx->timing) {
@@ -1104,6 +1291,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         else if (sum_d == m->sum_h_dev) std::memset(m->sum_h, 0, sizeof(double));  // empty shard: nothing is launched
         else HIP_TRY(hipMemsetAsync(sum_d, 0, sizeof(double), ctx->stream));
     }
+    m->rec_valid = m->record_reuse && !K01_d && count > 0;
     return ECC_OK;
 }
 
@@ -1166,8 +1354,9 @@ int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, 
                 std::memcpy(m->list_h, idx.data(), sizeof(int32_t) * 4 * L);
                 std::memcpy(m->list_h + 4 * L, slots.data(), sizeof(int32_t) * L);
                 EccPairParams p;
-                rc = fill_pair_params(m, &p, count);  // the sampling mode of the full range
+                rc = fill_pair_params(m, &p, n * (n - 1) / 2);  // the sampling mode of the full evaluation
                 if (rc) return rc;
+                m->rec_valid = false;  // the list's records overwrite the kept ones
                 rc = ensure_capacity(&m->records_d, &m->records_capacity, L, ctx->stream);
                 if (rc) return rc;
                 p.indices = m->list_h_dev;  // read over PCIe inside k01_kernel: 20 bytes per pair, no copy command
@@ -1236,7 +1425,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
     float* vals_d = m->pair_values_d;
     if (m->incremental) rc = evaluate_cached(m, first, count, m->sum_h_dev, &vals_d);
     else {
-        rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_h_dev);
+        rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_h_dev, /*synchronous=*/true);
         m->last_evaluated_pairs = count;
     }
     if (rc) return rc;
@@ -1245,6 +1434,8 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
         HIP_TRY(wait_stream_spin(ctx->stream));  // the copy has to land too
     }
     HIP_TRY(wait_result(m, ctx->stream, partial_sum));
+    // an empty shard launches no kernel behind e1_kernel: its result slot says nothing about the stream
+    if (count == 0) HIP_TRY(wait_stream_spin(ctx->stream));
     m->done_generation = m->set_generation;
     return ECC_OK;
 }
@@ -1280,7 +1471,7 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
         float* vals_d = nullptr;
         rc = evaluate_cached(m, 0, n_pairs, m->sum_h_dev, &vals_d);
     } else {
-        rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_h_dev);  // the sum lands in pinned host memory
+        rc = launch_range(m, 0, n_pairs, m->pair_values_d, cost_d, nullptr, m->sum_h_dev, /*synchronous=*/true);  // the sum lands in pinned host memory
         m->last_evaluated_pairs = n_pairs;
     }
     if (rc) return rc;
@@ -1317,6 +1508,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     EccPairParams p;
     rc = fill_pair_params(m, &p, n_pairs);
     if (rc) return rc;
+    m->rec_valid = false;  // the list's records overwrite the kept ones
     rc = ensure_capacity(&m->records_d, &m->records_capacity, n_pairs, ctx->stream);
     if (rc) return rc;
     p.indices = m->indices_d;
@@ -1401,6 +1593,11 @@ ECC_EXPORT int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, i
     std::memset(&p, 0, sizeof(p));
     p.dtr0 = m->dtrs[i]->base;
     p.dtr1 = m->dtrs[j]->base;
+    rc = ensure_e1(m);
+    if (rc) {
+        (void)hipFree(out_d);
+        return rc;
+    }
     p.Cs = m->Cs_d;
     p.PinvTs = m->PinvTs_d;
     p.out = out_d;

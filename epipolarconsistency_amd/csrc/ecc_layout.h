@@ -105,6 +105,14 @@ struct EccPairParams {
     float* cost;               // optional n x n cost image (index i + j*n)
     float* K01_out;            // optional debug output, 16 floats per pair
     EccPairRecord* records;    // `count` records, written by k01_kernel, read by pairs_kernel
+    // Record reuse (ecc_metric_set_record_reuse): k01_kernel runs over an index list of the pairs whose matrices changed
+    // and writes each record into its slot of a record array kept from the previous evaluation.
+    const int32_t* record_slots;  // optional, `count` entries: records[record_slots[k]] instead of records[k]
+    const int32_t* patch_ref;     // optional, 2 per pair: entry of patch_geo that holds view P0 / P1, or -1 (device arrays)
+    const float* patch_geo;       // 16 floats per entry: (P^+)^T (12) + C (4) of a view whose matrix changed, computed
+                                  // on the host (pinned memory: read over PCIe inside k01_kernel, no copy command)
+    const int32_t* patch_views;   // view of each entry; the launch also copies the entries into PinvTs / Cs
+    int patch_count;
     const EccPolyTables* poly; // constant tables of the polynomial fit (null: exact path for every pair)
     int64_t first;             // first pair (get_ij order) handled by this launch
     int64_t count;             // pairs handled by this launch

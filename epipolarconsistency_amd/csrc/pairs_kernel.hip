@@ -775,10 +775,32 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     // (dkappa, kappa_max) for view 1 -- the layout of the reference's K01 array
     float Kv[8], kappa_max = 0.f, dkappa = 0.f;
     for (int i = 0; i < 8; i++) Kv[i] = 0.f;
+    // Record reuse: views whose matrix changed since the kept records were made come from the host's patch list (the
+    // same E1 arithmetic, ecc_host_geometry.h); workgroup 0 also copies the list into the device arrays, which no
+    // thread of this launch reads for a patched view.
+    if (p.patch_count > 0 && blockIdx.x == 0)
+        for (int q = threadIdx.x; q < 16 * p.patch_count; q += 256) {
+            const int e = q >> 4, w = q & 15, view = p.patch_views[e];
+            const float val = p.patch_geo[q];
+            if (w < 12) const_cast<float*>(p.PinvTs)[12 * view + w] = val;
+            else const_cast<float*>(p.Cs)[4 * view + (w - 12)] = val;
+        }
+    if (live && p.record_slots) {  // the kept records serve all-pairs launches: cost-image position = the pair itself
+        ci = iP0;
+        cj = iP1;
+    }
     if (live && iP0 != iP1) {
         float Kp[8], s2, s3, K06, K07;
-        baseline_pencil(p.Cs + 4 * iP0, p.Cs + 4 * iP1, Kp, s2, s3);
-        project_pencil(p.PinvTs + 12 * (v ? iP1 : iP0), Kp, p.n_x2, p.n_y2, Kv);
+        const float *C0 = p.Cs + 4 * iP0, *C1 = p.Cs + 4 * iP1, *Pv = p.PinvTs + 12 * (v ? iP1 : iP0);
+        if (p.patch_ref) {
+            const int r0 = p.patch_ref[2 * (p.first + local)], r1 = p.patch_ref[2 * (p.first + local) + 1];
+            if (r0 >= 0) C0 = p.patch_geo + 16 * r0 + 12;
+            if (r1 >= 0) C1 = p.patch_geo + 16 * r1 + 12;
+            const int rv = v ? r1 : r0;
+            if (rv >= 0) Pv = p.patch_geo + 16 * rv;
+        }
+        baseline_pencil(C0, C1, Kp, s2, s3);
+        project_pencil(Pv, Kp, p.n_x2, p.n_y2, Kv);
         pencil_range(s2, s3, p.object_radius_mm, p.num_samples, p.dkappa_user, p.K01_out != nullptr && angle_role, K06, K07,
                      dkappa, kappa_max);
         Kv[6] = v ? dkappa : K06;
@@ -878,10 +900,18 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
     const long long first_pair = (long long)blockIdx.x * K01_PAIRS;
     const long long n_here = min((long long)K01_PAIRS, p.count - first_pair);
     if (n_here > 0) {
-        const int words = (int)(n_here * (sizeof(EccPairRecord) / 8));
+        constexpr int RW = (int)(sizeof(EccPairRecord) / 8);
+        const int words = (int)n_here * RW;
         const double* src = reinterpret_cast<const double*>(recs);
-        double* dst = reinterpret_cast<double*>(p.records + first_pair);
-        for (int q = threadIdx.x; q < words; q += 256) dst[q] = src[q];
+        if (!p.record_slots) {
+            double* dst = reinterpret_cast<double*>(p.records + first_pair);
+            for (int q = threadIdx.x; q < words; q += 256) dst[q] = src[q];
+        } else {  // each record into its own slot (still whole records, 37 consecutive 8-byte words)
+            for (int q = threadIdx.x; q < words; q += 256) {
+                const int rcd = q / RW, w = q - rcd * RW;
+                reinterpret_cast<double*>(p.records + p.record_slots[p.first + first_pair + rcd])[w] = src[q];
+            }
+        }
     }
 }
 

@@ -195,6 +195,9 @@ int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa,
  *                            ECC_SAMPLING_AUTO_REFERENCE_PAIRS pairs (the whole evaluation is one pair's latency either
  *                            way: 2-view metric values, index lists as in tools/Registration/Registration3D3D.hxx:95,109),
  *                            POLYNOMIAL above.  Callers that compare values ACROSS calls of different size fix the mode. */
+/* ECC_SAMPLING_AUTO resolves from the size of the EVALUATION, not of the launch: n (n - 1) / 2 for ecc_metric_evaluate_all
+ * and for every ecc_metric_evaluate_range[_async] shard of it (so G shard sums add up to the one-device sum's arithmetic
+ * whatever G, and cost-balanced or re-balanced shards never mix modes), the list length for index lists. */
 enum { ECC_SAMPLING_AUTO = 0, ECC_SAMPLING_POLYNOMIAL = 1, ECC_SAMPLING_PER_SAMPLE = 2, ECC_SAMPLING_REFERENCE = 3 };
 #define ECC_SAMPLING_AUTO_REFERENCE_PAIRS 512
 int ecc_metric_set_sampling(ecc_metric* m, int mode);
@@ -211,6 +214,18 @@ int ecc_metric_set_sampling(ecc_metric* m, int mode);
  * last evaluate_all / evaluate_range recomputed. */
 int ecc_metric_set_incremental(ecc_metric* m, int enable);
 int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
+/* Record reuse (default ON; not in the reference; ECC_RECORD_REUSE=0 in the environment turns the default off).  The
+ * per-pair geometry of an evaluation (the reference's K01 array, ref: ...RadonIntermediate.cu:13-67, here k01_kernel's
+ * records) is a function of the pair's two matrices and the parameters only.  ecc_metric_evaluate_all /
+ * ecc_metric_evaluate_range[_async] keep the records of their last evaluation; when the next call evaluates the same range
+ * with the same parameters and at most a quarter of the matrices differ bit-wise from the ones the records were made
+ * from, only the pairs that contain a changed view are refitted, E1 (ref: ...RadonIntermediate.cpp:134-163) of the
+ * changed views is computed on the host by the same code, and e1_kernel is not launched.  EVERY pair is still sampled by
+ * the pair kernel: the work that is skipped is geometry that would be recomputed to identical bits, so results are
+ * bit-identical with the switch on or off (tests/test_gpu_record_reuse.py).  This is the callers' pattern: the reference's
+ * optimisation problems overwrite one view's matrix per cost-function call (ref: Gui/SingleImageMotion.h:84-90).
+ * With the switch on, ecc_metric_set_projections only stages the matrices; E1 runs with the next call that needs it. */
+int ecc_metric_set_record_reuse(ecc_metric* m, int on);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
 int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);

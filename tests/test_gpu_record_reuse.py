@@ -1,0 +1,202 @@
+"""Record reuse (ecc_metric_set_record_reuse, default on; not in the reference).
+
+The reference's optimisation problems overwrite ONE view's matrix per cost-function call and evaluate all pairs again
+(ref: Gui/SingleImageMotion.h:84-90).  A pair's geometry record (the reference's K01 array, ref: ...RadonIntermediate.cu:13-67)
+depends on the pair's two matrices and the parameters only, so the library keeps the records of the last evaluation,
+refits only the pairs with a changed matrix, computes E1 of the changed views on the host and does not launch e1_kernel.
+Every pair is still sampled.  The contract tested here: results (mean, every pair value, cost images, E1 on the device)
+are BIT-IDENTICAL to a metric with the switch off, whatever the sequence of calls."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _moved(Ps, views, k=1.0):
+    import epipolarconsistency_amd as E
+    out = list(Ps)
+    for v in views:
+        out[v] = out[v] @ E.geometry.rigid_transform(tx=0.7 * k, ty=-0.3 * k, rz=0.01 * k, ry=0.004 * (v + 1))
+    return out
+
+
+def _pair(gpu_ctx, Ps, dtrs):
+    import epipolarconsistency_amd as E
+    on = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(True)
+    off = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(False)
+    return on, off
+
+
+def _same(on, off, n_pairs):
+    a, va = on.evaluate_range(0, n_pairs, want_pairs=True)
+    b, vb = off.evaluate_range(0, n_pairs, want_pairs=True)
+    assert a == b and np.array_equal(va, vb)
+    assert on.evaluate() == off.evaluate()
+    for x, y in zip(on.debug_geometry(), off.debug_geometry()):
+        assert np.array_equal(x, y)
+    return a
+
+
+def test_sequences_bit_identical(gpu_ctx, small_scan):
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    on, off = _pair(gpu_ctx, s["Ps"], dtrs)
+    n_pairs = 28
+    first = _same(on, off, n_pairs)
+    seen = {first}
+    Ps = list(s["Ps"])
+    # one view, none, two views, view 0 (the automatic object radius follows it: everything is refitted), three views
+    # (more than a quarter: everything), one view again
+    for k, views in enumerate([[3], [], [1, 6], [0], [0, 2, 4], [7]]):
+        Ps = _moved(Ps, views, k + 1.0)
+        on.setProjectionMatrices(Ps)
+        off.setProjectionMatrices(Ps)
+        v = _same(on, off, n_pairs)
+        if views:
+            assert v not in seen
+        seen.add(v)
+    # moved and moved back: the first value again, bit for bit
+    on.setProjectionMatrices(s["Ps"]); off.setProjectionMatrices(s["Ps"])
+    assert _same(on, off, n_pairs) == first
+    on.setProjectionMatrices(_moved(s["Ps"], [5])); off.setProjectionMatrices(_moved(s["Ps"], [5]))
+    assert _same(on, off, n_pairs) != first
+    on.setProjectionMatrices(s["Ps"]); off.setProjectionMatrices(s["Ps"])
+    assert _same(on, off, n_pairs) == first
+    # cost images: untouched entries survive, touched ones identical
+    for views in ([], [2], [4]):
+        P1 = _moved(s["Ps"], views, 0.3)
+        ca, cb = np.full((8, 8), 2.0, np.float32), np.full((8, 8), 2.0, np.float32)
+        assert on.setProjectionMatrices(P1).evaluate(ca) == off.setProjectionMatrices(P1).evaluate(cb)
+        assert np.array_equal(ca, cb) and ca[3, 3] == 2.0 and ca[0, 1] == 2.0 and ca[1, 0] != 2.0  # index i + j * n, i < j
+    # parameters, sampling modes: records of other parameters are never used
+    for change in (lambda m: m.setObjectRadius(25.0), lambda m: m.setdKappa(0.004), lambda m: m.useCorrelation(True),
+                   lambda m: m.useCorrelation(False).setObjectRadius(0.0).setdKappa(0.0), lambda m: m.setSampling("per_sample"),
+                   lambda m: m.setSampling("reference"), lambda m: m.setSampling("auto"), lambda m: m.setSampling("polynomial")):
+        change(on)
+        change(off)
+        _same(on, off, n_pairs)
+        P1 = _moved(s["Ps"], [2], 0.5)
+        on.setProjectionMatrices(P1); off.setProjectionMatrices(P1)
+        _same(on, off, n_pairs)
+        on.setProjectionMatrices(s["Ps"]); off.setProjectionMatrices(s["Ps"])
+    assert _same(on, off, n_pairs) == first
+    # index lists and image pairs in between use the record array: the kept records are dropped, not misused
+    idx = [(0, 5, 0, 5), (2, 3, 2, 3)]
+    assert on.evaluate(idx) == off.evaluate(idx)
+    on.setProjectionMatrices(_moved(s["Ps"], [6], 0.2)); off.setProjectionMatrices(_moved(s["Ps"], [6], 0.2))
+    _same(on, off, n_pairs)
+    a, b = on.evaluateForImagePair(1, 6), off.evaluateForImagePair(1, 6)
+    assert a[0] == b[0] and all(np.array_equal(a[1][k], b[1][k]) for k in a[1])
+    _same(on, off, n_pairs)
+    # the pose-delta mode on top of it
+    on.setIncremental(True)
+    for views in ([1], [], [4, 5]):
+        P1 = _moved(s["Ps"], views, 0.9)
+        assert on.setProjectionMatrices(P1).evaluate() == off.setProjectionMatrices(P1).evaluate()
+    on.setIncremental(False)
+    # switching off and on again
+    on.setRecordReuse(False)
+    _same(on, off, n_pairs)
+    on.setRecordReuse(True)
+    _same(on, off, n_pairs)
+    on.setProjectionMatrices(_moved(s["Ps"], [3], 0.1)); off.setProjectionMatrices(_moved(s["Ps"], [3], 0.1))
+    _same(on, off, n_pairs)
+    on.close()
+    off.close()
+
+
+def test_shards_and_ranges(gpu_ctx, small_scan):
+    """Ranges of the pair triangle (what one rank of a sharded evaluation calls): the changed view's pairs may all lie
+    outside the range (nothing refitted, nothing launched for E1), and a different range starts from scratch."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    on, off = _pair(gpu_ctx, s["Ps"], dtrs)
+    ranges = [(0, 7), (7, 6), (13, 15), (0, 28), (5, 0)]  # (0, 7) = the pairs of view 0 only: every other view's move leaves L = 0 ... except through view 0's partners
+    for first, count in ranges:
+        for views in ([], [7], [1], [7], [2, 3], []):
+            P1 = _moved(s["Ps"], views, 0.4 + 0.1 * len(views))
+            on.setProjectionMatrices(P1); off.setProjectionMatrices(P1)
+            a, va = on.evaluate_range(first, count, want_pairs=True)
+            b, vb = off.evaluate_range(first, count, want_pairs=True)
+            assert a == b and np.array_equal(va, vb), (first, count, views)
+    # pairs (6, 7) only: moving view 1 touches no pair of the range; afterwards a full evaluation must see view 1's new E1
+    P1 = _moved(s["Ps"], [1], 0.77)
+    for m in (on, off):
+        m.setProjectionMatrices(s["Ps"]).evaluate_range(27, 1)
+        m.setProjectionMatrices(P1)
+    assert on.evaluate_range(27, 1) == off.evaluate_range(27, 1)
+    assert on.evaluate() == off.evaluate()
+    for x, y in zip(on.debug_geometry(), off.debug_geometry()):
+        assert np.array_equal(x, y)
+    on.close()
+    off.close()
+
+
+def test_asynchronous_ranges_cycle_the_list_buffers(gpu_ctx, small_scan):
+    import torch
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    on, off = _pair(gpu_ctx, s["Ps"], dtrs)
+    dev = torch.device("cuda", 0)
+    sums = torch.zeros(12, dtype=torch.float64, device=dev)
+    want = []
+    for k in range(12):  # no synchronisation between the calls
+        P1 = _moved(s["Ps"], [k % 8] if k % 3 else [], 0.1 * (k + 1))
+        on.setProjectionMatrices(P1)
+        on.evaluate_range_async(0, 28, sums[k:k + 1])
+        want.append(off.setProjectionMatrices(P1).evaluate_range(0, 28))
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    assert sums.cpu().tolist() == want
+    on.close()
+    off.close()
+
+
+def test_many_changed_views_take_the_wide_list_kernel(gpu_ctx):
+    """200 views, 24 of them moved: 4 500 listed pairs, above the 8-lanes-per-fit limit of k01_kernel (4096)."""
+    import epipolarconsistency_amd as E
+    rng = np.random.default_rng(3)
+    n, S, B = 200, 128, 64
+    from epipolarconsistency_amd import synthetic
+    Ps = synthetic.short_scan(n, S, S, 0.308 * 1024 / S)
+    data = [rng.standard_normal((B, B)).astype(np.float32) for _ in range(4)]
+    base = [E.RadonIntermediate.from_host(gpu_ctx, d, S, S) for d in data]
+    dtrs = [base[v % 4] for v in range(n)]
+    on, off = _pair(gpu_ctx, Ps, dtrs)
+    n_pairs = n * (n - 1) // 2
+    _same(on, off, n_pairs)
+    moved = list(range(5, 200, 8))[:24]
+    P1 = _moved(Ps, moved, 0.6)
+    on.setProjectionMatrices(P1); off.setProjectionMatrices(P1)
+    _same(on, off, n_pairs)
+    P2 = _moved(P1, [100], 0.2)
+    on.setProjectionMatrices(P2); off.setProjectionMatrices(P2)
+    _same(on, off, n_pairs)
+    on.close()
+    off.close()
+    for d in base:
+        d.close()
+
+
+def test_group_default(gpu_ctx, small_scan):
+    """The single-process group runs with the library's default (reuse on) on every rank; compare with reuse off."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    g = E.Group([0, 0, 0])
+    gd = g.compute_batch(s["imgs"], s["n_alpha"], s["n_t"])
+    gm = E.GroupMetricRadonIntermediate(g, s["Ps"], gd)
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    off = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs).setRecordReuse(False)
+    bnd = off.balanced_shards(3)  # the group's shard bounds: fixed at creation from the first matrices
+    for views in ([], [3], [3], [0], [1, 2], []):
+        P1 = _moved(s["Ps"], views, 0.35)
+        a = gm.setProjectionMatrices(P1).evaluate()
+        off.setProjectionMatrices(P1)
+        parts = [off.evaluate_range(bnd[r], bnd[r + 1] - bnd[r]) for r in range(3)]
+        assert a == (parts[0] + parts[1] + parts[2]) / 28, views
+    gm.close()
+    off.close()
+    g.close()
