@@ -101,6 +101,10 @@ def ref():
         R.ref_line_to_sample_dtr.restype = C.c_int
         R.ref_weighting.argtypes = [C.c_float]
         R.ref_weighting.restype = C.c_float
+        R.ref_gaussian_kernel.argtypes = [C.c_double, C.c_int, _f64p]
+        R.ref_lowpass2D.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_int]
+        R.ref_image_view_at.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double]
+        R.ref_image_view_at.restype = C.c_double
         _ref = R
     return _ref
 
@@ -290,6 +294,24 @@ def preprocess(img, P=None, **kw):
     if P is not None:
         L.eccor_cos_weight(out, n_u, n_v, _P(P))
     return out
+
+
+def gaussian_kernel(sigma, k):
+    """eccor_gaussian_kernel (ref: HeaderOnly/NRRD/nrrd_lowpass.hxx:19-34): 2k + 1 float64 taps."""
+    L = lib()
+    L.eccor_gaussian_kernel.argtypes = [C.c_double, C.c_int, _f64p]
+    out = np.zeros(2 * k + 1, np.float64)
+    L.eccor_gaussian_kernel(float(sigma), int(k), out)
+    return out
+
+
+def tex2d(img, x, y):
+    """eccor_tex2d: the normative un-normalised bilinear rule."""
+    L = lib()
+    L.eccor_tex2d.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.eccor_tex2d.restype = C.c_float
+    img = np.ascontiguousarray(img, np.float32)
+    return L.eccor_tex2d(img, img.shape[1], img.shape[0], float(x), float(y))
 
 
 def intrinsics(P):

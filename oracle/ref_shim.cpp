@@ -11,6 +11,8 @@
 #include <cmath>
 #include <LibUtilsCuda/culaut/xprojectionmatrix.hxx>
 #include <LibEpipolarConsistency/EpipolarConsistencyCommon.hxx>
+#include <NRRD/nrrd_image.hxx>
+#include <NRRD/nrrd_lowpass.hxx>
 
 #define REF_API extern "C" __attribute__((visibility("default")))
 
@@ -46,4 +48,26 @@ REF_API int ref_line_to_sample_dtr(float* line, float range_t)
 REF_API float ref_weighting(float x)
 {
 	return weighting<float>(x);
+}
+
+// ---- the pre-processing low-pass and the host image interpolation (header-only NRRD library) ----
+// ref: HeaderOnly/NRRD/nrrd_lowpass.hxx:19-34 (gaussianKernel)
+REF_API void ref_gaussian_kernel(double sigma, int k, double* kernel)
+{
+	std::vector<double> g = NRRD::gaussianKernel(sigma, k);
+	for (size_t i = 0; i < g.size(); i++) kernel[i] = g[i];
+}
+
+// ref: HeaderOnly/NRRD/nrrd_lowpass.hxx:183-190 (lowpass2D -> convolve2D :45-79), in place on the caller's image
+REF_API void ref_lowpass2D(float* img, int w, int h, double sigma, int k)
+{
+	NRRD::ImageView<float> view(w, h, 1, img);
+	NRRD::lowpass2D(view, sigma, k);
+}
+
+// ref: HeaderOnly/NRRD/nrrd_image_view.hxx:189-210 (ImageView::operator()(double, double, double)), 2D
+REF_API double ref_image_view_at(float* img, int w, int h, double x, double y)
+{
+	NRRD::ImageView<float> view(w, h, 1, img);
+	return view(x, y);
 }

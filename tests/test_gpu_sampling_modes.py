@@ -104,3 +104,49 @@ def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan, monkeypatch):
     assert np.array_equal(a[1], b[1])
     m0.close()
     m1.close()
+
+
+def test_auto_resolves_from_the_evaluation_not_the_shard(gpu_ctx):
+    """ECC_SAMPLING_AUTO is a function of the size of the EVALUATION (n (n - 1) / 2 for evaluate_all and every range /
+    shard of it): 40 views = 780 pairs -> polynomial, although every one of three shards has fewer than 512 pairs; a
+    group of three ranks with the default mode therefore returns the rank-ordered sum of polynomial shard sums, and
+    moving a shard boundary across 512 pairs changes nothing."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    rng = np.random.default_rng(5)
+    n, S, B = 40, 128, 64
+    Ps = synthetic.short_scan(n, S, S, 0.308 * 1024 / S)
+    base = [E.RadonIntermediate.from_host(gpu_ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(4)]
+    dtrs = [base[v % 4] for v in range(n)]
+    auto = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("auto")
+    poly = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("polynomial")
+    ref = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("reference")
+    n_pairs = n * (n - 1) // 2
+    assert n_pairs > 512
+    for first, count in ((0, 260), (260, 260), (520, 260), (0, 511), (0, 513), (100, 1), (0, n_pairs)):
+        a, va = auto.evaluate_range(first, count, want_pairs=True)
+        b, vb = poly.evaluate_range(first, count, want_pairs=True)
+        c, vc = ref.evaluate_range(first, count, want_pairs=True)
+        assert a == b and np.array_equal(va, vb), (first, count)
+        assert not np.array_equal(va, vc)  # the other arithmetic really is different at these sizes
+    # index lists resolve from the list's length: 2 pairs -> the reference arithmetic
+    idx = [(0, 5, 0, 5), (2, 30, 2, 30)]
+    assert auto.evaluate(idx) == ref.evaluate(idx)
+    # the single-process group with the library default (AUTO) on every rank
+    saved = E.MetricRadonIntermediate.default_sampling
+    E.MetricRadonIntermediate.default_sampling = None
+    try:
+        g = E.Group([0, 0, 0])
+        gm = E.GroupMetricRadonIntermediate(g, Ps, dtrs)
+        bnd = poly.balanced_shards(3)
+        parts = [poly.evaluate_range(bnd[r], bnd[r + 1] - bnd[r]) for r in range(3)]
+        assert min(bnd[r + 1] - bnd[r] for r in range(3)) < 512
+        assert gm.evaluate() == (parts[0] + parts[1] + parts[2]) / n_pairs
+        gm.close()
+        g.close()
+    finally:
+        E.MetricRadonIntermediate.default_sampling = saved
+    for m in (auto, poly, ref):
+        m.close()
+    for d in base:
+        d.close()

@@ -4,6 +4,11 @@
     LibUtilsCuda/culaut/*.hxx) -- E1/E2 geometry, bit for bit in float32;
   * against the known-answer scalars of the example pair recorded in SURVEY.md 8c;
   * against residual KATs in the style of the reference's disabled TestCudaUtils.cpp:39-57.
+  * the pre-processing low-pass (Gaussian taps and the separable convolution with its dropped last tap) and the host
+    image interpolation against the reference's header-only NRRD library (nrrd_lowpass.hxx, nrrd_image_view.hxx),
+    compiled into the same oracle/_ref/libecc_ref.so -- bit for bit;
+  * the NORMATIVE variant 0 of the oracle (what every GPU test is held to) against the PINNED variant 2 at the level
+    of the metric (64-view short scan): the two differ only by the rounding of four elementary functions.
 The kernel bodies R1/E3 have no reference vectors (parity unpinned, see oracle header): they are
 covered by property tests (test_oracle_properties.py) and committed goldens (test_golden.py).
 """
@@ -136,3 +141,77 @@ def test_normative_variant_differs_only_by_elementary_function_rounding(oracle_m
     assert np.array_equal(K0[:7], L0[:7]) and np.array_equal(K1[:6], L1[:6])
     np.testing.assert_allclose(K0[7], L0[7], rtol=2e-7)
     np.testing.assert_allclose(K1[6:], L1[6:], rtol=2e-7)
+
+
+def test_gaussian_kernel_matches_reference_bitwise(oracle_mod):
+    """eccor_gaussian_kernel vs NRRD::gaussianKernel (ref: HeaderOnly/NRRD/nrrd_lowpass.hxx:19-34)."""
+    r = _need_ref(oracle_mod)
+    for sigma, k in ((1.84, 5), (1.0, 2), (0.7, 1), (3.3, 9), (2.5, 12), (10.0, 3)):
+        want = np.zeros(2 * k + 1, np.float64)
+        r.ref_gaussian_kernel(sigma, k, want)
+        got = oracle_mod.gaussian_kernel(sigma, k)
+        assert np.array_equal(got, want), (sigma, k)
+        assert abs(want.sum() - 1.0) < 1e-15
+
+
+def test_lowpass_stage_matches_reference_bitwise(oracle_mod):
+    """The low-pass stage of eccor_preprocess vs NRRD::lowpass2D (ref: nrrd_lowpass.hxx:183-190 -> convolve2D :45-79:
+    both passes run o = -k .. k-1 -- the last tap is dropped --, both use kernelx, float64 sums rounded to float per
+    pass, clamp addressing).  Every other stage of the pre-processing is switched off; images are non-negative so the
+    intensity stage (x * 1 + 0, negatives to zero) is the identity."""
+    r = _need_ref(oracle_mod)
+    rng = np.random.default_rng(21)
+    for (h, w), sigma, k in (((50, 70), 1.84, 5), ((33, 17), 1.0, 2), ((7, 9), 2.5, 6), ((64, 64), 0.8, 3), ((5, 40), 1.84, 5)):
+        img = rng.uniform(0, 100, (h, w)).astype(np.float32)
+        img[rng.integers(0, h, 3), rng.integers(0, w, 3)] = 1e4  # isolated peaks: every tap position matters
+        want = img.copy()
+        r.ref_lowpass2D(want, w, h, sigma, k)
+        got = oracle_mod.preprocess(img, gaussian_sigma=sigma, half_kernel_width=k, zero=(0,) * 4, feather=(0,) * 4)
+        assert np.array_equal(got, want), (h, w, sigma, k)
+        assert not np.array_equal(got, img)
+
+
+def test_tex2d_matches_reference_image_view_where_the_rules_coincide(oracle_mod):
+    """eccor_tex2d (texel centres at i + 0.5, float32) vs NRRD::ImageView::operator()(x, y) (texel centres at integers,
+    float64; ref: HeaderOnly/NRRD/nrrd_image_view.hxx:189-210) at coordinates where both are exact: integer-valued
+    texels, fractions that are multiples of 1/8, positions inside [0, n - 1] (the reference truncates negative
+    coordinates towards zero and extrapolates there; the texture rule clamps)."""
+    r = _need_ref(oracle_mod)
+    rng = np.random.default_rng(4)
+    h, w = 13, 17
+    img = rng.integers(-500, 500, (h, w)).astype(np.float32)
+    n = 0
+    for y8 in range(0, 8 * (h - 1) + 1, 3):
+        for x8 in range(0, 8 * (w - 1) + 1, 5):
+            x, y = x8 / 8.0, y8 / 8.0
+            want = r.ref_image_view_at(img, w, h, x, y)
+            got = oracle_mod.tex2d(img, x + 0.5, y + 0.5)
+            assert float(got) == want, (x, y, got, want)
+            n += 1
+    assert n > 500
+    # on the texel centres themselves both return the texel
+    for (i, j) in ((0, 0), (w - 1, h - 1), (3, 7), (w - 1, 0)):
+        assert oracle_mod.tex2d(img, i + 0.5, j + 0.5) == img[j, i] == r.ref_image_view_at(img, w, h, float(i), float(j))
+
+
+def test_normative_and_pinned_variant_agree_on_the_metric(oracle_mod):
+    """Config-2 geometry (64-view short scan) with small images: the mean over all 2016 pairs of the
+    normative variant 0 (correctly rounded sinf / cosf / atan2f / asinf; what the GPU is compared with) and of variant 2
+    (the platform's float libm; the one pinned bit for bit against the reference's headers above) agree to 5e-6
+    relative, and single pairs to the fp32 noise floor of the sample positions."""
+    from epipolarconsistency_amd import synthetic
+    n, S, B = 64, 128, 96
+    Ps = synthetic.short_scan(n, S, S, 0.616 * 512 / S)
+    imgs = synthetic.projections_numpy(Ps, S, S, synthetic.sphere_phantom())
+    dtrs = [oracle_mod.radon(im, B, B) for im in imgs]
+    a = oracle_mod.evaluate_all(Ps, dtrs, S, S)
+    oracle_mod.set_variant(2)
+    try:
+        b = oracle_mod.evaluate_all(Ps, dtrs, S, S)
+    finally:
+        oracle_mod.set_variant(0)
+    assert len(a["pairs"]) == 2016
+    assert abs(a["mean"] - b["mean"]) <= 5e-6 * abs(a["mean"]), (a["mean"], b["mean"])
+    assert a["mean"] != b["mean"] or np.array_equal(a["pairs"], b["pairs"])
+    np.testing.assert_allclose(a["pairs"], b["pairs"], rtol=2e-3)
+    assert np.median(np.abs(a["pairs"] - b["pairs"]) / np.abs(a["pairs"])) < 5e-5
