@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libecc_hip.so")
+# ECC_HIP_LIB: another build of the same library (scripts/sanitize.sh: host code under UndefinedBehaviorSanitizer)
+LIB_PATH = os.environ.get("ECC_HIP_LIB") or os.path.join(_HERE, "libecc_hip.so")
 
 ECC_OK = 0
 FILTER_DERIVATIVE, FILTER_RAMP, FILTER_NONE = 0, 1, 2

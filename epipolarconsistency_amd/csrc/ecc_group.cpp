@@ -28,117 +28,33 @@
 #include <vector>
 
 #include "../../include/ecc_hip.h"
+#include "ecc_worker_pool.h"
 
 #define ECC_EXPORT extern "C" __attribute__((visibility("default")))
 
 int ecc_set_error(int code, const char* msg);  // ecc_capi.hip: records the message for ecc_last_error()
 
-namespace {
-
-inline void cpu_relax()
-{
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#endif
-}
-
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-}  // namespace
-
 struct ecc_group {
     std::vector<int> devices;
     std::vector<ecc_ctx*> ctxs;
     std::vector<hipStream_t> streams;
-    // job hand-off to the workers of ranks 1..n-1
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<uint64_t> job_generation{0};
-    std::atomic<int> remaining{0};
-    std::atomic<int> sleepers{0};
-    std::atomic<bool> quit{false};
-    std::function<int(int)> job;  // rank -> status
-    std::vector<int> rc;
-    std::vector<std::string> err;
+    EccWorkerPool pool;  // job hand-off to the workers of ranks 1..n-1 (ecc_worker_pool.h)
 
     int size() const { return (int)devices.size(); }
 };
 
 namespace {
 
-void run_rank(ecc_group* g, int rank)
-{
-    int rc = ECC_OK;
-    try {
-        rc = g->job(rank);
-    } catch (const std::exception& e) {
-        rc = ECC_ERR_HIP;
-        g->err[rank] = e.what();
-        g->rc[rank] = rc;
-        return;
-    }
-    g->rc[rank] = rc;
-    if (rc != ECC_OK) g->err[rank] = ecc_last_error();  // thread-local in the library: copy it out of the worker
-}
-
-void worker_main(ecc_group* g, int rank)
-{
-    (void)hipSetDevice(g->devices[rank]);
-    uint64_t seen = 0;
-    for (;;) {
-        // spin ~100 us for the next job (an optimiser calls back within that), then sleep
-        const double t0 = now_s();
-        unsigned spins = 0;
-        while (g->job_generation.load(std::memory_order_acquire) == seen && !g->quit.load(std::memory_order_acquire)) {
-            cpu_relax();
-            if ((++spins & 0xff) == 0 && now_s() - t0 > 100e-6) {
-                std::unique_lock<std::mutex> lk(g->mu);
-                g->sleepers.fetch_add(1);
-                g->cv.wait(lk, [&] { return g->job_generation.load() != seen || g->quit.load(); });
-                g->sleepers.fetch_sub(1);
-            }
-        }
-        if (g->quit.load(std::memory_order_acquire)) return;
-        seen = g->job_generation.load(std::memory_order_acquire);
-        run_rank(g, rank);
-        g->remaining.fetch_sub(1, std::memory_order_release);
-    }
-}
-
 // Runs job(rank) for every rank (rank 0 on the calling thread) and returns the first failure, its message recorded
 // for ecc_last_error() on the calling thread.
 int run_all(ecc_group* g, std::function<int(int)> job)
 {
-    const int n = g->size();
-    g->job = std::move(job);
-    for (int r = 0; r < n; ++r) {
-        g->rc[r] = ECC_OK;
-        g->err[r].clear();
-    }
-    if (n > 1) {
-        g->remaining.store(n - 1, std::memory_order_relaxed);
-        {
-            // the generation changes under the mutex so that a worker about to sleep cannot miss it
-            std::lock_guard<std::mutex> lk(g->mu);
-            g->job_generation.fetch_add(1, std::memory_order_release);
-        }
-        if (g->sleepers.load() > 0) g->cv.notify_all();
-    }
-    run_rank(g, 0);
-    if (n > 1) {
-        unsigned spins = 0;
-        while (g->remaining.load(std::memory_order_acquire) != 0) {
-            cpu_relax();
-            if ((++spins & 0xffff) == 0) std::this_thread::yield();
-        }
-    }
+    const int bad = g->pool.run_all(std::move(job), ECC_ERR_HIP);
     (void)hipSetDevice(g->devices[0]);
-    for (int r = 0; r < n; ++r)
-        if (g->rc[r] != ECC_OK) {
-            const std::string msg = "rank " + std::to_string(r) + " (device " + std::to_string(g->devices[r]) + "): " + g->err[r];
-            return ecc_set_error(g->rc[r], msg.c_str());
-        }
+    if (bad >= 0) {
+        const std::string msg = "rank " + std::to_string(bad) + " (device " + std::to_string(g->devices[bad]) + "): " + g->pool.message(bad);
+        return ecc_set_error(g->pool.status(bad), msg.c_str());
+    }
     return ECC_OK;
 }
 
@@ -165,8 +81,6 @@ ECC_EXPORT int ecc_group_create(int n_dev, const int* devices, ecc_group** out)
         if (d < 0 || d >= visible) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "device index out of range");
         g->devices.push_back(d);
     }
-    g->rc.assign(n_dev, ECC_OK);
-    g->err.assign(n_dev, std::string());
     int rc = ECC_OK;
     for (int r = 0; r < n_dev && rc == ECC_OK; ++r) {
         hipStream_t s = nullptr;
@@ -200,7 +114,7 @@ ECC_EXPORT int ecc_group_create(int n_dev, const int* devices, ecc_group** out)
         return rc;
     }
     ecc_group* raw = g.release();
-    for (int r = 1; r < n_dev; ++r) raw->workers.emplace_back(worker_main, raw, r);
+    raw->pool.start(n_dev, [raw](int r) { (void)hipSetDevice(raw->devices[r]); }, [] { return std::string(ecc_last_error()); });
     (void)hipSetDevice(raw->devices[0]);
     *out = raw;
     return ECC_OK;
@@ -209,12 +123,7 @@ ECC_EXPORT int ecc_group_create(int n_dev, const int* devices, ecc_group** out)
 ECC_EXPORT int ecc_group_destroy(ecc_group* g)
 {
     if (!g) return ECC_OK;
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->quit.store(true, std::memory_order_release);
-    }
-    g->cv.notify_all();
-    for (std::thread& t : g->workers) t.join();
+    g->pool.stop();
     for (ecc_ctx* c : g->ctxs) ecc_ctx_destroy(c);
     for (size_t r = 0; r < g->streams.size(); ++r) {
         (void)hipSetDevice(g->devices[r]);

@@ -23,7 +23,7 @@ def build(native=False):
 
 
 def _load(name, native=False):
-    path = os.path.join(_HERE, name)
+    path = os.environ.get("ECC_ORACLE_LIB") or os.path.join(_HERE, name)  # override: the sanitizer build (scripts/sanitize.sh)
     if not os.path.exists(path):
         build(native=native)
     return C.CDLL(path)
