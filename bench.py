@@ -40,6 +40,7 @@ ENGINE_CLOCK_GHZ = 2.4      # peak engine clock; the pair kernel runs at ~2.1 GH
 N_CU, SIMD_PER_CU = 256, 4
 L1_BYTES_PER_CLK_CU = 64.0  # a 16-byte-per-lane gather occupies the CU's vector L1 for 16 cycles (profiles/r01_gather_rate.txt)
 LDS_READ2_B32_BYTES_PER_CLK_CU = 128.0  # ds_read2_b32 / ds_read_b32: 128 B/clk/CU (the guide's LDS table)
+LDS_READ_B64_BYTES_PER_CLK_CU = 256.0   # ds_read_b64 / b128: 256 B/clk/CU
 VALU_CYCLES_PER_WAVE_INSTR = 2.0        # wave64 fp32 instruction on a SIMD-32: 2 cycles (4 for cvt/fract/f64, not modelled)
 
 
@@ -130,7 +131,8 @@ def live_pmc(args):
         return None
     # already running under a profiler (scripts/pmc_pass.sh, profile_round.sh): its preloaded tool library would be
     # inherited by the child pass, whose launcher then execs from a GPU-initialised process -- do not nest
-    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or \
+            any(k.startswith(("ROCP", "ROCPROF", "ROCTX")) for k in os.environ):
         return None
     out_dir = tempfile.mkdtemp(prefix="ecc_pmc_", dir="/tmp")
     try:
@@ -529,31 +531,42 @@ def main():
                                     "reuse_factor_vs_hbm_peak": achieved / HBM_PEAK_GBS}}
 
     # ---- second headline metric: ms per Radon intermediate ---------------------------------------------------
+    # The Radon kernel reads its bilinear footprints from an LDS tile of texel pairs with ds_read_b64 (2 per fetch,
+    # 16 B); since round 3 its binding roof is vector-ALU issue, not the LDS pipe.  `frac` is the binding roof's
+    # fraction; the algorithmic LDS bytes are priced against both LDS rates for continuity with rounds 1-2.
     fetches = radon_fetches_per_image(S, S, B, B)
-    lds_peak = LDS_READ2_B32_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ
+    lds_peak_b32 = LDS_READ2_B32_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ
+    lds_peak_b64 = LDS_READ_B64_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ
     lds_ach = 16.0 * fetches / (ms_per_radon * 1e-3) / 1e9 if ms_per_radon > 0 else 0.0
-    roofline_radon = {"bound": "lds", "achieved": lds_ach, "peak": lds_peak, "unit": "GB/s", "frac": lds_ach / lds_peak,
-                      "kernel": "radon_kernel<true>", "kernel_ms_per_image": ms_per_radon,
+    roofs_r = {"lds_algorithmic_b64": {"achieved": lds_ach, "peak": lds_peak_b64, "unit": "GB/s", "frac": lds_ach / lds_peak_b64,
+                                       "note": "16 B per bilinear fetch (2 x ds_read_b64) against %.0f B/clk/CU x %d CUs x %.1f GHz"
+                                               % (LDS_READ_B64_BYTES_PER_CLK_CU, N_CU, ENGINE_CLOCK_GHZ)},
+               "lds_algorithmic_b32": {"achieved": lds_ach, "peak": lds_peak_b32, "unit": "GB/s", "frac": lds_ach / lds_peak_b32,
+                                       "note": "the same bytes against the ds_read2_b32 rate (128 B/clk/CU) rounds 1-2 were priced on"}}
+    roofline_radon = {"kernel": "radon_kernel<true>", "kernel_ms_per_image": ms_per_radon,
                       "algorithmic_bytes_per_image": 16 * fetches, "bilinear_fetches_per_image": fetches,
-                      "note": "16 B of LDS reads per bilinear fetch (2 x ds_read2_b32) against %.0f B/clk/CU x %d CUs x %.1f GHz; "
-                              "compulsory HBM bytes are 4 (n_u n_v + n_alpha n_t) = %.2f MB per image"
-                              % (LDS_READ2_B32_BYTES_PER_CLK_CU, N_CU, ENGINE_CLOCK_GHZ, 4e-6 * (S * S + B * B))}
+                      "compulsory_hbm_bytes_per_image": 4 * (S * S + B * B)}
     rp = load_pmc("radon_kernel<true>") if (S, B) == (1024, 768) else None
     if rp and rp.get("SQ_LDS_IDX_ACTIVE"):
         roofline_radon["lds_bank_conflict_ratio"] = rp["SQ_LDS_BANK_CONFLICT"] / rp["SQ_LDS_IDX_ACTIVE"]
-        roofline_radon["pmc_source"] = "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/pmc_current.json (%s)" % rp["_tag"]
-        # the committed passes profile this bench, whose Radon launches are `sub` = 50 images each
+        roofline_radon["pmc_source"] = ("SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU per 50-image launch: separate rocprofv3 --pmc "
+                                        "passes, profiles/pmc_current.json (%s); not this run" % rp["_tag"])
+        # the committed passes profile launches of `sub` = 50 images each
         img_s = ms_per_radon * 1e-3
-        roofs_r = {"lds_algorithmic": {"frac": roofline_radon["frac"], "note": "conflict-free 16 B per fetch"},
-                   "lds_pipe_active": {"frac": rp["SQ_LDS_IDX_ACTIVE"] / sub / (N_CU * ENGINE_CLOCK_GHZ * 1e9 * img_s),
-                                       "note": "SQ_LDS_IDX_ACTIVE cycles per image / (256 CUs x 2.4 GHz x seconds per image): "
-                                               "bank conflicts included"}}
+        roofs_r["lds_pipe_active"] = {"frac": rp["SQ_LDS_IDX_ACTIVE"] / sub / (N_CU * ENGINE_CLOCK_GHZ * 1e9 * img_s),
+                                      "note": "SQ_LDS_IDX_ACTIVE cycles per image / (256 CUs x 2.4 GHz x seconds per image): bank "
+                                              "conflicts included"}
         if rp.get("SQ_INSTS_VALU"):
-            valu_peak = N_CU * SIMD_PER_CU * ENGINE_CLOCK_GHZ * 1e9 / VALU_CYCLES_PER_WAVE_INSTR
-            roofs_r["valu"] = {"frac": rp["SQ_INSTS_VALU"] / sub / img_s / valu_peak,
-                               "note": "SQ_INSTS_VALU per image at 2 cycles per wave64 instruction on 1024 SIMDs"}
-        roofline_radon["roofs"] = roofs_r
-        roofline_radon["binding"] = max(roofs_r, key=lambda r: roofs_r[r]["frac"])
+            valu_peak = N_CU * SIMD_PER_CU * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTR  # G wave-instructions/s
+            valu_ach = rp["SQ_INSTS_VALU"] / sub / img_s / 1e9
+            roofs_r["valu"] = {"achieved": valu_ach, "peak": valu_peak, "unit": "G wave-instr/s", "frac": valu_ach / valu_peak,
+                               "note": "SQ_INSTS_VALU = %.4g per image at 2 cycles per wave64 instruction on 1024 SIMDs (the 4-cycle "
+                                       "v_floor_f32 count as 2: a lower bound of the pipe's occupancy)" % (rp["SQ_INSTS_VALU"] / sub)}
+    binding = max(roofs_r, key=lambda r: roofs_r[r]["frac"] if r != "lds_algorithmic_b32" else -1.0)
+    roofline_radon.update({"bound": {"valu": "valu", "lds_pipe_active": "lds"}.get(binding, "lds"), "binding": binding,
+                           "achieved": roofs_r[binding].get("achieved"), "peak": roofs_r[binding].get("peak"),
+                           "unit": roofs_r[binding].get("unit"), "frac": roofs_r[binding]["frac"], "traffic": None,
+                           "roofs": roofs_r})
 
     out = {
         "metric": "ECC evaluations/sec (N=%d, %d^2 projections)" % (n, S),
@@ -581,6 +594,9 @@ def main():
                    "k01_record_reuse": "on (library default); the same run with it off under timing.record_reuse_off",
                    "ranks_seen_by_collective_backend": ranks_seen, "devices": devices_seen},
         "timing": {"value_is": "median of %d blocks of %d steps" % (len(res["blocks"]), args.steps),
+                   # round 1's definition of the headline: all timed steps of the run over all their time
+                   "whole_run": {"ms_per_step": 1e3 * sum(res["blocks"]) / (args.steps * len(res["blocks"])),
+                                 "value": args.steps * len(res["blocks"]) / sum(res["blocks"])},
                    "blocks_ms_per_step": [1e3 * b / args.steps for b in res["blocks"]],
                    "cold": {"ms_per_step": 1e3 * res["cold"] / args.steps, "value": args.steps / res["cold"],
                             "note": "first block after the %d warm-up steps" % args.warmup},

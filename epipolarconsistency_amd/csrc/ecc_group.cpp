@@ -377,8 +377,8 @@ int group_evaluate(ecc_group_metric* gm, const double* Ps, int n_views, float* c
         int e = ECC_OK;
         if (P) {
             double radius = 0;
-            ecc_metric_set_projections(gm->metrics[0], P, n_views);  // rank 0 knows the matrices for the radius estimate
-            e = ecc_metric_get_object_radius(gm->metrics[0], &radius);
+            e = ecc_metric_set_projections(gm->metrics[0], P, n_views);  // rank 0 knows the matrices for the radius estimate
+            if (e == ECC_OK) e = ecc_metric_get_object_radius(gm->metrics[0], &radius);
             if (e == ECC_OK) e = ecc_pair_shards_balanced(P, n_views, radius, G, b.data());
         } else {
             e = ecc_metric_balanced_shards(gm->metrics[0], G, b.data());
@@ -429,9 +429,9 @@ ECC_EXPORT int ecc_group_metric_evaluate_poses(ecc_group_metric* gm, int n_poses
         }
         return ECC_OK;
     });
-    // the ranks' metrics now hold different matrices: the next sharded evaluation must hand them over again
-    if (gm->n_views == n_views && !gm->pending_Ps.empty()) gm->pending = true;
-    else if (gm->n_views != n_views) gm->n_views = 0;
+    // the ranks' metrics now hold the poses' matrices: the matrices of the last ecc_group_metric_set_projections stay the
+    // group's current ones (as the header says) and are handed over again by the next sharded evaluation
+    if (!gm->pending_Ps.empty()) gm->pending = true;
     return rc;
 }
 

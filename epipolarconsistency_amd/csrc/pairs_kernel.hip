@@ -1420,6 +1420,11 @@ namespace {
 // Hand-off between workgroups as the CDNA4 guide prescribes for it (MI355X_MICROARCH.md, "Valid forms"): the partial is an
 // agent-scope (sc1, write-through) store, the storing lane drains it (s_waitcnt vmcnt(0)) before its agent-scope ticket
 // add, the last arriver -- told by the value its add returned -- reads the partials with agent-scope (sc1) loads.
+// That hand-off is what gfx950's code generation of these operations guarantees, not what the C++ memory model does for
+// relaxed atomics: the kernel is tied to the target it was written and measured for.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "sum_pairs_split_kernel's cross-workgroup hand-off is specified for gfx950 only"
+#endif
 constexpr int SUM_BLOCKS = 16;
 struct SumScratch {
     double partial[SUM_BLOCKS];

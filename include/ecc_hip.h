@@ -233,6 +233,10 @@ int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);
 /* All-pairs evaluate, ref: double MetricRadonIntermediate::evaluate(float* out)
  * (…RadonIntermediate.cpp:166-225) = K01 + pair kernel + host mean.  cost_nxn (host, nullable) is
  * read-modify-written exactly like the reference's `out`.  *mean = sum_pairs / n_pairs. */
+/* The float64 sum over the pair values has a fixed order for a given number of values (the same bits every run), but the
+ * order is a function of that number: up to 32 767 values one workgroup adds them, from 32 768 on sixteen workgroups add
+ * contiguous slices and the slice sums are added in slice order.  A sum over G shards is the rank-ordered sum of G such
+ * sums.  So one-device and sharded sums of the same pair values agree to float64 rounding (~1e-16), not bit for bit. */
 int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean);
 
 /* Multi-GPU building block: evaluate only pairs ij in [first, first+count) of the get_ij order
