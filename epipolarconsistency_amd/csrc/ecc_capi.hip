@@ -209,6 +209,11 @@ struct ecc_metric {
     bool reuse_ev_used[2] = {false, false};
     uint64_t reuse_gen = 0;
     std::vector<int32_t> scratch_refs;
+    std::vector<int32_t> scratch_patch_of;
+    // second stream of the reuse path: refit + list launch of the changed pairs run there while the all-pairs launch
+    // (which skips them) already runs on the context's stream
+    hipStream_t side_stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
 };
 
 namespace {
@@ -958,6 +963,12 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
         if (m->reuse_h[b]) (void)hipHostFree(m->reuse_h[b]);
         if (m->reuse_ev[b]) (void)hipEventDestroy(m->reuse_ev[b]);
     }
+    if (m->side_stream) {
+        (void)hipStreamSynchronize(m->side_stream);
+        (void)hipStreamDestroy(m->side_stream);
+    }
+    if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
+    if (m->join_ev) (void)hipEventDestroy(m->join_ev);
     delete m;
     return ECC_OK;
 }
@@ -1190,16 +1201,46 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                            m->rec_n_views == (int)n && m->rec_mode == mode && m->rec_radius == p.object_radius_mm &&
                            m->rec_dkappa == p.dkappa_user && m->rec_tol == p.economise_tol && (int64_t)m->rec_Ps.size() == 12 * n;
     m->rec_valid = false;  // until everything below is enqueued
+    bool pairs_launched = false;
     if (rec_match) {
         std::vector<int>& changed = m->scratch_changed;
         changed.clear();
         for (int64_t v = 0; v < n; ++v)
             if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
         if ((int64_t)changed.size() * 4 <= n) {
+            const int64_t C = (int64_t)changed.size();
+            // Two streams: the all-pairs launch that SKIPS the pairs of the changed views starts at once on the context's
+            // stream; the refit of those pairs and their own list launch follow on the metric's side stream, hidden behind
+            // it; the sum waits for both.  (Not with a cost image -- the list launch does not write it --, not in the
+            // reference arithmetic -- evaluations of at most 512 pairs --, not beyond 512 views: the skip set is a
+            // 512-bit kernel argument.)
+            bool split = C > 0 && !cost_d && !p.reference_arithmetic && n <= 32 * ECC_SKIP_WORDS;
+            if (split && !m->side_stream) {
+                if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipGetLastError();
+                    split = false;
+                }
+            }
+            if (split) {
+                // whatever the caller queued on the context's stream before this call comes first for the side stream too
+                HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
+                EccPairParams pa = p;
+                pa.skip_enabled = 1;
+                for (int v : changed) pa.skip_mask[v >> 5] |= 1u << (v & 31);
+                if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+                HIP_TRY(ecc_launch_pairs(&pa, ctx->stream));
+                if (ctx->timing) {
+                    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+                    ctx->ev_valid[0] = true;
+                }
+                pairs_launched = true;
+            }
             std::vector<char>& is_changed = m->scratch_is_changed;
-            std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots, &refs = m->scratch_refs;
+            std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots, &refs = m->scratch_refs, &patch_of = m->scratch_patch_of;
             is_changed.assign((size_t)n, 0);
-            std::vector<int32_t> patch_of((size_t)n, -1);
+            patch_of.assign((size_t)n, -1);
             for (size_t e = 0; e < changed.size(); ++e) {
                 is_changed[changed[e]] = 1;
                 patch_of[changed[e]] = (int32_t)e;
@@ -1218,14 +1259,14 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                     refs.push_back(patch_of[i]);
                     refs.push_back(patch_of[j]);
                 }
-            const int64_t L = (int64_t)slots.size(), C = (int64_t)changed.size();
+            const int64_t L = (int64_t)slots.size();
             const int b = (int)(m->reuse_gen++ & 1);
             // L = 0 (no pair of this range contains a changed view): nothing to refit and nothing launched; rec_Ps keeps
             // the old matrices of those views, which is what PinvTs / Cs on the device still correspond to
             if (L > 0) {
                 rc = ensure_reuse_list(m, b, 7 * L + 17 * C);
                 if (rc) return rc;
-                if (m->reuse_ev_used[b]) {  // an asynchronous caller: the launch that read this buffer two calls ago
+                if (m->reuse_ev_used[b]) {  // an asynchronous caller: the launches that read this buffer two calls ago
                     HIP_TRY(hipEventSynchronize(m->reuse_ev[b]));
                     m->reuse_ev_used[b] = false;
                 }
@@ -1251,10 +1292,19 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 q.count = L;
                 q.cost = nullptr;
                 q.pair_values = nullptr;
-                HIP_TRY(ecc_launch_k01(&q, ctx->stream));
+                hipStream_t ks = split ? m->side_stream : ctx->stream;
+                if (split) HIP_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
+                HIP_TRY(ecc_launch_k01(&q, ks));
+                if (split) {  // the changed pairs' own launch: records and values in their slots
+                    q.pair_values = pair_values_d;
+                    q.value_slots = q.record_slots;
+                    HIP_TRY(ecc_launch_pairs(&q, m->side_stream));
+                    HIP_TRY(hipEventRecord(m->join_ev, m->side_stream));
+                    HIP_TRY(hipStreamWaitEvent(ctx->stream, m->join_ev, 0));
+                }
                 if (!synchronous) {
                     if (!m->reuse_ev[b]) HIP_TRY(hipEventCreateWithFlags(&m->reuse_ev[b], hipEventDisableTiming));
-                    HIP_TRY(hipEventRecord(m->reuse_ev[b], ctx->stream));
+                    HIP_TRY(hipEventRecord(m->reuse_ev[b], ks));
                     m->reuse_ev_used[b] = true;
                 }
                 for (int v : changed) std::memcpy(m->rec_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
@@ -1280,11 +1330,13 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             m->rec_tol = p.economise_tol;
         }
     }
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
-    if (ctx->timing) {
-        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-        ctx->ev_valid[0] = true;
+    if (!pairs_launched) {
+        if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+        if (ctx->timing) {
+            HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+            ctx->ev_valid[0] = true;
+        }
     }
     if (sum_d) {
         if (count > 0) HIP_TRY(ecc_launch_sum_pairs(pair_values_d, count, sum_d, m->sum_scratch_d, ctx->stream));

@@ -61,6 +61,7 @@ struct EccRadonParams {
 // Degree of the per-pair, per-view polynomials xa(kappa), yd(kappa) on [-kappa_max, kappa_max] (see pairs_kernel.hip):
 // 11 coefficients each plus a low part of the constant term (the constant is ~n/2 bins; its float rounding alone
 // would shift a whole curve by up to 1.5e-5 bins).
+#define ECC_SKIP_WORDS 16
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
 
@@ -113,6 +114,10 @@ struct EccPairParams {
                                   // on the host (pinned memory: read over PCIe inside k01_kernel, no copy command)
     const int32_t* patch_views;   // view of each entry; the launch also copies the entries into PinvTs / Cs
     int patch_count;
+    // pairs_kernel over all pairs EXCEPT those that contain a view of this set (they are refitted and sampled by a list
+    // launch on a second stream meanwhile): bit v of skip_mask = view v changed; views < 32 * ECC_SKIP_WORDS
+    int skip_enabled;
+    unsigned skip_mask[16];
     const EccPolyTables* poly; // constant tables of the polynomial fit (null: exact path for every pair)
     int64_t first;             // first pair (get_ij order) handled by this launch
     int64_t count;             // pairs handled by this launch

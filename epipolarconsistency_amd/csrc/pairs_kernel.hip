@@ -946,14 +946,20 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
     // wave-uniform record -> SGPRs (readfirstlane makes the address provably uniform: scalar loads)
     local = ((long long)__builtin_amdgcn_readfirstlane((int)(local >> 32)) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane((int)local);
-    const EccPairRecord* __restrict__ rec = p.records + local;
+    // a list launch over records kept in their slots of an all-pairs array (record reuse): the slot comes from the list
+    const long long rec_index = p.record_slots ? (long long)__builtin_amdgcn_readfirstlane(p.record_slots[local]) : local;
+    const EccPairRecord* __restrict__ rec = p.records + rec_index;
+    const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
+    if (p.skip_enabled) {  // this pair is being refitted and sampled by the list launch on the second stream
+        const unsigned m0 = p.skip_mask[(iD0 >> 5) & (ECC_SKIP_WORDS - 1)], m1 = p.skip_mask[(iD1 >> 5) & (ECC_SKIP_WORDS - 1)];
+        if (((m0 >> (iD0 & 31)) | (m1 >> (iD1 & 31))) & 1u) return;
+    }
     float K0[8], K1[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         K0[i] = uniformf(rec->K0[i]);
         K1[i] = uniformf(rec->K1[i]);
     }
-    const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
     const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
 
     const unsigned pitch4 = (unsigned)p.pitch * 8u;  // row pitch of the paired copies in bytes

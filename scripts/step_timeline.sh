@@ -17,18 +17,22 @@ def short(n):
         if k in n: return k
     return None
 ours = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if short(r["Kernel_Name"])]
-# a step ends with a sum kernel; take the last 40 steps
-ends = [i for i, o in enumerate(ours) if o[0].startswith("sum_pairs")]
-ends = ends[-41:]
-dur, gap = collections.defaultdict(list), collections.defaultdict(list)
-for a, b in zip(ends, ends[1:]):
-    step = ours[a + 1:b + 1]
-    for k, (nm, s, e) in enumerate(step):
-        dur[nm].append((e - s) / 1e3)
-        prev = ours[a + k]
-        gap[prev[0] + " -> " + nm].append((s - prev[2]) / 1e3)
-    gap["step (sum end -> sum end)"].append((ours[b][2] - ours[a][2]) / 1e3)
-for k, v in dur.items(): print("kernel %-28s %8.1f us (median of %d)" % (k, st.median(v), len(v)))
-for k, v in gap.items(): print("gap    %-48s %8.1f us (median of %d)" % (k, st.median(v), len(v)))
+# a step ends with a sum kernel.  bench.py's timed blocks come first (record reuse as the library defaults), its
+# reuse-off blocks near the end (5 + 3 x 20 timed steps, the event-timed pass, then 5 + 3 x 20 steps with reuse off):
+# steps 10..60 are in the former, steps -70..-10 in the latter
+ends_all = [i for i, o in enumerate(ours) if o[0].startswith("sum_pairs")]
+for title, ends in (("library default (record reuse on)", ends_all[10:61]), ("ecc_metric_set_record_reuse(0)", ends_all[-70:-10])):
+    dur, gap = collections.defaultdict(list), collections.defaultdict(list)
+    for a, b in zip(ends, ends[1:]):
+        step = ours[a + 1:b + 1]
+        prev_end = ours[a][2]
+        for nm, s, e in step:
+            dur[nm].append((e - s) / 1e3)
+            gap["start of %s after the previous step's sum" % nm].append((s - prev_end) / 1e3)
+        gap["step (sum end -> sum end)"].append((ours[b][2] - prev_end) / 1e3)
+        gap["sum start after the end of the step's last other kernel"].append((ours[b][1] - max(e for nm, s, e in step[:-1])) / 1e3)
+    print("== " + title)
+    for k, v in dur.items(): print("kernel %-28s %8.1f us (median of %d)" % (k, st.median(v), len(v)))
+    for k, v in gap.items(): print("       %-66s %8.1f us (median of %d)" % (k, st.median(v), len(v)))
 PY
 rm -rf $out
