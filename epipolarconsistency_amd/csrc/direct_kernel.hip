@@ -23,6 +23,7 @@
 #include "ecc_host_geometry.h"
 #include "ecc_layout.h"
 #include "ecc_sampling.h"
+#include "ecc_slab_tile.h"
 
 namespace {
 
@@ -126,11 +127,19 @@ __global__ __launch_bounds__(256) void direct_pair_kernel(EccDirectParams p)
     p.pairs[local] = r;
 }
 
-// ref: EpipolarConsistencyDirect.cu:31-125 (kernel_computeLineIntegrals, fbcc_d == 0).  The reference's launcher
-// hands n_u over for both image sizes (:137); the evident intent (n_u, n_v) is implemented, identical for square
-// images (oracle/ecc_oracle.c does the same).
-__device__ float direct_line_integral(const float* __restrict__ img, int si, int sj, int n_u, int n_v, float l0, float l1,
-                                      float l2)
+// ---- line integrals (ref: EpipolarConsistencyDirect.cu:31-125, kernel_computeLineIntegrals) ---------------------
+// One thread per epipolar line, stepping 0.4 px along the clipped line and accumulating bilinear samples sequentially
+// in fp32 in the reference's order: the derivative form takes two samples half a pixel to either side of the line
+// (sump, summ), the fan-beam form one weighted sample.  A workgroup is 256 ADJACENT lines of one pair's pencil in one
+// image: they are nearly parallel (the epipole of a C-arm scan is far outside the image) and sweep a narrow band --
+// exactly the Radon kernel's situation, so the band is walked slab by slab through the LDS tile of texel pairs of
+// ecc_slab_tile.h instead of gathering from global memory (round 2: 64 lanes = 64 cache lines per load even with the
+// transposed image copy).  Same arithmetic per sample (ecc_sampling.h), bit-identical results.
+// The reference's launcher hands n_u over for both image sizes (:137); the evident intent (n_u, n_v) is implemented,
+// identical for square images (oracle/ecc_oracle.c does the same).
+
+// ref: EpipolarConsistencyDirect.cu:44-76 (line -> origin, direction, clipped parameter range)
+__device__ __forceinline__ ecc_slab::LineRun direct_line_run(float l0, float l1, float l2, int n_u, int n_v)
 {
     float o0 = -l2 * l0, o1 = -l2 * l1;
     const float d0 = l1, d1 = -l0;
@@ -147,99 +156,150 @@ __device__ float direct_line_integral(const float* __restrict__ img, int si, int
                 ts[i + 1] = tmp;
             }
     const float t_min = ts[1], t_max = ts[2];
-    {
-        const float u = o0 + t_min * d0, v = o1 + t_min * d1;
-        if (!(u <= n_u && v <= n_v && u >= 0 && v >= 0)) return 0.f;
-    }
-    const float step = 0.4f;
+    const float u = o0 + t_min * d0, v = o1 + t_min * d1;
+    const bool inside = (u <= n_u && v <= n_v && u >= 0 && v >= 0);  // else the reference returns 0 (:78-82)
     o0 += .5f;
     o1 += .5f;
-    l0 *= 0.5f;
-    l1 *= 0.5f;
-    float sump = 0, summ = 0;
-    // bounded: t_max - t_min <= the image diagonal for a line that passed the test above; a degenerate line
-    // (NaN) fails the loop condition at once
-    for (float t = t_min; t <= t_max; t += step) {
-        const float u = o0 + t * d0;
-        const float v = o1 + t * d1;
-        sump += ecc_tex_global_strided(img, n_u, n_v, si, sj, u + l0, v + l1) * step;
-        summ += ecc_tex_global_strided(img, n_u, n_v, si, sj, u - l0, v - l1) * step;
-    }
-    return sump - summ;
+    // a degenerate line (NaN) fails every loop condition; t_max - t_min <= the image diagonal otherwise
+    return ecc_slab::LineRun{o0, o1, d0, d1, t_min, t_max, inside};
 }
 
-// ref: EpipolarConsistencyDirect.cu:87-101 (the fbcc_d branch): rectified by weighting, no derivative.
-__device__ float direct_line_integral_fbcc(const float* __restrict__ img, int si, int sj, int n_u, int n_v, float l0,
-                                           float l1, float l2, const ecc_host::FbccInfo& fbcc)
-{
-    float o0 = -l2 * l0, o1 = -l2 * l1;
-    const float d0 = l1, d1 = -l0;
-    float ts[4] = {(1 - o0) / d0, (n_u - 1 - o0) / d0, (1 - o1) / d1, (n_v - 1 - o1) / d1};
-    if ((double)(d0 * d0) < 1e-12) ts[0] = -(ts[1] = 1e10f);
-    if ((double)(d1 * d1) < 1e-12) ts[2] = -(ts[3] = 1e10f);
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-            if (ts[i] > ts[i + 1]) {
-                const float tmp = ts[i];
-                ts[i] = ts[i + 1];
-                ts[i + 1] = tmp;
-            }
-    const float t_min = ts[1], t_max = ts[2];
+struct DirectDerivSums {  // ref: EpipolarConsistencyDirect.cu:103-113
+    float sump = 0.f, summ = 0.f;
+    __device__ __forceinline__ void add(float vA, float vB, float)
     {
-        const float u = o0 + t_min * d0, v = o1 + t_min * d1;
-        if (!(u <= n_u && v <= n_v && u >= 0 && v >= 0)) return 0.f;
+        sump += vA * 0.4f;
+        summ += vB * 0.4f;
     }
-    const float step = 0.4f;
-    o0 += .5f;
-    o1 += .5f;
-    float sum = 0;
-    for (float t = t_min; t <= t_max; t += step) {
+};
+struct DirectFbccSum {  // ref: EpipolarConsistencyDirect.cu:87-101 (the fbcc_d branch): rectified by weighting, no derivative
+    float sum = 0.f;
+    ecc_host::FbccInfo fbcc;
+    __device__ __forceinline__ void add(float vA, float, float t)
+    {
         const float u_prime = fbcc.transform(t) - fbcc.t_prime_ak;
         const float fbcc_weight = fbcc.derivative(t) / sqrtf(u_prime * u_prime + fbcc.d_l_kappa_C_sq);
-        sum += step * ecc_tex_global_strided(img, n_u, n_v, si, sj, o0 + t * d0, o1 + t * d1) * fbcc_weight;
+        sum += 0.4f * vA * fbcc_weight;
     }
-    return sum;
+};
+
+// The band of a workgroup's lines from four workgroup-wide extremes: the smallest / largest fast coordinate of any line
+// (both samples) at two reference slow coordinates.  Every line is linear in s, so between the references the band lies
+// within the interpolated extremes -- whatever the lines are (no pencil assumption); tight when they do not cross
+// inside the image.
+struct LinearBand {
+    float f0lo, f0hi, f1lo, f1hi, s0, inv_ds01, beta;
+    __device__ __forceinline__ void operator()(float sa, float sb, float& gmin, float& gmax) const
+    {
+        const float la = (sa - s0) * inv_ds01, lb = (sb - s0) * inv_ds01;
+        const float loa = f0lo + (f1lo - f0lo) * la - beta * sa, lob = f0lo + (f1lo - f0lo) * lb - beta * sb;
+        const float hia = f0hi + (f1hi - f0hi) * la - beta * sa, hib = f0hi + (f1hi - f0hi) * lb - beta * sb;
+        gmin = fminf(loa, lob);
+        gmax = fmaxf(hia, hib);
+    }
+};
+
+template <bool TRANSP>
+__device__ __forceinline__ float direct_lines_body(const EccDirectParams& p, ecc_slab::Shared& sh, const float* img,
+                                                   const float* imgT, ecc_slab::LineRun& ln, float lh0, float lh1, float sigma,
+                                                   float beta0, const ecc_host::FbccInfo* fbcc)
+{
+    using namespace ecc_slab;
+    const int W = p.n_u, H = p.n_v;
+    const int Ns = TRANSP ? W : H;
+    const float of = TRANSP ? ln.o1 : ln.o0, os = TRANSP ? ln.o0 : ln.o1;
+    const float df = TRANSP ? ln.d1 : ln.d0, ds = TRANSP ? ln.d0 : ln.d1;
+    const float hf = TRANSP ? lh1 : lh0, hs = TRANSP ? lh0 : lh1;  // the derivative pair's offset from the line
+    BandFrame bf;
+    bf.sigma = sigma;
+    set_beta(bf, beta0);
+    bf.marg = uni(.75f);
+    const bool runs_with = ln.active && ds * sigma > .3f;  // (the walker's own rule)
+    LinearBand band;
+    band.s0 = -2.f;
+    band.inv_ds01 = 1.f / ((float)Ns + 4.f);
+    band.beta = bf.beta;
+    {
+        const float m = runs_with ? df / ds : 0.f;
+        const float s1 = (float)Ns + 2.f;
+        // the line itself at the two reference coordinates, widened by the derivative pair's offsets
+        const float c = of - os * m;  // f = c + m s
+        const float w = fbcc ? 0.f : fabsf(hf) + fabsf(hs * m);
+        float lo0 = runs_with ? c + m * band.s0 - w : FLT_MAX, hi0 = runs_with ? c + m * band.s0 + w : -FLT_MAX;
+        float lo1 = runs_with ? c + m * s1 - w : FLT_MAX, hi1 = runs_with ? c + m * s1 + w : -FLT_MAX;
+        block_min_max(sh, lo0, hi0);
+        block_min_max(sh, lo1, hi1);
+        band.f0lo = lo0; band.f0hi = hi0; band.f1lo = lo1; band.f1hi = hi1;
+    }
+    const float* src = TRANSP ? imgT : img;
+    if (fbcc) {
+        DirectFbccSum acc;
+        acc.fbcc = *fbcc;
+        walk<TRANSP, false, false>(sh, img, W, H, src, bf, band, ln, 0.f, 0.f, 0.f, 0.f, 0.4f, acc);
+        return acc.sum;
+    }
+    DirectDerivSums acc;
+    walk<TRANSP, true, true>(sh, img, W, H, src, bf, band, ln, lh0, lh1, -lh0, -lh1, 0.4f, acc);
+    return acc.sump - acc.summ;
 }
 
-__global__ __launch_bounds__(256) void direct_lines_kernel(EccDirectParams p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void direct_lines_kernel(EccDirectParams p)
 {
+    __shared__ ecc_slab::Shared sh;
+    __shared__ float s_first_line[2];
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const long long pair = blockIdx.y;
     const int which = blockIdx.z;  // 0: first view of the pair, 1: second
     const EccDirectPair& r = p.pairs[pair];
-    if (k >= r.n_lines) return;
-    // ref: EpipolarConsistencyDirect.cpp:113-117 (kappa grid, float) and :49-63 (the line of plane kappa)
-    const float kf = p.user_kappas ? p.user_kappas[k] : (float)(r.k_first + r.dkappa * k);
-    const double kappa = kf, c = cos(kappa), s = sin(kappa);
-    double E[4], l[3];
-    for (int q = 0; q < 4; ++q) E[q] = c * r.E0[q] + s * r.E90[q];
+    if ((int)(blockIdx.x * blockDim.x) >= r.n_lines) return;  // uniform: nothing below this line returns early
+    const bool live = k < r.n_lines;
     const EccDirectView& V = p.views[which ? r.j : r.i];
-    ecc_host::RowQR f;
-    for (int a = 0; a < 3; ++a) {
-        for (int q = 0; q < 4; ++q) f.Q[a][q] = V.Q[4 * a + q];
-        for (int b = 0; b < 3; ++b) f.L[a][b] = V.L[3 * a + b];
+    float lf0 = 0.f, lf1 = 1.f, lf2 = 0.f, kf = 0.f;
+    if (live) {
+        // ref: EpipolarConsistencyDirect.cpp:113-117 (kappa grid, float) and :49-63 (the line of plane kappa)
+        kf = p.user_kappas ? p.user_kappas[k] : (float)(r.k_first + r.dkappa * k);
+        const double kappa = kf, c = cos(kappa), s = sin(kappa);
+        double E[4], l[3];
+        for (int q = 0; q < 4; ++q) E[q] = c * r.E0[q] + s * r.E90[q];
+        ecc_host::RowQR f;
+        for (int a = 0; a < 3; ++a) {
+            for (int q = 0; q < 4; ++q) f.Q[a][q] = V.Q[4 * a + q];
+            for (int b = 0; b < 3; ++b) f.L[a][b] = V.L[3 * a + b];
+        }
+        ecc_host::plane_to_line(f, E, l);
+        const double nn = sqrt(l[0] * l[0] + l[1] * l[1]);
+        lf0 = (float)(l[0] / nn);
+        lf1 = (float)(l[1] / nn);
+        lf2 = (float)(l[2] / nn);
     }
-    ecc_host::plane_to_line(f, E, l);
-    const double nn = sqrt(l[0] * l[0] + l[1] * l[1]);
-    const float lf0 = (float)(l[0] / nn), lf1 = (float)(l[1] / nn), lf2 = (float)(l[2] / nn);
-    // The lanes of a wave are adjacent lines of the pencil at the same step: for a near-horizontal line
-    // (|normal_v| > |normal_u|, what a circular C-arm scan produces) they differ in v, i.e. they sit in 64
-    // different rows of the row-major image -- one cache line per lane.  The transposed copy puts them next to
-    // each other (measured: 98.5 -> 21.3 ms per 496-pair evaluation of 1024^2 images).
-    const bool use_T = p.imagesT && fabsf(lf1) > fabsf(lf0);
-    const float* img = (use_T ? p.imagesT : p.images) + (int64_t)(which ? r.j : r.i) * p.image_stride;
-    const int si = use_T ? p.n_v : 1, sj = use_T ? 1 : p.n_u;
-    float v;
-    if (p.use_fbcc) {
-        ecc_host::FbccInfo info;
+    ecc_slab::LineRun ln = direct_line_run(lf0, lf1, lf2, p.n_u, p.n_v);
+    ln.active = ln.active && live;
+    ecc_host::FbccInfo info;
+    if (p.use_fbcc && live) {
         const float lf[3] = {lf0, lf1, lf2};
         ecc_host::fbcc_line_info(V.P, V.C, which ? r.H1 : r.H0, r.dvec, r.Eplane, lf, &info);
-        v = direct_line_integral_fbcc(img, si, sj, p.n_u, p.n_v, lf0, lf1, lf2, info);
-    } else {
-        v = direct_line_integral(img, si, sj, p.n_u, p.n_v, lf0, lf1, lf2);
     }
+    // The workgroup's tile orientation, walking direction and window slope come from its first line (uniform): the
+    // tile's fast axis is the image axis the line NORMAL is closer to (as in the Radon kernel); lines with y-normals
+    // stage from the transposed copy of the images.
+    if (threadIdx.x == 0) {
+        s_first_line[0] = lf0;
+        s_first_line[1] = lf1;
+    }
+    __syncthreads();
+    const float n0 = ecc_slab::uni(s_first_line[0]), n1 = ecc_slab::uni(s_first_line[1]);
+    const float* img = p.images + (int64_t)(which ? r.j : r.i) * p.image_stride;
+    const float* imgT = p.imagesT ? p.imagesT + (int64_t)(which ? r.j : r.i) * p.image_stride : nullptr;
+    const bool transp = imgT && fabsf(n1) > fabsf(n0);
+    // direction (d0, d1) = (l1, -l0); plain tile: s = y, ds = -l0, df = l1; transposed: s = x, ds = l1, df = -l0
+    const float ds0 = transp ? n1 : -n0, df0 = transp ? -n0 : n1;
+    const float sigma = ds0 >= 0.f ? 1.f : -1.f;
+    const float beta0 = df0 / (fabsf(ds0) > 1e-6f ? ds0 : 1e-6f);
+    float v;
+    if (transp) v = direct_lines_body<true>(p, sh, img, imgT, ln, 0.5f * lf0, 0.5f * lf1, sigma, beta0, p.use_fbcc ? &info : nullptr);
+    else v = direct_lines_body<false>(p, sh, img, imgT, ln, 0.5f * lf0, 0.5f * lf1, sigma, beta0, p.use_fbcc ? &info : nullptr);
+    if (!live) return;
+    if (!ln.active) v = 0.f;
     p.samples[((size_t)pair * 2 + which) * p.n_max + k] = v;
     if (p.debug_lines && pair == 0) {
         float* dl = p.debug_lines + 6 * (size_t)k + 3 * which;

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of MetricDirect (GPU box): python scripts/fuzz_direct.py [cases] [seed]
 Random small scans (sizes, perturbed views, object radius, user dkappa, derivative or fan-beam (FBCC) form) -> all-pairs
-sum against the oracle: 1e-5 relative for the derivative form, 1e-3 for FBCC (its float weights amplify a one-ulp
-difference of a line)."""
+sum against the oracle: 1e-5 relative for both forms (round 3, 200 cases: 1.4e-15 / 1.1e-15 at most)."""
 import os
 import sys
 import time
@@ -42,7 +41,7 @@ for c in range(cases):
     want = oracle.direct_evaluate(Ps, imgs, dkappa=dkappa, object_radius_mm=radius, fbcc=fbcc)["sum"]
     rel = abs(got - want) / max(abs(want), 1e-30)
     # (an FBCC weight can divide by zero for a small user radius: the reference's formula, both sides return inf)
-    ok = (not np.isfinite(want) and (got == want or (np.isnan(got) and np.isnan(want)))) or rel <= (1e-3 if fbcc else 1e-5)
+    ok = (not np.isfinite(want) and (got == want or (np.isnan(got) and np.isnan(want)))) or rel <= 1e-5
     bad += 0 if ok else 1
     print("case %2d: n=%d %3dx%3d fbcc %d r=%4.1f dk=%.3f: hip %.7g oracle %.7g rel %.2e %s" % (c, n, n_u, n_v, fbcc, radius, dkappa,
                                                                                                    got, want, rel, "ok" if ok else "MISMATCH"), flush=True)

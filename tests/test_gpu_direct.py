@@ -91,13 +91,15 @@ def test_fan_beam_consistency_variant(gpu_ctx, oracle_mod, small_scan):
         want = oracle_mod.direct_pair(Ps[i], Ps[j], imgs[i], imgs[j], 0.0, radius, fbcc=True)
         assert len(got["kappas"]) == len(want["kappas"])
         scale = np.abs(want["samples0"]).max()
-        assert np.abs(got["redundant_samples0"] - want["samples0"]).max() <= 1e-4 * scale
-        assert np.abs(got["redundant_samples1"] - want["samples1"]).max() <= 1e-4 * scale
+        assert np.abs(got["redundant_samples0"] - want["samples0"]).max() <= 1e-5 * scale
+        assert np.abs(got["redundant_samples1"] - want["samples1"]).max() <= 1e-5 * scale
         # the fan-beam condition: the two weighted signals agree for consistent data
         assert np.corrcoef(got["redundant_samples0"], got["redundant_samples1"])[0, 1] > 0.999
-        assert _rel(val, want["metric"]) < 1e-3
+        # (measured: identical lines give bit-identical weighted integrals; 200 random configurations of
+        # scripts/fuzz_direct.py agree to 1e-15 -- the bar leaves room for a line that differs by one float ulp)
+        assert _rel(val, want["metric"]) < 1e-5
     want = oracle_mod.direct_evaluate(Ps, imgs, fbcc=True)
-    assert _rel(m.evaluate(), want["sum"]) < 1e-3
+    assert _rel(m.evaluate(), want["sum"]) < 1e-5
     # switching back gives the derivative form again
     assert _rel(m.setFanBeamConsistency(False).evaluate(), oracle_mod.direct_evaluate(Ps, imgs)["sum"]) < 1e-5
 
