@@ -36,8 +36,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <set>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -71,6 +73,82 @@ struct ProjectionMatrix {
 };
 #endif
 }  // namespace Geometry
+
+/// Projection tables as text, one matrix per line ("[a b c d; e f g h; i j k l]"), '#' comments, "#> key="value" ..."
+/// attribute lines -- the .ompl files the reference's tools exchange
+/// (ref: HeaderOnly/Utils/Projtable.hxx:168-220, LibProjectiveGeometry/EigenToStr.hxx).
+namespace ProjTable {
+
+/// ref: loadProjectionsOneMatrixPerLine (Projtable.hxx:168-188): '#>' lines fill *meta, the first other comment is
+/// stored under "comment", every other non-empty line is a matrix.
+inline std::vector<Geometry::ProjectionMatrix> loadProjectionsOneMatrixPerLine(const std::string& file,
+                                                                               std::map<std::string, std::string>* meta = 0x0)
+{
+    std::vector<Geometry::ProjectionMatrix> ret;
+    std::ifstream pt(file.c_str());
+    std::string line;
+    while (pt && std::getline(pt, line)) {
+        while (!line.empty() && (line[line.size() - 1] == '\r' || line[line.size() - 1] == '\n')) line.erase(line.size() - 1);
+        if (line.empty()) continue;
+        if (line[0] == '#') {
+            if (meta && line.size() > 1 && line[1] == '>') {
+                // key="value" pairs
+                size_t pos = 2;
+                while (pos < line.size()) {
+                    const size_t eq = line.find("=\"", pos);
+                    if (eq == std::string::npos) break;
+                    const size_t end = line.find('"', eq + 2);
+                    if (end == std::string::npos) break;
+                    size_t k0 = line.find_first_not_of(" \t", pos);
+                    (*meta)[line.substr(k0, eq - k0)] = line.substr(eq + 2, end - eq - 2);
+                    pos = end + 1;
+                }
+            } else if (meta && meta->find("comment") == meta->end())
+                (*meta)["comment"] = line.substr(1);
+            continue;
+        }
+        for (size_t i = 0; i < line.size(); ++i)
+            if (line[i] == '[' || line[i] == ']' || line[i] == ';' || line[i] == ',') line[i] = ' ';
+        std::istringstream in(line);
+        Geometry::ProjectionMatrix P;
+        bool ok = true;
+        for (int r = 0; r < 3 && ok; ++r)
+            for (int c = 0; c < 4 && ok; ++c) {
+                double v = 0;
+                ok = !!(in >> v);
+                P(r, c) = v;
+            }
+        if (ok) ret.push_back(P);
+    }
+    return ret;
+}
+
+/// ref: saveProjectionsOneMatrixPerLine (Projtable.hxx:199-220); detector_size_px: null = not written.
+inline bool saveProjectionsOneMatrixPerLine(const std::vector<Geometry::ProjectionMatrix>& Ps, const std::string& path,
+                                            const std::string& first_line_comment = "", double spacing = 0.0,
+                                            const int* detector_size_px = 0x0)
+{
+    std::ofstream file(path.c_str());
+    if (!file) return false;
+    file.precision(12);
+    if (!first_line_comment.empty()) file << "#" << first_line_comment << std::endl;
+    if (spacing != 0.0) {
+        file << "#> spacing=\"" << spacing << "\"";
+        if (detector_size_px) file << " detector_size_px=\"" << detector_size_px[0] << " " << detector_size_px[1] << "\"";
+        file << std::endl;
+    }
+    for (size_t i = 0; i < Ps.size(); ++i) {
+        file << "[";
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 4; ++c) file << (c ? " " : "") << Ps[i](r, c);
+            file << (r < 2 ? "; " : "] ");
+        }
+        file << std::endl;
+    }
+    return true;
+}
+
+}  // namespace ProjTable
 
 namespace EpipolarConsistency {
 

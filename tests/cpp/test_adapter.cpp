@@ -14,6 +14,15 @@ using namespace EpipolarConsistency;
 
 int main(int argc, char** argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "ompl")) {  // projection-table round trip (no device): load, report, save
+        std::map<std::string, std::string> meta;
+        std::vector<ProjectionMatrix> Ps = ProjTable::loadProjectionsOneMatrixPerLine(argv[2], &meta);
+        printf("matrices %d\n", (int)Ps.size());
+        for (std::map<std::string, std::string>::const_iterator it = meta.begin(); it != meta.end(); ++it)
+            printf("meta %s=%s\n", it->first.c_str(), it->second.c_str());
+        const int det[2] = {640, 480};
+        return ProjTable::saveProjectionsOneMatrixPerLine(Ps, argv[3], meta["comment"], 0.308, det) ? 0 : 3;
+    }
     if (argc < 8) return 2;
     const char* path = argv[1];
     const int n = atoi(argv[2]), n_u = atoi(argv[3]), n_v = atoi(argv[4]), n_alpha = atoi(argv[5]), n_t = atoi(argv[6]);
