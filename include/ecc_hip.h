@@ -224,7 +224,10 @@ int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
  * the pair kernel: the work that is skipped is geometry that would be recomputed to identical bits, so results are
  * bit-identical with the switch on or off (tests/test_gpu_record_reuse.py).  This is the callers' pattern: the reference's
  * optimisation problems overwrite one view's matrix per cost-function call (ref: Gui/SingleImageMotion.h:84-90).
- * With the switch on, ecc_metric_set_projections only stages the matrices; E1 runs with the next call that needs it. */
+ * With the switch on, ecc_metric_set_projections only stages the matrices; E1 runs with the next call that needs it.
+ * The refit of the changed pairs and their own pair-kernel launch run on a stream of the metric's own beside the
+ * all-pairs launch (which skips them) on the context's stream; events order that stream after whatever the caller had
+ * queued on the context's stream and the final sum after both (up to 512 views, no cost image; otherwise one stream). */
 int ecc_metric_set_record_reuse(ecc_metric* m, int on);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
