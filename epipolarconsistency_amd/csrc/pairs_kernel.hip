@@ -358,9 +358,28 @@ __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_
 template <bool DERIV, int PITCH4>
 __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f)
 {
-    yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
-    const float fx = __builtin_amdgcn_fractf(xa), fy = __builtin_amdgcn_fractf(yd);
-    const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
+    float fx, fy;
+    unsigned off;
+    if (PITCH4 > 0) {
+        // Cell index and fraction without v_fract_f32 / v_cvt_u32_f32 (quarter rate): x + (2^23 - 0.5) is rounded to the
+        // integer 2^23 + rn(x - 0.5) -- the cell floor(x), or x - 1 with fraction 1 when x is an exact integer: the same
+        // point of the same bilinear surface -- and leaves the index in the low mantissa bits.  Needs x >= 0.25: the angle
+        // coordinate is >= 0.5 in padded texel units; the distance coordinate is clamped at 0.5 instead of 0 (cell 0 is
+        // the replicated border: both its bins hold the same bits, the value does not depend on the fraction there).
+        yd = __builtin_amdgcn_fmed3f(yd, 0.5f, n_t_f);
+        const float ma = xa + 8388607.5f, md = yd + 8388607.5f;
+        fx = xa - (ma - 8388608.f);
+        fy = yd - (md - 8388608.f);
+        unsigned bin8;  // the low 24 bits of md's pattern (the bin index) times 8: one v_mul_u32_u24 (the compiler would
+                        // turn the multiplication by 8 into a shift and a mask)
+        asm("v_mul_u32_u24 %0, %1, 8" : "=v"(bin8) : "v"(__float_as_uint(md)));
+        off = __umul24(__float_as_uint(ma), (unsigned)PITCH4) + bin8;
+    } else {
+        yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
+        fx = __builtin_amdgcn_fractf(xa);
+        fy = __builtin_amdgcn_fractf(yd);
+        off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
+    }
     const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
     const float r0 = fmaf(fx, q.y, q.x);  // q.y, q.w: the row differences, formed when the copy is built
     const float r1 = fmaf(fx, q.w, q.z);
