@@ -310,18 +310,21 @@ def main():
     lo, hi = min(rank * chunk, n), min((rank + 1) * chunk, n)
     slabs_all = torch.zeros((chunk * world, slab), dtype=torch.float32, device=dev)
     local = slabs_all[rank * chunk:(rank + 1) * chunk]
-    radon_ms = 0.0
-    sub = 50  # images generated and transformed 50 at a time (200 MB of projections in flight)
+    sub = 50  # projections are generated 50 at a time
+    # "ms per Radon intermediate at 1024^2 -> 768^2 bins, device-resident in/out, batch of 400" -- this
+    # rank's whole share of the projection stack is resident (1.68 GB at N = 1) before ONE timed call transforms it (the
+    # library walks it in sub-batches of 64 images: the transposed copy is scratch of the context)
+    imgs_all = torch.empty((hi - lo, S, S), dtype=torch.float32, device=dev)
     for a in range(lo, hi, sub):
         b = min(a + sub, hi)
-        imgs = synthetic.projections_torch(Ps[a:b], S, S, phantom, dev)
-        if a == lo:  # untimed first call: the context allocates its scratch (transposed image copy, trig table)
-            keep = E.RadonIntermediate.compute_into(ctx, imgs, local[a - lo:b - lo], B, B)
-            ctx.synchronize()
-        keep = E.RadonIntermediate.compute_into(ctx, imgs, local[a - lo:b - lo], B, B)
-        ctx.synchronize()
-        radon_ms += ctx.last_kernel_ms("radon")
-        del keep, imgs
+        imgs_all[a - lo:b - lo] = synthetic.projections_torch(Ps[a:b], S, S, phantom, dev)
+    # untimed first call: the context allocates its scratch (transposed image copy, trig table), clocks ramp
+    keep = E.RadonIntermediate.compute_into(ctx, imgs_all[:min(sub, hi - lo)], local[:min(sub, hi - lo)], B, B)
+    ctx.synchronize()
+    keep = E.RadonIntermediate.compute_into(ctx, imgs_all, local[:hi - lo], B, B)
+    ctx.synchronize()
+    radon_ms = ctx.last_kernel_ms("radon")
+    del keep, imgs_all
     ms_per_radon = radon_ms / max(hi - lo, 1)
     # pre-processing (the step in front of the Radon intermediate) on one sub-batch, device
     # resident in and out, reference defaults + cosine weighting: HBM-bound, 8 B per pixel algorithmic
@@ -551,7 +554,7 @@ def main():
         roofline_radon["lds_bank_conflict_ratio"] = rp["SQ_LDS_BANK_CONFLICT"] / rp["SQ_LDS_IDX_ACTIVE"]
         roofline_radon["pmc_source"] = ("SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU per 50-image launch: separate rocprofv3 --pmc "
                                         "passes, profiles/pmc_current.json (%s); not this run" % rp["_tag"])
-        # the committed passes profile launches of `sub` = 50 images each
+        # the committed passes (scripts/pmc_radon.sh on scripts/bench_radon.py) profile launches of 50 images each
         img_s = ms_per_radon * 1e-3
         roofs_r["lds_pipe_active"] = {"frac": rp["SQ_LDS_IDX_ACTIVE"] / sub / (N_CU * ENGINE_CLOCK_GHZ * 1e9 * img_s),
                                       "note": "SQ_LDS_IDX_ACTIVE cycles per image / (256 CUs x 2.4 GHz x seconds per image): bank "
