@@ -200,3 +200,27 @@ def test_group_default(gpu_ctx, small_scan):
     gm.close()
     off.close()
     g.close()
+
+
+def test_more_views_than_the_skip_set_holds(gpu_ctx):
+    """520 views: the two-stream form's skip set is a 512-bit kernel argument, so the refit runs in front of the
+    all-pairs launch on the context's stream instead -- same bits."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    rng = np.random.default_rng(8)
+    n, S, B = 520, 96, 48
+    Ps = synthetic.short_scan(n, S, S, 0.308 * 1024 / S)
+    base = [E.RadonIntermediate.from_host(gpu_ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(3)]
+    dtrs = [base[v % 3] for v in range(n)]
+    on, off = _pair(gpu_ctx, Ps, dtrs)
+    n_pairs = n * (n - 1) // 2
+    assert on.evaluate() == off.evaluate()
+    for views in ([515], [3, 519], []):
+        P1 = _moved(Ps, views, 0.4)
+        a, va = on.setProjectionMatrices(P1).evaluate_range(0, n_pairs, want_pairs=True)
+        b, vb = off.setProjectionMatrices(P1).evaluate_range(0, n_pairs, want_pairs=True)
+        assert a == b and np.array_equal(va, vb), views
+    on.close()
+    off.close()
+    for d in base:
+        d.close()
