@@ -11,12 +11,22 @@ import csv, glob, collections, re
 rows=[]
 for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
-acc=collections.defaultdict(lambda: collections.defaultdict(list))
+def grid(r):
+    return int(float(r.get("Grid_Size") or r.get("Grid_Size_X") or 0))
+# pairs_kernel is launched twice per step since round 3 (all pairs, and the list of the moved view's pairs on the side
+# stream): per name only the dispatches of the larger kind count (grid at least half the largest)
+gmax=collections.defaultdict(int)
+for r in rows: gmax[r["Kernel_Name"]]=max(gmax[r["Kernel_Name"]], grid(r))
+per=collections.defaultdict(float)   # a dispatch's counter can come in several rows (one per XCC group): they add up
+name_of={}
 for r in rows:
     k=r["Kernel_Name"]
-    m=re.search(r"(pairs_kernel<[\w, ]+>|k01_kernel|radon_kernel<\w+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w, ]+>)", k)
+    if 2*grid(r) < gmax[k]: continue
+    m=re.search(r"(pairs_kernel<[\w, ]+>|k01_kernel<\d+>|k01_kernel|radon_kernel<\w+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w, ]+>)", k)
     if m:
-        acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        per[(m.group(1), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for (name, d, c), v in per.items(): acc[name][c].append(v)
 with open("$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.summary.txt","w") as f:
     for k,v in sorted(acc.items()):
         line = k + " " + ", ".join("%s=%.6g (n=%d)" % (c, sum(x)/len(x), len(x)) for c,x in sorted(v.items()))
