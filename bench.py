@@ -410,7 +410,9 @@ def main():
                 return metric.evaluate()
             if mode == "shm":
                 return sharding.exchanged_evaluate(metric, n, exchange, shard=(first, count))
-            return sharding.distributed_evaluate(metric, n, sum_t, rank, world, shard=(first, count))
+            # (the context's stream is torch's current stream here, so the reduced scalar can come back through the
+            # metric's pinned result slot; with gloo the reduction runs on the host anyway)
+            return sharding.distributed_evaluate(metric, n, sum_t, rank, world, shard=(first, count), publish=args.backend == "nccl")
         return step
 
     def fence():

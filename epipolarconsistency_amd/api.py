@@ -522,6 +522,16 @@ class MetricRadonIntermediate:
             self._h, int(first), int(count), C.c_void_p(pair_tensor.data_ptr() if pair_tensor is not None else 0),
             C.c_void_p(sum_tensor.data_ptr())))
 
+    def publish_scalar(self, value_tensor):
+        """ecc_metric_publish_scalar: queue the hand-over of a 1-element float64 device tensor (e.g. an all-reduced partial
+        sum) to the metric's pinned result slot on the context's stream; wait_scalar() returns it."""
+        check(_lib.lib().ecc_metric_publish_scalar(self._h, C.c_void_p(value_tensor.data_ptr())))
+
+    def wait_scalar(self):
+        v = C.c_double()
+        check(_lib.lib().ecc_metric_wait_scalar(self._h, C.byref(v)))
+        return v.value
+
     def debug_geometry(self):
         n = self.getNumberOfProjetions()
         PinvTs, Cs = np.empty((n, 12), np.float32), np.empty((n, 4), np.float32)

@@ -51,6 +51,7 @@ extern "C" hipError_t ecc_launch_direct_transpose(const float* src, float* dst, 
 extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* total, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, void* scratch, hipStream_t stream);
+extern "C" hipError_t ecc_launch_publish_scalar(const double* value_d, double* host_slot_dev, hipStream_t stream);
 extern "C" size_t ecc_sum_scratch_bytes();
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
 
@@ -1462,6 +1463,26 @@ ECC_EXPORT int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int
         vals = m->pair_values_d;
     }
     return launch_range(m, first, count, vals, nullptr, nullptr, sum_d);
+}
+
+ECC_EXPORT int ecc_metric_publish_scalar(ecc_metric* m, const double* value_d)
+{
+    if (!m || !value_d) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(m->ctx);
+    if (rc) return rc;
+    arm_result(m);
+    HIP_TRY(ecc_launch_publish_scalar(value_d, m->sum_h_dev, m->ctx->stream));
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_wait_scalar(ecc_metric* m, double* value)
+{
+    if (!m || !value) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = set_device(m->ctx);
+    if (rc) return rc;
+    HIP_TRY(wait_result(m, m->ctx->stream, value));
+    m->done_generation = m->set_generation;  // the publishing kernel is ordered behind everything the metric launched
+    return ECC_OK;
 }
 
 ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values,

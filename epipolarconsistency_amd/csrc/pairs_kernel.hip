@@ -1512,6 +1512,23 @@ __global__ __launch_bounds__(1024) void sum_pairs_split_kernel(const float* __re
 }
 }  // namespace
 
+namespace {
+// One double from device memory into a pinned, device-mapped host slot (system-scope store): how a value that a
+// collective left on the device (the all-reduced sum of a sharded evaluation) reaches a polling host without a copy command.
+__global__ void publish_scalar_kernel(const double* __restrict__ value, double* __restrict__ host_slot)
+{
+    const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(value), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+extern "C" hipError_t ecc_launch_publish_scalar(const double* value_d, double* host_slot_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, stream, value_d, host_slot_dev);
+    return hipGetLastError();
+}
+
 extern "C" size_t ecc_sum_scratch_bytes() { return sizeof(SumScratch); }
 
 // scratch: ecc_sum_scratch_bytes() of zeroed device memory owned by the caller (one per stream of launches), or null.

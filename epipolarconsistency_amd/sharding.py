@@ -34,9 +34,12 @@ def view_range(rank, world, n_views):
     return lo, min(lo + chunk, n_views), chunk
 
 
-def allreduce_mean(partial_sum_tensor, n_pairs, group=None):
+def allreduce_mean(partial_sum_tensor, n_pairs, group=None, metric=None):
     """In-place all-reduce(sum) of a 1-element float64 tensor holding this rank's partial sum;
-    returns the mean over all pairs as a Python float."""
+    returns the mean over all pairs as a Python float.
+    metric: when given (and the tensor lives on the device the metric's context works on, torch's current stream being the
+    context's stream), the reduced value comes back through the metric's pinned result slot (a one-thread kernel queued
+    behind the collective + a poll) instead of tensor.item() (a device-to-host copy command and its synchronisation)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if partial_sum_tensor.is_cuda and dist.get_backend(group) == "gloo":
@@ -44,17 +47,20 @@ def allreduce_mean(partial_sum_tensor, n_pairs, group=None):
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             return float(host.item()) / n_pairs
         dist.all_reduce(partial_sum_tensor, op=dist.ReduceOp.SUM, group=group)
+    if metric is not None and partial_sum_tensor.is_cuda:
+        metric.publish_scalar(partial_sum_tensor)
+        return metric.wait_scalar() / n_pairs
     return float(partial_sum_tensor.item()) / n_pairs
 
 
-def distributed_evaluate(metric, n_views, sum_tensor, rank, world, group=None, shard=None):
+def distributed_evaluate(metric, n_views, sum_tensor, rank, world, group=None, shard=None, publish=False):
     """One all-pairs evaluation sharded over `world` ranks: launches this rank's shard
     asynchronously on the metric's stream, all-reduces the 8-byte partial sum, returns the mean.
-    shard: (first, count) of this rank (default: the equal-count chunk)."""
+    shard: (first, count) of this rank (default: the equal-count chunk).  publish: see allreduce_mean(metric=...)."""
     n_pairs = n_views * (n_views - 1) // 2
     first, count = shard if shard is not None else pair_range(rank, world, n_pairs)
     metric.evaluate_range_async(first, count, sum_tensor)
-    return allreduce_mean(sum_tensor, n_pairs, group)
+    return allreduce_mean(sum_tensor, n_pairs, group, metric=metric if publish else None)
 
 
 class ScalarExchange:

@@ -254,6 +254,14 @@ int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t count, float
 int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int64_t count,
                                     float* pair_values_d, double* sum_d);
 
+/* Companions of ecc_metric_evaluate_range_async for the one-process-per-GPU form: after the collective that adds the
+ * ranks' partial sums has been queued on the context's stream (an RCCL all-reduce of sum_d), ecc_metric_publish_scalar
+ * queues a one-thread kernel behind it that stores *value_d into the metric's pinned result slot, and
+ * ecc_metric_wait_scalar polls that slot (bounded, like ecc_metric_evaluate_all's wait): the reduced value reaches the
+ * host without a device-to-host copy command and its stream synchronisation. */
+int ecc_metric_publish_scalar(ecc_metric* m, const double* value_d);
+int ecc_metric_wait_scalar(ecc_metric* m, double* value);
+
 /* Index-list evaluate, ref: evaluate(const std::vector<Eigen::Vector4i>&, float*)
  * (…RadonIntermediate.cpp:267-322).  idx4: n_pairs x 4 int32 on the host.  Indices are range
  * checked in every build (the reference only checks under _DEBUG, .cpp:248-264). */

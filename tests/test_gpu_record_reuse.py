@@ -224,3 +224,23 @@ def test_more_views_than_the_skip_set_holds(gpu_ctx):
     off.close()
     for d in base:
         d.close()
+
+
+def test_published_scalar_equals_the_copied_one(gpu_ctx, small_scan):
+    """sharding.distributed_evaluate(publish=True): the (all-reduced) sum comes back through the metric's pinned result
+    slot instead of tensor.item(); same value, also over several calls in a row."""
+    import torch
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import sharding
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    sum_t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", 0))
+    for k, views in enumerate(([], [2], [2], [5, 6], [])):
+        P1 = _moved(s["Ps"], views, 0.2 * (k + 1))
+        m.setProjectionMatrices(P1)
+        a = sharding.distributed_evaluate(m, 8, sum_t, 0, 1, publish=True)
+        gpu_ctx.synchronize()
+        assert a == float(sum_t.item()) / 28
+        assert a == sharding.distributed_evaluate(m, 8, sum_t, 0, 1, publish=False) == m.evaluate()
+    m.close()
