@@ -18,6 +18,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -264,6 +265,9 @@ ECC_EXPORT int ecc_group_metric_create(ecc_group* g, int n_dtrs, ecc_dtr* const*
         if (hipSetDevice(dev) != hipSuccess) return ecc_set_error(ECC_ERR_HIP, "hipSetDevice failed");
         bool all_local = true;
         for (int k = 0; k < n_dtrs; ++k) all_local = all_local && src_dev[k] == dev;
+        // ECC_GROUP_FORCE_REPLICA=1 (tests): replicate even what is already here, so that the replica path -- allocation,
+        // copies, probes, metrics on the copy -- runs on a one-GPU box too
+        if (const char* e = std::getenv("ECC_GROUP_FORCE_REPLICA")) all_local = all_local && e[0] != '1';
         if (!all_local) {
             if (hipMalloc((void**)&raw->replicas[r], sizeof(float) * (size_t)slab * n_dtrs) != hipSuccess) {
                 (void)hipGetLastError();
@@ -285,7 +289,25 @@ ECC_EXPORT int ecc_group_metric_create(ecc_group* g, int n_dtrs, ecc_dtr* const*
             const int e = ecc_dtr_wrap_device(g->ctxs[r], base, n_alpha, n_t, n_u, n_v, filter, &raw->dtrs[r][k]);
             if (e != ECC_OK) return e;
         }
-        return ecc_metric_create(g->ctxs[r], n_dtrs, raw->dtrs[r].data(), &raw->metrics[r]);  // synchronises the stream
+        const int e = ecc_metric_create(g->ctxs[r], n_dtrs, raw->dtrs[r].data(), &raw->metrics[r]);  // synchronises the stream
+        if (e != ECC_OK || all_local) return e;
+        // The replica must BE the stack: three probes (first, middle, last Radon intermediate, 1 KB from the middle of
+        // each) read back from the copy and from its source.  A peer copy that silently did something else (first contact
+        // with a multi-GPU box, a fabric without peer access, ...) fails here and not as a wrong metric value later.
+        const int probes[3] = {0, n_dtrs / 2, n_dtrs - 1};
+        float a[256], b[256];
+        const size_t off = (size_t)slab / 2, cnt = slab - (int64_t)off < 256 ? (size_t)(slab - (int64_t)off) : 256;
+        for (int q = 0; q < 3; ++q) {
+            const int k = probes[q];
+            if (hipMemcpy(a, raw->replicas[r] + (size_t)slab * k + off, sizeof(float) * cnt, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(b, src_base[k] + off, sizeof(float) * cnt, hipMemcpyDeviceToHost) != hipSuccess) {
+                (void)hipGetLastError();
+                return ecc_set_error(ECC_ERR_HIP, "could not read back a probe of the replicated Radon-intermediate stack");
+            }
+            if (std::memcmp(a, b, sizeof(float) * cnt) != 0)
+                return ecc_set_error(ECC_ERR_HIP, "the replica of the Radon-intermediate stack differs from its source (device-to-device copy)");
+        }
+        return ECC_OK;
     });
     if (rc != ECC_OK) {
         ecc_group_metric_destroy(gm.release());

@@ -141,3 +141,30 @@ def test_multi_rank_group_on_one_device(gpu_ctx, oracle_mod, small_scan, ranks):
     m.close()
     del dtrs
     g.close()
+
+
+@pytest.mark.gpu
+def test_replica_path_on_one_device(gpu_ctx, small_scan, monkeypatch):
+    """ECC_GROUP_FORCE_REPLICA=1: every rank copies the Radon-intermediate stack although it is already on its device --
+    the code the ranks of a real multi-GPU group run (allocation, device-to-device copies, read-back probes against the
+    source, metrics built on the copy), minus the peer-to-peer flavour of the copy."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    monkeypatch.setenv("ECC_GROUP_FORCE_REPLICA", "1")
+    g = E.Group([0, 0])
+    dtrs = g.compute_batch(s["imgs"], s["n_alpha"], s["n_t"])
+    gm = E.GroupMetricRadonIntermediate(g, s["Ps"], dtrs)
+    monkeypatch.delenv("ECC_GROUP_FORCE_REPLICA")
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"])
+                                                     for d in s["dtrs"]])
+    bnd = m.balanced_shards(2)
+    parts = [m.evaluate_range(bnd[r], bnd[r + 1] - bnd[r]) for r in range(2)]
+    assert gm.evaluate() == (parts[0] + parts[1]) / 28
+    moved = list(s["Ps"])
+    moved[5] = moved[5] @ E.geometry.rigid_transform(ty=0.8, rx=0.01)
+    m.setProjectionMatrices(moved)
+    parts = [m.evaluate_range(bnd[r], bnd[r + 1] - bnd[r]) for r in range(2)]
+    assert gm.setProjectionMatrices(moved).evaluate() == (parts[0] + parts[1]) / 28
+    gm.close()
+    g.close()
+    m.close()
