@@ -18,7 +18,6 @@ def grid(r):
 gmax=collections.defaultdict(int)
 for r in rows: gmax[r["Kernel_Name"]]=max(gmax[r["Kernel_Name"]], grid(r))
 per=collections.defaultdict(float)   # a dispatch's counter can come in several rows (one per XCC group): they add up
-name_of={}
 for r in rows:
     k=r["Kernel_Name"]
     if 2*grid(r) < gmax[k]: continue
