@@ -1319,6 +1319,9 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         if (rc) return rc;
         // (Replaying the three launches below as an instantiated hipGraph was measured on ROCm 7.2: 6-9 us SLOWER per
         // evaluation than launching them on the stream, at 79 800 pairs and at a 9 975-pair shard.)
+        // (Round 3: pipelining a full refit over the two streams -- first eighth of the range k01 -> pairs on the context's
+        // stream, the rest k01 -> pairs on the side stream beside it -- was measured too: 0.392 against 0.370 ms per step;
+        // two concurrent pair-kernel launches cost more than the hidden 23 us of k01_kernel.)
         HIP_TRY(ecc_launch_k01(&p, ctx->stream));
         if (m->record_reuse && !K01_d && count > 0) {
             m->rec_Ps.assign(Pcur, Pcur + 12 * n);
