@@ -436,11 +436,12 @@ class MetricRadonIntermediate:
             check(_lib.lib().ecc_metric_set_incremental(self._h, int(self._incremental)))
         return self
 
-    def setRecordReuse(self, on=True):
+    def setRecordReuse(self, on=True, always=False):
         """Not in the reference (ecc_metric_set_record_reuse, default on): keep the per-pair geometry records of the last
         all-pairs / range evaluation and refit only the pairs whose matrices changed; every pair is still sampled and
-        results are bit-identical either way."""
-        self._record_reuse = bool(on)
+        results are bit-identical either way.  on=True: for ranges of more than 4096 pairs (smaller evaluations are
+        faster refitting everything); always=True: for every size."""
+        self._record_reuse = (2 if always else 1) if on else 0
         if self._h:
             check(_lib.lib().ecc_metric_set_record_reuse(self._h, int(self._record_reuse)))
         return self

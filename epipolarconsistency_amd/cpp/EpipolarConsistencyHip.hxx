@@ -631,7 +631,7 @@ public:
     MetricRadonIntermediate& setIncremental(bool on = true) { incremental = on; push_params(); return *this; }
     /// Not in the reference: ecc_metric_set_record_reuse (library default: on) -- the per-pair geometry of pairs whose
     /// matrices did not change is kept between evaluate() calls; every pair is still sampled, bit-identical results.
-    MetricRadonIntermediate& setRecordReuse(bool on = true) { record_reuse = on ? 1 : 0; push_params(); return *this; }
+    MetricRadonIntermediate& setRecordReuse(bool on = true, bool always = false) { record_reuse = on ? (always ? 2 : 1) : 0; push_params(); return *this; }
 
     /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
     MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)

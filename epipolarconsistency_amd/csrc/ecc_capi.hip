@@ -196,6 +196,7 @@ struct ecc_metric {
     // refits only the pairs with a changed matrix.  E1 is deferred to the evaluation for the same reason.
     int record_reuse = 1;
     bool e1_pending = false;   // matrices of set_generation are staged, e1_kernel has not been launched for them
+    bool eager_e1 = false;     // the last range was too small for record reuse: set_projections launches e1_kernel itself
     bool rec_valid = false;
     int64_t rec_first = 0, rec_count = 0;
     int rec_n_views = 0, rec_mode = 0;
@@ -817,8 +818,8 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     if (!m) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
     m->ctx = ctx;
     {
-        const char* e = std::getenv("ECC_RECORD_REUSE");
-        if (e && e[0] == '0') m->record_reuse = 0;
+        const char* e = std::getenv("ECC_RECORD_REUSE");  // 0: off, 1: default, 2: for every size
+        if (e && e[0] >= '0' && e[0] <= '2') m->record_reuse = e[0] - '0';
     }
     m->dtrs.assign(dtrs, dtrs + n_dtrs);
     // sizes come from dtrs[0] only, ref: ...RadonIntermediate.cpp:92-98
@@ -925,7 +926,7 @@ int ensure_e1(ecc_metric* m)
 ECC_EXPORT int ecc_metric_set_record_reuse(ecc_metric* m, int on)
 {
     if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
-    m->record_reuse = on ? 1 : 0;
+    m->record_reuse = on < 0 ? 0 : (on > 2 ? 2 : on);
     m->rec_valid = false;
     if (!m->record_reuse && m->n_views > 0) {
         const int rc = set_device(m->ctx);
@@ -1019,7 +1020,7 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
     // E1 itself is launched by whoever needs PinvTs / Cs next (ensure_e1): an evaluation that finds most matrices
     // unchanged computes the few changed views on the host and never launches it.
     m->e1_pending = true;
-    if (!m->record_reuse) return ensure_e1(m);
+    if (!m->record_reuse || m->eager_e1) return ensure_e1(m);  // nobody is going to skip it: launch it now, as round 2 did
     return ECC_OK;
 }
 
@@ -1198,7 +1199,13 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     const int mode = p.reference_arithmetic ? ECC_SAMPLING_REFERENCE : (p.poly ? ECC_SAMPLING_POLYNOMIAL : ECC_SAMPLING_PER_SAMPLE);
     const double* Pcur = m->Ps_h[m->set_generation & 1];
     bool reused = false;
-    const bool rec_match = m->record_reuse && m->rec_valid && !K01_d && count > 0 && m->rec_first == first && m->rec_count == count &&
+    // Small ranges gain nothing: up to ECC_RECORD_REUSE_MIN_PAIRS pairs the refit of everything is one 7-us launch of
+    // k01_kernel<8>, and a short pair kernel cannot hide the list launches of the two-stream form behind it -- the moved
+    // view's own pairs include its neighbours', whose waves run 40-50 us (64 views, 2016 pairs: 61 us per step with two
+    // streams against 40 us refitting everything).  Mode 2 (tests) applies the two-stream form at every size.
+    const bool size_ok = m->record_reuse >= 2 || count > ECC_RECORD_REUSE_MIN_PAIRS;
+    m->eager_e1 = !size_ok;
+    const bool rec_match = m->record_reuse && size_ok && m->rec_valid && !K01_d && count > 0 && m->rec_first == first && m->rec_count == count &&
                            m->rec_n_views == (int)n && m->rec_mode == mode && m->rec_radius == p.object_radius_mm &&
                            m->rec_dkappa == p.dkappa_user && m->rec_tol == p.economise_tol && (int64_t)m->rec_Ps.size() == 12 * n;
     m->rec_valid = false;  // until everything below is enqueued
@@ -1215,7 +1222,8 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             // it; the sum waits for both.  (Not with a cost image -- the list launch does not write it --, not in the
             // reference arithmetic -- evaluations of at most 512 pairs --, not beyond 512 views: the skip set is a
             // 512-bit kernel argument.)
-            bool split = C > 0 && !cost_d && !p.reference_arithmetic && n <= 32 * ECC_SKIP_WORDS;
+            bool split = C > 0 && !cost_d && !p.reference_arithmetic && n <= 32 * ECC_SKIP_WORDS &&
+                         (m->record_reuse >= 2 || count >= ECC_RECORD_REUSE_SPLIT_PAIRS);
             if (split && !m->side_stream) {
                 if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
                     hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess ||

@@ -228,6 +228,12 @@ int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
  * The refit of the changed pairs and their own pair-kernel launch run on a stream of the metric's own beside the
  * all-pairs launch (which skips them) on the context's stream; events order that stream after whatever the caller had
  * queued on the context's stream and the final sum after both (up to 512 views, no cost image; otherwise one stream). */
+#define ECC_RECORD_REUSE_MIN_PAIRS 4096
+#define ECC_RECORD_REUSE_SPLIT_PAIRS 8192
+/* on: 0 = off; 1 (default) = by size: ranges of more than ECC_RECORD_REUSE_MIN_PAIRS pairs (up to there refitting
+ * everything is one short launch), the two-stream form from ECC_RECORD_REUSE_SPLIT_PAIRS pairs on (a shorter pair kernel
+ * cannot hide the refit's launches: measured 2016 pairs, 61 us per step with two streams, 40 us refitting everything; a
+ * 10 873-pair shard 63 us with, 77 us without); 2 = the two-stream form for every size (tests). */
 int ecc_metric_set_record_reuse(ecc_metric* m, int on);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */

@@ -22,7 +22,7 @@ def _moved(Ps, views, k=1.0):
 
 def _pair(gpu_ctx, Ps, dtrs):
     import epipolarconsistency_amd as E
-    on = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(True)
+    on = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(True, always=True)  # (the default leaves small ranges alone)
     off = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(False)
     return on, off
 
@@ -98,7 +98,7 @@ def test_sequences_bit_identical(gpu_ctx, small_scan):
     # switching off and on again
     on.setRecordReuse(False)
     _same(on, off, n_pairs)
-    on.setRecordReuse(True)
+    on.setRecordReuse(True, always=True)
     _same(on, off, n_pairs)
     on.setProjectionMatrices(_moved(s["Ps"], [3], 0.1)); off.setProjectionMatrices(_moved(s["Ps"], [3], 0.1))
     _same(on, off, n_pairs)
@@ -181,10 +181,12 @@ def test_many_changed_views_take_the_wide_list_kernel(gpu_ctx):
         d.close()
 
 
-def test_group_default(gpu_ctx, small_scan):
-    """The single-process group runs with the library's default (reuse on) on every rank; compare with reuse off."""
+def test_group_with_reuse_on_every_rank(gpu_ctx, small_scan, monkeypatch):
+    """The single-process group with record reuse on every rank (ECC_RECORD_REUSE=2: for every size -- the library's
+    default leaves ranges below 8192 pairs alone); compare with reuse off."""
     import epipolarconsistency_amd as E
     s = small_scan
+    monkeypatch.setenv("ECC_RECORD_REUSE", "2")
     g = E.Group([0, 0, 0])
     gd = g.compute_batch(s["imgs"], s["n_alpha"], s["n_t"])
     gm = E.GroupMetricRadonIntermediate(g, s["Ps"], gd)
@@ -234,7 +236,7 @@ def test_published_scalar_equals_the_copied_one(gpu_ctx, small_scan):
     from epipolarconsistency_amd import sharding
     s = small_scan
     dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
-    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs)
+    m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], dtrs).setRecordReuse(True, always=True)
     sum_t = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", 0))
     for k, views in enumerate(([], [2], [2], [5, 6], [])):
         P1 = _moved(s["Ps"], views, 0.2 * (k + 1))
