@@ -243,6 +243,76 @@ __device__ __forceinline__ float direct_lines_body(const EccDirectParams& p, ecc
     return acc.sump - acc.summ;
 }
 
+// ref: EpipolarConsistencyDirect.cpp:113-117 (kappa grid, float) and :49-63 (the line of plane kappa), normalised
+__device__ __forceinline__ void direct_line_of(const EccDirectParams& p, const EccDirectPair& r, const EccDirectView& V, int k,
+                                               float& lf0, float& lf1, float& lf2, float& kf)
+{
+    kf = p.user_kappas ? p.user_kappas[k] : (float)(r.k_first + r.dkappa * k);
+    const double kappa = kf, c = cos(kappa), s = sin(kappa);
+    double E[4], l[3];
+    for (int q = 0; q < 4; ++q) E[q] = c * r.E0[q] + s * r.E90[q];
+    ecc_host::RowQR f;
+    for (int a = 0; a < 3; ++a) {
+        for (int q = 0; q < 4; ++q) f.Q[a][q] = V.Q[4 * a + q];
+        for (int b = 0; b < 3; ++b) f.L[a][b] = V.L[3 * a + b];
+    }
+    ecc_host::plane_to_line(f, E, l);
+    const double nn = sqrt(l[0] * l[0] + l[1] * l[1]);
+    lf0 = (float)(l[0] / nn);
+    lf1 = (float)(l[1] / nn);
+    lf2 = (float)(l[2] / nn);
+}
+
+// Small images (either side below DIRECT_SLAB_MIN_SIZE pixels): 256 adjacent lines of a pencil are a third of such an
+// image wide, the slabs of their band get short and wide, and the whole image is cache-resident anyway -- one thread per
+// line gathering from global memory (round 1-2's kernel) is faster there (256^2: 0.33 against 0.52 ms per 28-pair
+// evaluation; 512^2: 1.77 against 0.91).  The lanes of a wave are adjacent lines at the same step: for near-horizontal
+// lines they differ in v, so those read the transposed copy.  Same arithmetic, same bits as the slab kernel.
+constexpr int DIRECT_SLAB_MIN_SIZE = 384;
+__global__ __launch_bounds__(256) void direct_lines_gather_kernel(EccDirectParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pair = blockIdx.y;
+    const int which = blockIdx.z;
+    const EccDirectPair& r = p.pairs[pair];
+    if (k >= r.n_lines) return;
+    const EccDirectView& V = p.views[which ? r.j : r.i];
+    float lf0, lf1, lf2, kf;
+    direct_line_of(p, r, V, k, lf0, lf1, lf2, kf);
+    const bool use_T = p.imagesT && fabsf(lf1) > fabsf(lf0);
+    const float* img = (use_T ? p.imagesT : p.images) + (int64_t)(which ? r.j : r.i) * p.image_stride;
+    const int si = use_T ? p.n_v : 1, sj = use_T ? 1 : p.n_u;
+    const ecc_slab::LineRun ln = direct_line_run(lf0, lf1, lf2, p.n_u, p.n_v);
+    float v = 0.f;
+    if (ln.active) {
+        if (p.use_fbcc) {
+            DirectFbccSum acc;
+            const float lf[3] = {lf0, lf1, lf2};
+            ecc_host::fbcc_line_info(V.P, V.C, which ? r.H1 : r.H0, r.dvec, r.Eplane, lf, &acc.fbcc);
+            for (float t = ln.t; t <= ln.t_max; t += 0.4f)
+                acc.add(ecc_tex_global_strided(img, p.n_u, p.n_v, si, sj, ln.o0 + t * ln.d0, ln.o1 + t * ln.d1), 0.f, t);
+            v = acc.sum;
+        } else {
+            DirectDerivSums acc;
+            const float h0 = 0.5f * lf0, h1 = 0.5f * lf1;
+            for (float t = ln.t; t <= ln.t_max; t += 0.4f) {
+                const float x = ln.o0 + t * ln.d0, y = ln.o1 + t * ln.d1;
+                acc.add(ecc_tex_global_strided(img, p.n_u, p.n_v, si, sj, x + h0, y + h1),
+                        ecc_tex_global_strided(img, p.n_u, p.n_v, si, sj, x - h0, y - h1), t);
+            }
+            v = acc.sump - acc.summ;
+        }
+    }
+    p.samples[((size_t)pair * 2 + which) * p.n_max + k] = v;
+    if (p.debug_lines && pair == 0) {
+        float* dl = p.debug_lines + 6 * (size_t)k + 3 * which;
+        dl[0] = lf0;
+        dl[1] = lf1;
+        dl[2] = lf2;
+        if (which == 0) p.debug_kappas[k] = kf;
+    }
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void direct_lines_kernel(EccDirectParams p)
 {
     __shared__ ecc_slab::Shared sh;
@@ -255,23 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const bool live = k < r.n_lines;
     const EccDirectView& V = p.views[which ? r.j : r.i];
     float lf0 = 0.f, lf1 = 1.f, lf2 = 0.f, kf = 0.f;
-    if (live) {
-        // ref: EpipolarConsistencyDirect.cpp:113-117 (kappa grid, float) and :49-63 (the line of plane kappa)
-        kf = p.user_kappas ? p.user_kappas[k] : (float)(r.k_first + r.dkappa * k);
-        const double kappa = kf, c = cos(kappa), s = sin(kappa);
-        double E[4], l[3];
-        for (int q = 0; q < 4; ++q) E[q] = c * r.E0[q] + s * r.E90[q];
-        ecc_host::RowQR f;
-        for (int a = 0; a < 3; ++a) {
-            for (int q = 0; q < 4; ++q) f.Q[a][q] = V.Q[4 * a + q];
-            for (int b = 0; b < 3; ++b) f.L[a][b] = V.L[3 * a + b];
-        }
-        ecc_host::plane_to_line(f, E, l);
-        const double nn = sqrt(l[0] * l[0] + l[1] * l[1]);
-        lf0 = (float)(l[0] / nn);
-        lf1 = (float)(l[1] / nn);
-        lf2 = (float)(l[2] / nn);
-    }
+    if (live) direct_line_of(p, r, V, k, lf0, lf1, lf2, kf);
     ecc_slab::LineRun ln = direct_line_run(lf0, lf1, lf2, p.n_u, p.n_v);
     ln.active = ln.active && live;
     ecc_host::FbccInfo info;
@@ -391,7 +445,10 @@ extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     dim3 grid((p->n_max + 255) / 256, (unsigned)p->count, 2);
-    hipLaunchKernelGGL(direct_lines_kernel, grid, dim3(256), 0, stream, *p);
+    if (p->n_u < DIRECT_SLAB_MIN_SIZE || p->n_v < DIRECT_SLAB_MIN_SIZE)
+        hipLaunchKernelGGL(direct_lines_gather_kernel, grid, dim3(256), 0, stream, *p);
+    else
+        hipLaunchKernelGGL(direct_lines_kernel, grid, dim3(256), 0, stream, *p);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(direct_reduce_kernel, dim3((unsigned)((p->count + 3) / 4)), dim3(256), 0, stream, *p);

@@ -126,3 +126,30 @@ def test_caller_provided_kappa_grid(gpu_ctx, small_scan):
     with pytest.raises(E.EccError):
         d.evaluateForImagePair(0, 2, kappas=np.zeros(0, np.float32))
     d.close()
+
+
+@pytest.mark.parametrize("fbcc", [False, True])
+def test_larger_images_take_the_lds_slab_kernel(gpu_ctx, oracle_mod, fbcc):
+    """From 384 pixels per side on the line integrals go through the LDS slab tile the Radon kernel uses
+    (csrc/ecc_slab_tile.h); smaller images (everything above) gather from global memory.  Same arithmetic: identical
+    lines give bit-identical integrals, the metric agrees to 1e-5, in both forms and for a non-square image whose lines
+    run closer to x (transposed tile) as well as to y."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import geometry, synthetic
+    n_u, n_v = 448, 400
+    Ps = synthetic.short_scan(4, n_u, n_v, 0.308 * 1024 / n_u)
+    Ps[2] = Ps[2] @ geometry.rigid_transform(tz=40.0, rx=0.5)  # a pair whose epipolar lines are steep in the image
+    imgs = np.ascontiguousarray(synthetic.projections_numpy(Ps, n_u, n_v, synthetic.sphere_phantom()), np.float32)
+    radius = oracle_mod.object_radius(Ps[0], n_u, n_v)
+    m = E.MetricDirect(gpu_ctx, Ps, imgs).setFanBeamConsistency(fbcc)
+    for (i, j) in ((0, 3), (2, 1), (0, 2)):
+        val, got = m.evaluateForImagePair(i, j)
+        want = oracle_mod.direct_pair(Ps[i], Ps[j], imgs[i], imgs[j], 0.0, radius, fbcc=fbcc)
+        assert len(got["kappas"]) == len(want["kappas"]) > 1000
+        same = np.all(got["lines"] == want["lines"], axis=1)
+        assert same.mean() > 0.9
+        assert np.array_equal(got["redundant_samples0"][same], want["samples0"][same])
+        assert np.array_equal(got["redundant_samples1"][same], want["samples1"][same])
+        assert _rel(val, want["metric"]) < 1e-5
+    assert _rel(m.evaluate(), oracle_mod.direct_evaluate(Ps, imgs, fbcc=fbcc)["sum"]) < 1e-5
+    m.close()
