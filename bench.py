@@ -8,13 +8,21 @@ all n(n-1)/2 pairs, the float64 reduction and the scalar back on the host.  Rado
 resident in HBM when the timed region starts (they are computed once per data set, before it, and
 that cost is reported separately as ms_per_radon_intermediate).
 
-N GPUs: one process per GPU (torchrun), dtr stack produced data-parallel + all-gathered once (RCCL),
-contiguous shards of the pair range per rank, and per evaluation the 8-byte partial sums are added
-either through the library's shared-memory exchange (they are on the host already) or by an RCCL
-all-reduce of a device scalar.  BOTH are timed; `value` is the faster one, the other is reported next
-to it (config.sum_exchange says which).  The total work per evaluation is fixed: scaling is "strong".
+N GPUs: one process per GPU, dtr stack produced data-parallel + all-gathered once (RCCL), contiguous
+cost-balanced shards of the pair range per rank, and per evaluation the 8-byte partial sums are added by
+an RCCL all-reduce of a device scalar (the exchange north_star names): THAT step is `value`.  The
+library's shared-memory exchange of the same sums (they are on the host already) is timed too and
+reported under timing.other_exchange (config.sum_exchange says which one `value` is).  The total work
+per evaluation is fixed: scaling is "strong".
 (The single-process form of the same partitioning -- ecc_group_* of the C ABI, what a C++ caller of the
 adapter uses -- is measured by scripts/bench_group.py.)
+
+Launch forms: under torchrun (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, RANK /
+WORLD_SIZE in the environment) this process is one rank.  WITHOUT them `python bench.py --gpus N` with N > 1
+starts its own N ranks: the parent -- before it imports torch or touches the GPU -- runs `python -m
+torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+<same arguments>` as a CHILD process, forwards rank 0's single JSON line and exits with the child's status
+(a failing or killed rank ends the job non-zero); it never falls back to one rank.
 
 Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by barrier + synchronize on both
 sides and reduced with MAX over ranks.  The first block is what a cold process gets (clocks still
@@ -68,6 +76,10 @@ def parse():
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
                     help="CPU baseline evaluates all pairs among every k-th view")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rehearse only the launch: every rank joins the process group (gloo, no GPU touched), one all-reduce "
+                         "checks the rank count, rank 0 prints one JSON line; ECC_BENCH_FAIL_RANK=r makes rank r die first "
+                         "(tests/test_bench_launch.py)")
     ap.add_argument("--sweep-poses", action="store_true",
                     help="BASELINE config 5 instead of the per-step bench: the 600-point 6-DoF sweep of one view "
                          "(ref: Gui/Visualization.h:78-98), the POSES sharded round-robin over the ranks, every rank "
@@ -253,8 +265,84 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
         dist.destroy_process_group()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a child job and forward its one JSON
+    line and its exit status.  Nothing here imports torch or makes a HIP call: the ranks are children of a process that
+    has never initialised the GPU (an exec / fork from a GPU-initialised process is what the pool forbids)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL between processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for raw in proc.stdout:  # rank 0's JSON line goes to stdout exactly once; anything else the ranks print goes to stderr
+        t = raw.strip()
+        is_json = False
+        if t.startswith("{") and t.endswith("}"):
+            try:
+                is_json = "metric" in json.loads(t)
+            except ValueError:
+                is_json = False
+        if is_json:
+            line = t
+        else:
+            sys.stderr.write(raw)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the %d-rank job ended without a result line\n" % args.gpus)
+        rc = 1
+    if rc == 0:
+        d = json.loads(line)
+        if d.get("n_gpus") != args.gpus:
+            sys.stderr.write("bench.py: asked for %d ranks, the job reports n_gpus = %r\n" % (args.gpus, d.get("n_gpus")))
+            rc = 1
+    if rc == 0:
+        print(line)
+        sys.stdout.flush()
+    sys.exit(rc if rc >= 0 else 1)  # (negative: torchrun itself was killed by a signal)
+
+
+def launch_check(args, rank, world):
+    """--launch-check: the process group of the launch, nothing else (runs without a GPU)."""
+    import torch
+    import torch.distributed as dist
+    fail = os.environ.get("ECC_BENCH_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        os._exit(7)  # a rank that dies before it joins the group
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        probe = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(probe)
+        if probe.item() != world * (world + 1) / 2.0:
+            raise SystemExit("all-reduce over %d ranks returned %r" % (world, probe.item()))
+        seen = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (nothing measured)", "value": None, "n_gpus": world,
+                          "config": {"ranks_seen_by_collective_backend": seen, "launch_check": True}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        self_launch(args)  # does not return
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%s: the job must have exactly --gpus ranks"
+                         % (args.gpus, os.environ.get("WORLD_SIZE", "<unset>")))
+    if args.launch_check:
+        launch_check(args, int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -265,8 +353,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.single_device:
@@ -680,6 +766,10 @@ if __name__ == "__main__":
     except BaseException as e:  # a failing rank must take the job down with a non-zero status, never hang the others
         if isinstance(e, SystemExit) and e.code in (0, None):
             raise
+        if isinstance(e, SystemExit) and isinstance(e.code, int):  # the self-launching parent handing on its job's status
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(e.code)
         import traceback
         traceback.print_exc()
         sys.stderr.flush()

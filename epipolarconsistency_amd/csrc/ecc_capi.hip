@@ -919,6 +919,11 @@ int ensure_e1(ecc_metric* m)
     const int slot = (int)(m->set_generation & 1);
     HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], m->n_views, m->PinvTs_d, m->Cs_d, m->ctx->stream));
     m->e1_pending = false;
+    // The reuse path of launch_range assumes PinvTs / Cs on the device are E1(rec_Ps) for every view it finds unchanged.
+    // This launch has just made them E1 of the CURRENT matrices for all views (an image-pair or debug call between two
+    // evaluations gets here), so the kept records no longer describe the device geometry: the next evaluation refits
+    // everything.  (launch_range's own full refit comes through here too and sets rec_valid again when it is done.)
+    m->rec_valid = false;
     return ECC_OK;
 }
 }  // namespace

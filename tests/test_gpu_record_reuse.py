@@ -246,3 +246,48 @@ def test_published_scalar_equals_the_copied_one(gpu_ctx, small_scan):
         assert a == float(sum_t.item()) / 28
         assert a == sharding.distributed_evaluate(m, 8, sum_t, 0, 1, publish=False) == m.evaluate()
     m.close()
+
+
+def test_geometry_users_between_two_sets_drop_the_kept_records(gpu_ctx, small_scan):
+    """Round-3 advisor finding: evaluateForImagePair / debug_geometry run E1 for ALL views of the currently staged
+    matrices.  After set(P + e_v); <one of them>; set(P + e_w) the device holds E1((P + e_v)_v) while the kept records
+    belong to P -- the refit of pair (v, w) must not read that stale geometry.  Also the variant with no view changed
+    relative to the kept matrices: set(P + e_v); debug_geometry; set(P); evaluate; then users of the device geometry."""
+    import epipolarconsistency_amd as E
+    s = small_scan
+    dtrs = [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"]) for d in s["dtrs"]]
+    n_pairs = 28
+    for user in ("debug_geometry", "image_pair"):
+        on, off = _pair(gpu_ctx, s["Ps"], dtrs)
+        _same(on, off, n_pairs)
+        for v, w in ((2, 5), (6, 1), (3, 3)):
+            Pv = _moved(s["Ps"], [v], 0.8)
+            Pw = _moved(s["Ps"], [w], 0.6)
+            for m in (on, off):
+                m.setProjectionMatrices(Pv)
+                if user == "debug_geometry":
+                    m.debug_geometry()
+                else:
+                    m.evaluateForImagePair(min(v, 7 - v), 7)
+                m.setProjectionMatrices(Pw)
+            a, va = on.evaluate_range(0, n_pairs, want_pairs=True)
+            b, vb = off.evaluate_range(0, n_pairs, want_pairs=True)
+            assert a == b and np.array_equal(va, vb), (user, v, w)
+        # no view changed relative to the kept matrices, but the device geometry was overwritten in between
+        Pv = _moved(s["Ps"], [4], 0.5)
+        for m in (on, off):
+            m.setProjectionMatrices(s["Ps"]).evaluate()
+            m.setProjectionMatrices(Pv)
+            m.debug_geometry()
+            m.setProjectionMatrices(s["Ps"])
+        assert on.evaluate() == off.evaluate()
+        idx = np.array([[4, 6, 4, 6], [1, 4, 1, 4], [0, 7, 0, 7]], np.int32)
+        assert on.evaluate(idx) == off.evaluate(idx)
+        for x, y in zip(on.debug_geometry(), off.debug_geometry()):
+            assert np.array_equal(x, y)
+        (ea, da), (eb, db) = on.evaluateForImagePair(4, 6), off.evaluateForImagePair(4, 6)
+        assert ea == eb
+        for k in da:
+            assert np.array_equal(da[k], db[k]), k
+        on.close()
+        off.close()
