@@ -71,7 +71,7 @@ def parse():
                          "measures the pair kernel's HBM bytes and vector instructions for the roofline objects; the "
                          "committed profiles/pmc_current.json is used instead")
     ap.add_argument("--blocks", type=int, default=0,
-                    help="number of timed K-step blocks (0 = automatic: up to 9, about 1 s in total)")
+                    help="number of timed K-step blocks (0 = automatic: up to 25, about 0.3 s in total)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
@@ -415,8 +415,19 @@ def main():
     keep = E.RadonIntermediate.compute_into(ctx, imgs_all, local[:hi - lo], B, B)
     ctx.synchronize()
     radon_ms = ctx.last_kernel_ms("radon")
-    del keep, imgs_all
     ms_per_radon = radon_ms / max(hi - lo, 1)
+    # the same stack in the contracted arithmetic (ecc_radon_set_arithmetic(ECC_RADON_FMA): positions fmaf(t, d, o), lerps
+    # as one fma each; bit-identical to the oracle's contracted variant, tests/test_gpu_radon_fma.py).  The metric below is
+    # evaluated on the EXACT stack; at N = 1 it is evaluated on this one too and the two means are compared.
+    slabs_fma = torch.zeros((hi - lo, slab), dtype=torch.float32, device=dev)
+    ctx.setRadonArithmetic("fma")
+    keep = E.RadonIntermediate.compute_into(ctx, imgs_all, slabs_fma, B, B)
+    ctx.synchronize()
+    ms_per_radon_fma = ctx.last_kernel_ms("radon") / max(hi - lo, 1)
+    ctx.setRadonArithmetic("exact")
+    del keep, imgs_all
+    if world > 1:
+        del slabs_fma
     # pre-processing (the step in front of the Radon intermediate) on one sub-batch, device
     # resident in and out, reference defaults + cosine weighting: HBM-bound, 8 B per pixel algorithmic
     imgs = synthetic.projections_torch(Ps[lo:min(lo + sub, hi)], S, S, phantom, dev)
@@ -445,7 +456,23 @@ def main():
             raise SystemExit("rank %d: gathered Radon intermediate of view %d differs from a local recomputation" % (rank, probe_view))
         del keep, pimg, pslab
     dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
+    radon_tie = None
+    if world == 1:  # metric-level tie of the two Radon arithmetic modes on this very data set
+        dtrs_fma = [E.RadonIntermediate.wrap_device(ctx, slabs_fma[k], B, B, S, S) for k in range(n)]
+        m_fma = E.MetricRadonIntermediate(ctx, Ps, dtrs_fma)
+        mean_fma = m_fma.evaluate()
+        m_fma.close()
+        for d in dtrs_fma:
+            d.close()
+        del dtrs_fma, slabs_fma
+        radon_tie = {"mean_on_fma_stack": mean_fma}
     metric = E.MetricRadonIntermediate(ctx, Ps, dtrs)
+    if radon_tie is not None:
+        mean_exact = metric.evaluate()
+        radon_tie.update({"mean_on_exact_stack": mean_exact, "rel_diff": abs(mean_fma - mean_exact) / abs(mean_exact),
+                          "bar": 2e-6})
+        if radon_tie["rel_diff"] > 2e-6:
+            raise SystemExit("Radon arithmetic modes disagree on the metric: %r" % (radon_tie,))
 
     n_pairs = n * (n - 1) // 2
     if args.sweep_poses:
@@ -530,7 +557,10 @@ def main():
         blocks, last = [], None
         el, last = timed_block(step, 0)
         blocks.append(el)
-        n_blocks = args.blocks if args.blocks > 0 else int(min(9, max(3, 1.0 / max(el, 1e-6))))
+        # automatic: about 0.3 s of timed steps, at most 25 blocks -- the driver's 20-step blocks last 8 ms each and the clocks
+        # of a box that idled through the host-side set-up take 5+ such blocks to settle (round 4: blocks 1-5 0.40-0.45 ms
+        # per step, 6-9 0.364-0.370); the median of 9 sat on the ramp
+        n_blocks = args.blocks if args.blocks > 0 else int(min(25, max(3, 0.3 / max(el, 1e-6))))
         if world > 1:  # every rank must run the same number of blocks
             nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
             dist.broadcast(nb, 0)
@@ -679,6 +709,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%d-projection %dx%d circular short scan, %dx%d Radon bins, all %d pairs"
                                % (n, S, S, B, B, n_pairs),
+                   "radon_arithmetic": "exact (the Radon intermediates the timed evaluations sample; ms_per_radon_intermediate is this mode)",
                    "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d (contiguous, cost-balanced)" % world,
                    "sum_exchange": exch_name[best],
                    # the step moves one view like the reference's optimiser loop does; the library's opt-in pose-delta mode
@@ -703,6 +734,11 @@ def main():
         "roofline": roofline,
         "roofline_radon": roofline_radon,
         "ms_per_radon_intermediate": ms_per_radon,
+        "ms_per_radon_intermediate_by_arithmetic": {
+            "exact": ms_per_radon, "fma": ms_per_radon_fma,
+            "headline_mode": "exact (library default: unfused fp32, bit-identical to the oracle's normative variant); fma = "
+                             "ecc_radon_set_arithmetic(ECC_RADON_FMA), bit-identical to the oracle's contracted variant",
+            "metric_tie": radon_tie},
         "ms_per_preprocess": ms_per_preprocess,
         "preprocess_hbm_GBs": 8.0 * S * S / (ms_per_preprocess * 1e-3) / 1e9 if ms_per_preprocess > 0 else 0.0,
         "pairs_per_s": n_pairs * args.steps / elapsed,

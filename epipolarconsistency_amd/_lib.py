@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("ECC_HIP_LIB") or os.path.join(_HERE, "libecc_hip.so")
 ECC_OK = 0
 FILTER_DERIVATIVE, FILTER_RAMP, FILTER_NONE = 0, 1, 2
 POST_IDENTITY, POST_SQUARE_ROOT, POST_LOGARITHM = 0, 1, 2
+RADON_EXACT, RADON_FMA = 0, 1
 SAMPLING_AUTO, SAMPLING_POLYNOMIAL, SAMPLING_PER_SAMPLE, SAMPLING_REFERENCE = 0, 1, 2, 3
 
 
@@ -45,6 +46,8 @@ SIGNATURES = {
     "ecc_radon_compute": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_radon_compute_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_radon_compute_into": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecc_radon_set_arithmetic": (_i, [_vp, _i]),
+    "ecc_radon_get_arithmetic": (_i, [_vp, _pi]),
     "ecc_dtr_from_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_dtr_readback": (_i, [_vp, _vp]),
     "ecc_dtr_info": (_i, [_vp, _pi, _pi, _pi, _pi, _pi, _pd, _pd]),

@@ -53,6 +53,17 @@ class Context:
         check(_lib.lib().ecc_ctx_last_kernel_ms(self._h, {"pairs": 0, "radon": 1, "preprocess": 2}[which], C.byref(ms)))
         return ms.value
 
+    def setRadonArithmetic(self, mode="exact"):
+        """ecc_radon_set_arithmetic: "exact" (default; unfused fp32, bit-identical to the oracle's normative variant) or
+        "fma" (contracted sampling loop, bit-identical to the oracle's contracted variant, ~25 % faster)."""
+        check(_lib.lib().ecc_radon_set_arithmetic(self._h, {"exact": _lib.RADON_EXACT, "fma": _lib.RADON_FMA}[mode]))
+        return self
+
+    def getRadonArithmetic(self):
+        v = C.c_int()
+        check(_lib.lib().ecc_radon_get_arithmetic(self._h, C.byref(v)))
+        return {_lib.RADON_EXACT: "exact", _lib.RADON_FMA: "fma"}[v.value]
+
     def close(self):
         if self._h:
             _lib.lib().ecc_ctx_destroy(self._h)

@@ -235,11 +235,11 @@ __device__ __forceinline__ float direct_lines_body(const EccDirectParams& p, ecc
     if (fbcc) {
         DirectFbccSum acc;
         acc.fbcc = *fbcc;
-        walk<TRANSP, false, false>(sh, img, W, H, src, bf, band, ln, 0.f, 0.f, 0.f, 0.f, 0.4f, acc);
+        walk<TRANSP, false, false, false>(sh, img, W, H, src, bf, band, ln, 0.f, 0.f, 0.f, 0.f, 0.4f, acc);
         return acc.sum;
     }
     DirectDerivSums acc;
-    walk<TRANSP, true, true>(sh, img, W, H, src, bf, band, ln, lh0, lh1, -lh0, -lh1, 0.4f, acc);
+    walk<TRANSP, true, true, false>(sh, img, W, H, src, bf, band, ln, lh0, lh1, -lh0, -lh1, 0.4f, acc);
     return acc.sump - acc.summ;
 }
 

@@ -96,6 +96,7 @@ struct ecc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool timing = false;
+    int radon_arithmetic = ECC_RADON_EXACT;  // ecc_radon_set_arithmetic
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pair, radon, preprocess start/stop
     bool ev_valid[3] = {false, false, false};
     // trig table cache for the Radon kernel
@@ -471,6 +472,7 @@ int radon_launch(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, i
         p.n_t = n_t;
         p.pitch = ecc_layout_pitch(n_t);
         p.post_process = post;
+        p.arithmetic = ctx->radon_arithmetic;
         HIP_TRY(ecc_launch_direct_transpose(p.images, ctx->radon_T_d, cnt, n_u, n_v, ctx->stream));
         HIP_TRY(ecc_launch_radon(&p, filter == ECC_FILTER_DERIVATIVE ? 1 : 0, ctx->stream));
     }
@@ -486,6 +488,25 @@ int radon_launch(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, i
     }
     return ECC_OK;
 }
+
+}  // namespace
+
+ECC_EXPORT int ecc_radon_set_arithmetic(ecc_ctx* ctx, int mode)
+{
+    if (!ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "context is null");
+    if (mode != ECC_RADON_EXACT && mode != ECC_RADON_FMA) return fail(ECC_ERR_INVALID_ARGUMENT, "unknown Radon arithmetic mode");
+    ctx->radon_arithmetic = mode;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_radon_get_arithmetic(const ecc_ctx* ctx, int* mode)
+{
+    if (!ctx || !mode) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    *mode = ctx->radon_arithmetic;
+    return ECC_OK;
+}
+
+namespace {
 
 int check_radon_args(ecc_ctx* ctx, const float* image, int n, int n_u, int n_v, int n_alpha, int n_t, int filter,
                      int post, ecc_dtr** out)

@@ -55,6 +55,7 @@ struct EccRadonParams {
     int n_alpha, n_t;
     int pitch;
     int post_process;
+    int arithmetic;        // 0: exact (unfused) sampling loop, 1: contracted (ECC_RADON_FMA)
 };
 
 // ---- pair kernel ---------------------------------------------------------------------------

@@ -213,7 +213,7 @@ static_assert(S_MAX <= 256, "stage_load / stage_store dispatch on ceil(S / 64) =
 // The exact bilinear rule (ecc_sampling.h) on the pair tile.  base = LDS byte address of the tile, minus
 // 8 * (R0 * S + I0) (tile origin), minus (0x4B000000 << 3) (the 2^23 trick), all modulo 2^32.
 // TRANSP: f is the image's y axis: pair (j, i) = {T(i, j), T(i, j+1)}, the next row is i + 1.
-template <bool TRANSP>
+template <bool TRANSP, bool FMA>
 __device__ __forceinline__ float tex_pairs(unsigned base, float Sf, unsigned S8, float x, float y)
 {
     float xb = x - 0.5f, yb = y - 0.5f;
@@ -231,9 +231,14 @@ __device__ __forceinline__ float tex_pairs(unsigned base, float Sf, unsigned S8,
     const v2f pb = *(const lds_v2f*)(size_t)a1;
     const float T00 = pa.x, T10 = TRANSP ? pb.x : pa.y;
     const float T01 = TRANSP ? pa.y : pb.x, T11 = pb.y;
-    float r0 = (1.f - fx) * T00 + fx * T10;
-    float r1 = (1.f - fx) * T01 + fx * T11;
-    return (1.f - fy) * r0 + fy * r1;
+    return ecc_bilerp<FMA>(fx, fy, T00, T10, T01, T11);
+}
+
+// position(t) of a line: o + t * d, rounded twice (exact convention) or once (contracted)
+template <bool FMA>
+__device__ __forceinline__ float line_pos(float o, float t, float d)
+{
+    return FMA ? __builtin_fmaf(t, d, o) : o + t * d;
 }
 
 
@@ -272,7 +277,8 @@ __device__ __forceinline__ void block_min_max(Shared& sh, float& lo, float& hi)
 // TRANSP: the tile's fast axis is the image's y axis and src is the transposed copy of the image (n_u rows of n_v
 // texels); img is always the image itself (global-memory path of threads whose run fails the containment check).
 // bf.sigma / bf.beta must describe the band; threads whose line does not run with it never use the tile.
-template <bool TRANSP, bool TWO, bool A_OFFSET, class Band, class Acc>
+// FMA: the contracted arithmetic convention (positions fmaf(t, d, o), ecc_bilerp<true>) instead of the exact one.
+template <bool TRANSP, bool TWO, bool A_OFFSET, bool FMA, class Band, class Acc>
 __device__ __forceinline__ void walk(Shared& sh, const float* __restrict__ img, int W, int H, const float* __restrict__ src,
                                      const BandFrame& bf, const Band& band, LineRun& ln, float a0, float a1, float b0, float b1,
                                      const float step, Acc& acc)
@@ -342,17 +348,17 @@ __device__ __forceinline__ void walk(Shared& sh, const float* __restrict__ img, 
                     const unsigned base = tile_addr - 8u * (unsigned)(cur.R0 * cur.S + cur.I0) - (0x4B000000u << 3);
                     for (; t <= t_end; t += step) {  // t += step accumulates in fp32, like the reference's loops
                         ECC_SLAB_STAT(1, 1);
-                        const float x = o0 + t * d0, y = o1 + t * d1;
-                        const float vA = tex_pairs<TRANSP>(base, Sf, S8, A_OFFSET ? x + a0 : x, A_OFFSET ? y + a1 : y);
-                        const float vB = TWO ? tex_pairs<TRANSP>(base, Sf, S8, x + b0, y + b1) : 0.f;
+                        const float x = line_pos<FMA>(o0, t, d0), y = line_pos<FMA>(o1, t, d1);
+                        const float vA = tex_pairs<TRANSP, FMA>(base, Sf, S8, A_OFFSET ? x + a0 : x, A_OFFSET ? y + a1 : y);
+                        const float vB = TWO ? tex_pairs<TRANSP, FMA>(base, Sf, S8, x + b0, y + b1) : 0.f;
                         acc.add(vA, vB, t);
                     }
                 } else {
                     for (; t <= t_end; t += step) {
                         ECC_SLAB_STAT(2, 1);
-                        const float x = o0 + t * d0, y = o1 + t * d1;
-                        const float vA = ecc_tex_global(img, W, H, A_OFFSET ? x + a0 : x, A_OFFSET ? y + a1 : y);
-                        const float vB = TWO ? ecc_tex_global(img, W, H, x + b0, y + b1) : 0.f;
+                        const float x = line_pos<FMA>(o0, t, d0), y = line_pos<FMA>(o1, t, d1);
+                        const float vA = ecc_tex_global<FMA>(img, W, H, A_OFFSET ? x + a0 : x, A_OFFSET ? y + a1 : y);
+                        const float vB = TWO ? ecc_tex_global<FMA>(img, W, H, x + b0, y + b1) : 0.f;
                         acc.add(vA, vB, t);
                     }
                 }
@@ -364,9 +370,9 @@ __device__ __forceinline__ void walk(Shared& sh, const float* __restrict__ img, 
     if (ln.active)
         for (; t <= t_max; t += step) {
             ECC_SLAB_STAT(3, 1);
-            const float x = o0 + t * d0, y = o1 + t * d1;
-            const float vA = ecc_tex_global(img, W, H, A_OFFSET ? x + a0 : x, A_OFFSET ? y + a1 : y);
-            const float vB = TWO ? ecc_tex_global(img, W, H, x + b0, y + b1) : 0.f;
+            const float x = line_pos<FMA>(o0, t, d0), y = line_pos<FMA>(o1, t, d1);
+            const float vA = ecc_tex_global<FMA>(img, W, H, A_OFFSET ? x + a0 : x, A_OFFSET ? y + a1 : y);
+            const float vB = TWO ? ecc_tex_global<FMA>(img, W, H, x + b0, y + b1) : 0.f;
             acc.add(vA, vB, t);
         }
     ln.t = t;

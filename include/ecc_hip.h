@@ -91,6 +91,21 @@ int ecc_radon_compute_batch(ecc_ctx* ctx, const float* images, int images_on_dev
 int ecc_radon_compute_into(ecc_ctx* ctx, const float* images_d, int n, int n_u, int n_v, int n_alpha,
                            int n_t, int filter, int post_process, float* slabs_d);
 
+/* Arithmetic convention of the Radon kernel's sampling loop (per context; default ECC_RADON_EXACT).
+ *   ECC_RADON_EXACT: every float expression of ref: RadonIntermediate.cu:118-123 and of the bilinear rule
+ *     ((1 - fx) * T00 + fx * T10, ...) rounded separately, source order -- the CPU reading of the source; results are
+ *     bit-identical to the oracle's normative variant.
+ *   ECC_RADON_FMA: the loop body contracted -- positions fmaf(t, d, o), lerps as T00 + fx * (T10 - T00) with one fused
+ *     multiply-add each (3 differences + 3 fma instead of 11 operations per sample).  This is the arithmetic class of
+ *     the reference's own GPU build, which interpolates in texture hardware (ref: LibUtilsCuda/CudaBindlessTexture.cpp:
+ *     25-39) and whose compiler contracts o + t * d; results are bit-identical to the oracle's contracted variant
+ *     (eccor_set_radon_contract(1)) and move the ECC metric by less than 2e-6 relative (tests/test_gpu_radon_fma.py,
+ *     DESIGN.md 4.1).  About 25 % faster.
+ * The per-bin set-up (line, clipping, bounds test), the accumulation order and the post-process are the same in both. */
+enum { ECC_RADON_EXACT = 0, ECC_RADON_FMA = 1 };
+int ecc_radon_set_arithmetic(ecc_ctx* ctx, int mode);
+int ecc_radon_get_arithmetic(const ecc_ctx* ctx, int* mode);
+
 /* Wraps existing host data (alpha-fast, n_t x n_alpha), ref: RadonIntermediate(ImageView<float>)
  * + replaceRadonIntermediateData (RadonIntermediate.cpp:69-80,105-123). */
 int ecc_dtr_from_host(ecc_ctx* ctx, const float* data, int n_alpha, int n_t, int n_u, int n_v,

@@ -166,13 +166,30 @@ def line_to_sample_dtr(line, range_t, use_ref=False):
     return l, bool(moved)
 
 
-def radon(img, n_alpha, n_t, filter=0, post=0, count_fetches=False):
-    """img: (n_v, n_u) float32.  Returns (n_t, n_alpha) float32 [, fetch count]."""
+class _radon_contract:
+    """eccor_set_radon_contract around one call: the sampling loop of the Radon intermediate in contracted arithmetic
+    (fmaf positions, 3-difference / 3-fmaf texel rule) -- the variant the product's ECC_RADON_FMA mode is pinned to."""
+
+    def __init__(self, L, on):
+        self.L, self.on = L, on
+
+    def __enter__(self):
+        self.L.eccor_set_radon_contract.argtypes = [C.c_int]
+        self.L.eccor_set_radon_contract(1 if self.on else 0)
+
+    def __exit__(self, *a):
+        self.L.eccor_set_radon_contract(0)
+
+
+def radon(img, n_alpha, n_t, filter=0, post=0, count_fetches=False, contract=False, native=False):
+    """img: (n_v, n_u) float32.  Returns (n_t, n_alpha) float32 [, fetch count].  contract: see _radon_contract."""
     img = np.ascontiguousarray(img, np.float32)
     n_v, n_u = img.shape
     out = np.zeros((n_t, n_alpha), np.float32)
     nf = C.c_longlong(0)
-    lib().eccor_radon(img, n_u, n_v, n_alpha, n_t, filter, post, out, C.byref(nf))
+    L = lib(native)
+    with _radon_contract(L, contract):
+        L.eccor_radon(img, n_u, n_v, n_alpha, n_t, filter, post, out, C.byref(nf))
     return (out, nf.value) if count_fetches else out
 
 
@@ -191,12 +208,14 @@ def ramp_filter(dtr):
     return out
 
 
-def radon_bins(img, n_alpha, n_t, bins, filter=0, post=0, native=False):
+def radon_bins(img, n_alpha, n_t, bins, filter=0, post=0, native=False, contract=False):
     img = np.ascontiguousarray(img, np.float32)
     n_v, n_u = img.shape
     bins = np.ascontiguousarray(bins, np.int32)
     out = np.zeros(len(bins), np.float32)
-    lib(native).eccor_radon_bins(img, n_u, n_v, n_alpha, n_t, filter, post, bins, len(bins), out)
+    L = lib(native)
+    with _radon_contract(L, contract):
+        L.eccor_radon_bins(img, n_u, n_v, n_alpha, n_t, filter, post, bins, len(bins), out)
     return out
 
 

@@ -349,6 +349,26 @@ ECCOR_API float eccor_tex2d(const float *img, int W, int H, float x, float y)
     return (1.f - fy) * r0 + fy * r1;
 }
 
+/* The CONTRACTED statement of the same rule (eccor_set_radon_contract(1), Radon intermediate only): what a compiler
+ * that fuses a*b+c does with the lerp written as T00 + fx*(T10 - T00) -- three rounded differences and three fmaf,
+ * 6 operations instead of 11.  The reference's GPU build never executes the unfused form either: it interpolates in
+ * texture hardware (ref: LibUtilsCuda/CudaBindlessTexture.cpp:25-39) and nvcc contracts the position arithmetic
+ * (ref: RadonIntermediate.cu:118-123).  The product's ECC_RADON_FMA mode is held to THIS function bit for bit. */
+static float or_tex2d_contract(const float *img, int W, int H, float x, float y)
+{
+    float xb = x - 0.5f, yb = y - 0.5f;
+    float fi = floorf(xb), fj = floorf(yb);
+    float fx = xb - fi, fy = yb - fj;
+    int i = (int)fi, j = (int)fj;
+    int i0 = or_clampi(i, 0, W - 1), i1 = or_clampi(i + 1, 0, W - 1);
+    int j0 = or_clampi(j, 0, H - 1), j1 = or_clampi(j + 1, 0, H - 1);
+    float T00 = img[(size_t)j0 * W + i0], T10 = img[(size_t)j0 * W + i1];
+    float T01 = img[(size_t)j1 * W + i0], T11 = img[(size_t)j1 * W + i1];
+    float r0 = fmaf(fx, T10 - T00, T00);
+    float r1 = fmaf(fx, T11 - T01, T01);
+    return fmaf(fy, r1 - r0, r0);
+}
+
 /* Normalised coordinates (dtr textures, ref: RadonIntermediate.cpp:192). */
 ECCOR_API float eccor_tex2d_norm(const float *img, int W, int H, float s, float t)
 {
@@ -367,6 +387,13 @@ static void or_sort4(float *v)
         for (i = 0; i < 3; i++)
             if (v[i] > v[i + 1]) { float tmp = v[i]; v[i] = v[i + 1]; v[i + 1] = tmp; }
 }
+
+/* 0: every expression of the sampling loop unfused (normative, the CPU reading of the source); 1: the loop body
+ * contracted -- positions fmaf(t, d, o), texel rule or_tex2d_contract.  The per-bin set-up (line, clipping, bounds
+ * test) and the accumulation are the same rounded operations in both. */
+static int g_radon_contract = 0;
+ECCOR_API void eccor_set_radon_contract(int on) { g_radon_contract = on ? 1 : 0; }
+ECCOR_API int eccor_get_radon_contract(void) { return g_radon_contract; }
 
 /* One Radon bin.  filter: 0 Derivative, 1 Ramp (line integral; the filter follows in eccor_radon), 2 None; post: 0/1/2.
  * ref: RadonIntermediate.cu:32-143 (radonDerivative<derivative>); *fetches += #bilinear fetches. */
@@ -408,21 +435,35 @@ static float or_radon_bin(const float *img, int W, int H, int n_alpha, int n_t, 
     o[0] += .5f;
     o[1] += .5f;
     if (filter != 0) {
-        for (; t <= t_max; t += step) {
-            sum += eccor_tex2d(img, W, H, o[0] + t * d[0], o[1] + t * d[1]);
-            nf++;
-        }
+        if (g_radon_contract)
+            for (; t <= t_max; t += step) {
+                sum += or_tex2d_contract(img, W, H, fmaf(t, d[0], o[0]), fmaf(t, d[1], o[1]));
+                nf++;
+            }
+        else
+            for (; t <= t_max; t += step) {
+                sum += eccor_tex2d(img, W, H, o[0] + t * d[0], o[1] + t * d[1]);
+                nf++;
+            }
         if (fetches) *fetches += nf;
         return sum * step;
     } else {
         float sumo = 0, result;
         o[0] -= .5f * d[1];
         o[1] += .5f * d[0];
-        for (; t <= t_max; t += step) {
-            sum += eccor_tex2d(img, W, H, o[0] + t * d[0], o[1] + t * d[1]);
-            sumo += eccor_tex2d(img, W, H, o[0] + t * d[0] + d[1], o[1] + t * d[1] - d[0]);
-            nf += 2;
-        }
+        if (g_radon_contract)
+            for (; t <= t_max; t += step) {
+                const float x = fmaf(t, d[0], o[0]), y = fmaf(t, d[1], o[1]);
+                sum += or_tex2d_contract(img, W, H, x, y);
+                sumo += or_tex2d_contract(img, W, H, x + d[1], y - d[0]);
+                nf += 2;
+            }
+        else
+            for (; t <= t_max; t += step) {
+                sum += eccor_tex2d(img, W, H, o[0] + t * d[0], o[1] + t * d[1]);
+                sumo += eccor_tex2d(img, W, H, o[0] + t * d[0] + d[1], o[1] + t * d[1] - d[0]);
+                nf += 2;
+            }
         if (fetches) *fetches += nf;
         result = (sum - sumo) * step;
         if (post == 1) return result < 0 ? -sqrtf(-result) : sqrtf(result);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised bit-exactness sweep of the Radon kernel (GPU box): python scripts/fuzz_radon.py [cases] [seed]
+"""Randomised bit-exactness sweep of the Radon kernel (GPU box): python scripts/fuzz_radon.py [cases] [seed] [exact|fma|both]
+(third argument: the arithmetic mode, ecc_radon_set_arithmetic; "both" alternates per case; each mode against ITS oracle variant)
 Random image sizes (odd, tiny, wide, tall), bin grids, filters (derivative / none) and post-processes, image contents
 (smooth, noise, constant, sparse) -> np.array_equal against the oracle.  Filter::Ramp goes through a float64
 convolution and is compared at 1e-6 of the maximum."""
@@ -15,6 +16,7 @@ import oracle  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+arith = sys.argv[3] if len(sys.argv) > 3 else "exact"
 rng = np.random.default_rng(seed)
 ctx = E.Context(0)
 bad = 0
@@ -37,13 +39,15 @@ for c in range(cases):
     else:
         img = np.zeros((n_v, n_u), np.float32)
         img[rng.integers(0, n_v, 5), rng.integers(0, n_u, 5)] = 1000.0
+    mode = arith if arith != "both" else ("fma" if c % 2 else "exact")
+    ctx.setRadonArithmetic(mode)
     n_img = int(rng.integers(1, 4))
     imgs = np.stack([img * (k + 1) for k in range(n_img)])
     dtrs = E.RadonIntermediate.compute_batch(ctx, imgs, n_alpha, n_t, filter=filt, post_process=post)
     ok = True
     for k, d in enumerate(dtrs):
         got = d.readback()
-        want = oracle.radon(imgs[k], n_alpha, n_t, filter=filt, post=post)
+        want = oracle.radon(imgs[k], n_alpha, n_t, filter=filt, post=post, contract=mode == "fma")
         if filt == E.FILTER_RAMP:
             ok = ok and np.abs(got - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-30)
         else:
@@ -51,7 +55,7 @@ for c in range(cases):
         d.close()
     if not ok:
         bad += 1
-    print("case %2d: %3dx%3d x%d -> %3dx%3d filter %d post %d kind %d: %s" % (c, n_u, n_v, n_img, n_alpha, n_t, filt, post, kind,
-                                                                           "ok" if ok else "MISMATCH"), flush=True)
+    print("case %2d: %3dx%3d x%d -> %3dx%3d filter %d post %d kind %d %s: %s" % (c, n_u, n_v, n_img, n_alpha, n_t, filt, post, kind, mode,
+                                                                              "ok" if ok else "MISMATCH"), flush=True)
 print("%d of %d cases differ, %.1f s" % (bad, cases, time.time() - t0))
 sys.exit(1 if bad else 0)

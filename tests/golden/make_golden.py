@@ -18,6 +18,10 @@ container that has /root/reference):
   variants_128.npz      SURVEY.md 8c (a) and (d): every Radon filter / post-process on one 128x96 image at 96x80
                         bins; index-list, subset and user-parameter variants of the metric on the 8-view set.
 
+  radon_contract.npz    round 4: the CONTRACTED arithmetic variant of the Radon intermediate (eccor_set_radon_contract(1),
+                        what ecc_radon_set_arithmetic(ECC_RADON_FMA) is held to bit for bit) on the three data sets above:
+                        dtr checksums, sparse samples, and the metric evaluated on those dtrs next to the exact variant's.
+
 The reference has no golden vectors for this path: these pin the ORACLE against
 regressions and travel to the GPU box, where /root/reference does not exist.
 """
@@ -156,10 +160,49 @@ def variants():
     print("variants: idx mean %.9g subset mean %.9g param mean %.9g" % (r_idx["mean"], r_sub["mean"], r_par["mean"]))
 
 
+def radon_contract():
+    out = {}
+    for tag in ("example_pair_256", "example_pair_native"):
+        g = np.load(os.path.join(HERE, tag + ".npz"))
+        imgs, Ps = g["images"], list(g["Ps"])
+        n_v, n_u = imgs[0].shape
+        n_alpha, n_t = int(g["n_alpha"]), int(g["n_t"])
+        dtrs = [oracle.radon(im, n_alpha, n_t, contract=True) for im in imgs]
+        exact = [oracle.radon(im, n_alpha, n_t) for im in imgs]
+        assert all(np.array_equal(checksum(d), c) for d, c in zip(exact, g["dtr_checksums"]))  # the exact variant is what it was
+        res = oracle.evaluate_all(Ps, dtrs, n_u, n_v)
+        k = "pair256" if tag.endswith("256") else "native"
+        out[k + "_dtr_checksums"] = np.stack([checksum(d) for d in dtrs])
+        out[k + "_dtr_samples"] = np.stack([d.reshape(-1)[g["sample_bins"]] for d in dtrs])
+        out[k + "_mean"] = res["mean"]
+        out[k + "_mean_exact"] = float(g["mean"])
+        out[k + "_max_bin_dev_rel"] = max(np.abs(a - b).max() for a, b in zip(dtrs, exact)) / max(np.abs(b).max() for b in exact)
+        print("%s: contracted mean %.9g, exact %.9g (rel %.2e), max bin deviation / max|dtr| %.2e"
+              % (tag, res["mean"], float(g["mean"]), abs(res["mean"] - float(g["mean"])) / abs(float(g["mean"])), out[k + "_max_bin_dev_rel"]))
+    from conftest import make_small_scan
+    Ps, imgs = make_small_scan()
+    dtrs = [oracle.radon(im, 96, 96, contract=True) for im in imgs]
+    res = oracle.evaluate_all(Ps, dtrs, 128, 128)
+    out["synthetic8_dtr_checksums"] = np.stack([checksum(d) for d in dtrs])
+    out["synthetic8_mean"] = res["mean"]
+    out["synthetic8_pairs"] = res["pairs"]
+    v = np.load(os.path.join(HERE, "variants_128.npz"))
+    for name, (f, post) in dict(deriv=(0, 0), deriv_sqrt=(0, 1), deriv_log=(0, 2), plain=(2, 0), ramp=(1, 0)).items():
+        d = oracle.radon(v["image"], 96, 80, filter=f, post=post, contract=True)
+        out["variants_%s_checksum" % name] = checksum(d)
+        out["variants_%s_samples" % name] = d.reshape(-1)[v["bins"]]
+    np.savez_compressed(os.path.join(HERE, "radon_contract.npz"), **out)
+    print("radon_contract: synthetic8 mean %.9g" % res["mean"])
+
+
 if __name__ == "__main__":
+    if "--only-contract" in sys.argv:
+        radon_contract()
+        sys.exit(0)
     if os.path.isdir(REF):
         example_pair()
         example_pair_native()
     synthetic8()
     widened_rows()
     variants()
+    radon_contract()
