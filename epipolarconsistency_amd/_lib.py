@@ -64,6 +64,7 @@ SIGNATURES = {
     "ecc_metric_set_sampling": (_i, [_vp, _i]),
     "ecc_metric_set_incremental": (_i, [_vp, _i]),
     "ecc_metric_set_record_reuse": (_i, [_vp, _i]),
+    "ecc_metric_set_small_eval": (_i, [_vp, _i]),
     "ecc_metric_publish_scalar": (_i, [_vp, _vp]),
     "ecc_metric_wait_scalar": (_i, [_vp, _pd]),
     "ecc_metric_last_evaluated_pairs": (_i, [_vp, C.POINTER(_i64)]),

@@ -457,6 +457,11 @@ class MetricRadonIntermediate:
             check(_lib.lib().ecc_metric_set_record_reuse(self._h, int(self._record_reuse)))
         return self
 
+    def setSmallEval(self, on=True):
+        """ecc_metric_set_small_eval: evaluations of at most 4096 pairs as ONE launch (default on; bit-identical results)."""
+        check(_lib.lib().ecc_metric_set_small_eval(self._h, 1 if on else 0))
+        return self
+
     def last_evaluated_pairs(self):
         """Pairs the last evaluate() / evaluate_range() actually recomputed."""
         v = C.c_int64()

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <new>
 #include <string>
@@ -43,6 +44,8 @@ extern "C" hipError_t ecc_launch_build_quad(const float* const* slabs_tbl_d, flo
                                             int rows, int pitch, hipStream_t stream);
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
+extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds_bytes);
+extern "C" hipError_t ecc_launch_small_eval(const EccPairParams* p, const EccSmallEval* x, hipStream_t stream);
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream);
 extern "C" size_t ecc_preprocess_lds_bytes(int k);
 extern "C" hipError_t ecc_launch_direct_views(const double* Ps_d, int n, EccDirectView* views, int n_u, int n_v,
@@ -196,7 +199,11 @@ struct ecc_metric {
     // stay in records_d together with the matrices and parameters they belong to; the next evaluation of the same range
     // refits only the pairs with a changed matrix.  E1 is deferred to the evaluation for the same reason.
     int record_reuse = 1;
-    bool e1_pending = false;   // matrices of set_generation are staged, e1_kernel has not been launched for them
+    bool e1_pending = false;   // matrices were staged since PinvTs_d / Cs_d were last known to be current (ensure_e1 finds out)
+    // the matrices PinvTs_d / Cs_d on the device were made from, view by view (e1_kernel: all views; the patch lists of the
+    // reuse path and of the one-launch path: the listed views)
+    std::vector<double> dev_Ps;
+    bool dev_valid = false;
     bool eager_e1 = false;     // the last range was too small for record reuse: set_projections launches e1_kernel itself
     bool rec_valid = false;
     int64_t rec_first = 0, rec_count = 0;
@@ -211,12 +218,24 @@ struct ecc_metric {
     hipEvent_t reuse_ev[2] = {nullptr, nullptr};  // recorded after the k01 launch that read list b (asynchronous callers)
     bool reuse_ev_used[2] = {false, false};
     uint64_t reuse_gen = 0;
+    std::vector<int> scratch_patched;
     std::vector<int32_t> scratch_refs;
     std::vector<int32_t> scratch_patch_of;
     // second stream of the reuse path: refit + list launch of the changed pairs run there while the all-pairs launch
     // (which skips them) already runs on the context's stream
     hipStream_t side_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // ecc_metric_set_small_eval: evaluations of at most ECC_SMALL_EVAL_MAX_PAIRS pairs as ONE launch (small_eval_kernel.hip).
+    // E1 of the views whose matrix changed since the device arrays were made is done on the host and handed over in the
+    // kernel arguments (dev_Ps above says which views those are).
+    int small_eval = 1;
+    int32_t* sidx_h = nullptr;    // index list of a fused index-list evaluation (pinned, device-mapped)
+    int32_t* sidx_h_dev = nullptr;
+    int64_t sidx_capacity = 0;    // pairs
+    float* svals_h = nullptr;     // pair values a caller wants on the host (pinned, device-mapped)
+    float* svals_h_dev = nullptr;
+    int64_t svals_capacity = 0;
+    unsigned* small_ticket_d = nullptr;
 };
 
 namespace {
@@ -938,7 +957,14 @@ int ensure_e1(ecc_metric* m)
 {
     if (!m->e1_pending) return ECC_OK;
     const int slot = (int)(m->set_generation & 1);
+    const size_t n12 = (size_t)12 * m->n_views;
+    if (m->dev_valid && m->dev_Ps.size() == n12 && std::memcmp(m->dev_Ps.data(), m->Ps_h[slot], sizeof(double) * n12) == 0) {
+        m->e1_pending = false;  // the device arrays already belong to these matrices (patched view by view, or set back)
+        return ECC_OK;
+    }
     HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], m->n_views, m->PinvTs_d, m->Cs_d, m->ctx->stream));
+    m->dev_Ps.assign(m->Ps_h[slot], m->Ps_h[slot] + n12);
+    m->dev_valid = true;
     m->e1_pending = false;
     // The reuse path of launch_range assumes PinvTs / Cs on the device are E1(rec_Ps) for every view it finds unchanged.
     // This launch has just made them E1 of the CURRENT matrices for all views (an image-pair or debug call between two
@@ -954,11 +980,14 @@ ECC_EXPORT int ecc_metric_set_record_reuse(ecc_metric* m, int on)
     if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
     m->record_reuse = on < 0 ? 0 : (on > 2 ? 2 : on);
     m->rec_valid = false;
-    if (!m->record_reuse && m->n_views > 0) {
-        const int rc = set_device(m->ctx);
-        if (rc) return rc;
-        return ensure_e1(m);
-    }
+    if (!m->record_reuse) m->eager_e1 = true;  // until an evaluation says otherwise
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_metric_set_small_eval(ecc_metric* m, int on)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    m->small_eval = on ? 1 : 0;
     return ECC_OK;
 }
 
@@ -997,6 +1026,9 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     }
     if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
     if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+    if (m->sidx_h) (void)hipHostFree(m->sidx_h);
+    if (m->svals_h) (void)hipHostFree(m->svals_h);
+    if (m->small_ticket_d) (void)hipFree(m->small_ticket_d);
     delete m;
     return ECC_OK;
 }
@@ -1021,6 +1053,7 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
         m->Cs_d = m->PinvTs_d = nullptr;
         m->Ps_d = nullptr;
         m->geom_capacity = 0;
+        m->dev_valid = false;
         HIP_TRY(hipMalloc((void**)&m->Cs_d, sizeof(float) * 4 * n_views));
         HIP_TRY(hipMalloc((void**)&m->PinvTs_d, sizeof(float) * 12 * n_views));
         HIP_TRY(hipMalloc((void**)&m->Ps_d, sizeof(double) * 12 * n_views));
@@ -1046,7 +1079,7 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
     // E1 itself is launched by whoever needs PinvTs / Cs next (ensure_e1): an evaluation that finds most matrices
     // unchanged computes the few changed views on the host and never launches it.
     m->e1_pending = true;
-    if (!m->record_reuse || m->eager_e1) return ensure_e1(m);  // nobody is going to skip it: launch it now, as round 2 did
+    if (m->eager_e1) return ensure_e1(m);  // the last evaluation needed it on the device and skipped nothing: launch it now
     return ECC_OK;
 }
 
@@ -1190,6 +1223,114 @@ int ensure_reuse_list(ecc_metric* m, int b, int64_t words)
     return ECC_OK;
 }
 
+// One launch for an evaluation of at most ECC_SMALL_EVAL_MAX_PAIRS pairs (small_eval_kernel.hip; ref for what it replaces:
+// ...RadonIntermediate.cu:300-409, two kernels and two device-wide syncs).  p: the launch as fill_pair_params and the caller
+// left it (first, count, pair_values, cost; indices ignored -- the list comes as idx4_host).  E1 of the views whose
+// matrix differs from what PinvTs_d / Cs_d were made from (dev_Ps) is computed here on the host with the code e1_kernel
+// compiles (ecc_host_geometry.h, bit-identical) and travels in the kernel arguments -- at most ECC_SMALL_PATCH_MAX views;
+// beyond that (the first call, a new trajectory) e1_kernel runs in front.  The kept records are not touched.
+// *taken = false: the evaluation does not qualify and nothing was launched.
+unsigned long long* g_small_dbg = nullptr;
+int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, double* sum_d, bool values_to_host, bool synchronous,
+                   bool* taken)
+{
+    *taken = false;
+    int wpp = 0;
+    size_t lds = 0;
+    if (!m->small_eval || !ecc_small_eval_plan(&p, &wpp, &lds)) return ECC_OK;
+    const double T0 = now_seconds();
+    ecc_ctx* ctx = m->ctx;
+    const int n = m->n_views;
+    if (!m->small_ticket_d) {
+        HIP_TRY(hipMalloc((void**)&m->small_ticket_d, sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(m->small_ticket_d, 0, sizeof(unsigned), ctx->stream));
+    }
+    EccSmallEval x;
+    std::memset(&x, 0, sizeof(x));
+    const int slot = (int)(m->set_generation & 1);
+    const double* Pcur = m->Ps_h[slot];
+    // views whose geometry on the device is behind the current matrices
+    std::vector<int>& stale = m->scratch_changed;
+    stale.clear();
+    const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * (int64_t)n;
+    if (dev_known && m->e1_pending)
+        for (int v = 0; v < n && (int)stale.size() <= ECC_SMALL_PATCH_MAX; ++v)
+            if (std::memcmp(Pcur + 12 * v, m->dev_Ps.data() + 12 * v, sizeof(double) * 12) != 0) stale.push_back(v);
+    if (!dev_known || (int)stale.size() > ECC_SMALL_PATCH_MAX) {
+        const int rc = ensure_e1(m);  // the first call, a new trajectory: e1_kernel, ordered before the launch below
+        if (rc) return rc;
+    } else {
+        for (size_t e = 0; e < stale.size(); ++e) {  // ref: ...RadonIntermediate.cpp:134-163
+            const int v = stale[e];
+            ecc_host::pinv_transpose(Pcur + 12 * v, x.patch_geo[e]);
+            ecc_host::source_position(Pcur + 12 * v, x.patch_geo[e] + 12);
+            x.patch_views[e] = v;
+            std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);  // workgroup 0 stores the entry
+        }
+        x.patch_count = (int)stale.size();
+        m->e1_pending = false;
+    }
+    p.PinvTs = m->PinvTs_d;
+    p.Cs = m->Cs_d;
+    p.indices = nullptr;
+    if (idx4_host) {
+        if (m->sidx_capacity < p.count) {
+            if (m->sidx_h) HIP_TRY(hipHostFree(m->sidx_h));
+            m->sidx_h = nullptr;
+            m->sidx_capacity = 0;
+            const int64_t cap = std::max<int64_t>(2 * p.count, 1024);
+            HIP_TRY(hipHostMalloc((void**)&m->sidx_h, sizeof(int32_t) * 4 * cap, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&m->sidx_h_dev, m->sidx_h, 0));
+            m->sidx_capacity = cap;
+        }
+        std::memcpy(m->sidx_h, idx4_host, sizeof(int32_t) * 4 * (size_t)p.count);
+        p.indices = m->sidx_h_dev;
+    }
+    x.sum_out = sum_d;
+    x.ticket = m->small_ticket_d;
+    if (values_to_host) {
+        if (m->svals_capacity < p.count) {
+            if (m->svals_h) HIP_TRY(hipHostFree(m->svals_h));
+            m->svals_h = nullptr;
+            m->svals_capacity = 0;
+            const int64_t cap = std::max<int64_t>(2 * p.count, 1024);
+            HIP_TRY(hipHostMalloc((void**)&m->svals_h, sizeof(float) * cap, hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&m->svals_h_dev, m->svals_h, 0));
+            m->svals_capacity = cap;
+        }
+        x.values_host = m->svals_h_dev;
+    }
+    static unsigned long long* dbg_d = [] {  // experiments only: ECC_SMALL_DEBUG=1, read back by ecc_debug_small_stamps
+        unsigned long long* d = nullptr;
+        if (std::getenv("ECC_SMALL_DEBUG")) (void)hipMalloc((void**)&d, sizeof(unsigned long long) * 4 * 4096);
+        return d;
+    }();
+    x.dbg = dbg_d;
+    g_small_dbg = dbg_d;
+    {
+        const char* e = std::getenv("ECC_SMALL_DBG_MODE");  // experiments only (read per call: the script changes it)
+        x.dbg_mode = e ? std::atoi(e) : 0;
+    }
+    std::atomic_thread_fence(std::memory_order_seq_cst);  // the host's writes to pinned memory before the doorbell
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    const double T1 = now_seconds();
+    HIP_TRY(ecc_launch_small_eval(&p, &x, ctx->stream));
+    const double T2 = now_seconds();
+    if (dbg_d) {
+        static int cnt = 0;
+        if ((++cnt % 100) == 0) std::fprintf(stderr, "[small] prep %.2f us launch %.2f us\n", 1e6 * (T1 - T0), 1e6 * (T2 - T1));
+    }
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        ctx->ev_valid[0] = true;
+    }
+    (void)synchronous;
+    m->eager_e1 = false;  // the views that changed are patched by the next launch: ecc_metric_set_projections does not launch E1
+    m->last_evaluated_pairs = p.count;
+    *taken = true;
+    return ECC_OK;
+}
+
 // k01_kernel + pairs_kernel (+ sum) over the pair range [first, first + count).
 // Record reuse (default on, ecc_metric_set_record_reuse): a pair's record is a function of its two matrices and the
 // parameters only.  When this range was evaluated before with the same parameters and at most a quarter of the matrices
@@ -1221,6 +1362,12 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     p.K01_out = K01_d;
     p.records = m->records_d;
     m->last_evaluated_pairs = count;
+    if (sum_d && pair_values_d) {  // few pairs: ONE launch (small_eval_kernel.hip), the kept records are not touched
+        bool taken = false;
+        rc = try_small_eval(m, p, nullptr, sum_d, false, synchronous, &taken);
+        if (rc) return rc;
+        if (taken) return ECC_OK;
+    }
 
     const int mode = p.reference_arithmetic ? ECC_SAMPLING_REFERENCE : (p.poly ? ECC_SAMPLING_POLYNOMIAL : ECC_SAMPLING_PER_SAMPLE);
     const double* Pcur = m->Ps_h[m->set_generation & 1];
@@ -1230,7 +1377,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     // view's own pairs include its neighbours', whose waves run 40-50 us (64 views, 2016 pairs: 61 us per step with two
     // streams against 40 us refitting everything).  Mode 2 (tests) applies the two-stream form at every size.
     const bool size_ok = m->record_reuse >= 2 || count > ECC_RECORD_REUSE_MIN_PAIRS;
-    m->eager_e1 = !size_ok;
+    m->eager_e1 = !m->record_reuse || !size_ok;
     const bool rec_match = m->record_reuse && size_ok && m->rec_valid && !K01_d && count > 0 && m->rec_first == first && m->rec_count == count &&
                            m->rec_n_views == (int)n && m->rec_mode == mode && m->rec_radius == p.object_radius_mm &&
                            m->rec_dkappa == p.dkappa_user && m->rec_tol == p.economise_tol && (int64_t)m->rec_Ps.size() == 12 * n;
@@ -1241,8 +1388,19 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         changed.clear();
         for (int64_t v = 0; v < n; ++v)
             if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
-        if ((int64_t)changed.size() * 4 <= n) {
-            const int64_t C = (int64_t)changed.size();
+        // views whose geometry on the device is not that of the current matrices although their records are (an E1 launch
+        // or a patch list of another call in between): they need a patch entry too, but no refit
+        std::vector<int>& patched = m->scratch_patched;
+        patched = changed;
+        const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * n;
+        if (dev_known) {
+            for (int64_t v = 0; v < n; ++v)
+                if (std::memcmp(Pcur + 12 * v, m->dev_Ps.data() + 12 * v, sizeof(double) * 12) != 0 &&
+                    std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) == 0)
+                    patched.push_back((int)v);
+        }
+        if (dev_known && (int64_t)patched.size() * 4 <= n) {
+            const int64_t C = (int64_t)changed.size(), Cp = (int64_t)patched.size();
             // Two streams: the all-pairs launch that SKIPS the pairs of the changed views starts at once on the context's
             // stream; the refit of those pairs and their own list launch follow on the metric's side stream, hidden behind
             // it; the sum waits for both.  (Not with a cost image -- the list launch does not write it --, not in the
@@ -1276,10 +1434,8 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots, &refs = m->scratch_refs, &patch_of = m->scratch_patch_of;
             is_changed.assign((size_t)n, 0);
             patch_of.assign((size_t)n, -1);
-            for (size_t e = 0; e < changed.size(); ++e) {
-                is_changed[changed[e]] = 1;
-                patch_of[changed[e]] = (int32_t)e;
-            }
+            for (int v : changed) is_changed[v] = 1;
+            for (size_t e = 0; e < patched.size(); ++e) patch_of[patched[e]] = (int32_t)e;
             idx.clear();
             slots.clear();
             refs.clear();
@@ -1299,7 +1455,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             // L = 0 (no pair of this range contains a changed view): nothing to refit and nothing launched; rec_Ps keeps
             // the old matrices of those views, which is what PinvTs / Cs on the device still correspond to
             if (L > 0) {
-                rc = ensure_reuse_list(m, b, 7 * L + 17 * C);
+                rc = ensure_reuse_list(m, b, 7 * L + 17 * Cp);
                 if (rc) return rc;
                 if (m->reuse_ev_used[b]) {  // an asynchronous caller: the launches that read this buffer two calls ago
                     HIP_TRY(hipEventSynchronize(m->reuse_ev[b]));
@@ -1310,19 +1466,19 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 std::memcpy(h + 4 * L, slots.data(), sizeof(int32_t) * L);
                 std::memcpy(h + 5 * L, refs.data(), sizeof(int32_t) * 2 * L);
                 float* geo = reinterpret_cast<float*>(h + 7 * L);
-                int32_t* views = h + 7 * L + 16 * C;
-                for (int64_t e = 0; e < C; ++e) {  // E1 of the changed views (ref: ...RadonIntermediate.cpp:134-163)
-                    ecc_host::pinv_transpose(Pcur + 12 * changed[e], geo + 16 * e);
-                    ecc_host::source_position(Pcur + 12 * changed[e], geo + 16 * e + 12);
-                    views[e] = changed[e];
+                int32_t* views = h + 7 * L + 16 * Cp;
+                for (int64_t e = 0; e < Cp; ++e) {  // E1 of the patched views (ref: ...RadonIntermediate.cpp:134-163)
+                    ecc_host::pinv_transpose(Pcur + 12 * patched[e], geo + 16 * e);
+                    ecc_host::source_position(Pcur + 12 * patched[e], geo + 16 * e + 12);
+                    views[e] = patched[e];
                 }
                 EccPairParams q = p;  // k01_kernel over the list
                 q.indices = m->reuse_h_dev[b];
                 q.record_slots = m->reuse_h_dev[b] + 4 * L;
                 q.patch_ref = m->reuse_h_dev[b] + 5 * L;
                 q.patch_geo = reinterpret_cast<const float*>(m->reuse_h_dev[b] + 7 * L);
-                q.patch_views = m->reuse_h_dev[b] + 7 * L + 16 * C;
-                q.patch_count = (int)C;
+                q.patch_views = m->reuse_h_dev[b] + 7 * L + 16 * Cp;
+                q.patch_count = (int)Cp;
                 q.first = 0;
                 q.count = L;
                 q.cost = nullptr;
@@ -1343,8 +1499,10 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                     m->reuse_ev_used[b] = true;
                 }
                 for (int v : changed) std::memcpy(m->rec_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
+                for (int v : patched) std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
+                m->e1_pending = false;  // workgroup 0 of the list launch stores the patches: PinvTs / Cs are current again
             }
-            if (L > 0 || C == 0) m->e1_pending = false;  // PinvTs / Cs are those of the current matrices again
+            // (L = 0: nothing was launched; dev_Ps says which views of the device arrays are behind, ensure_e1 will look)
             reused = true;
         }
     }
@@ -1614,10 +1772,35 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     if (rc) return rc;
     rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, n_pairs, ctx->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(m->indices_d, idx4, sizeof(int32_t) * 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     EccPairParams p;
-    rc = fill_pair_params(m, &p, n_pairs);
+    rc = fill_pair_params(m, &p, n_pairs, /*need_e1=*/false);
     if (rc) return rc;
+    {   // few pairs: ONE launch; the list and the values travel through pinned memory, no copy commands
+        EccPairParams q = p;
+        q.first = 0;
+        q.count = n_pairs;
+        q.pair_values = m->pair_values_d;
+        bool taken = false;
+        arm_result(m);
+        rc = try_small_eval(m, q, idx4, m->sum_h_dev, out != nullptr, /*synchronous=*/true, &taken);
+        if (rc) return rc;
+        if (taken) {
+            double sum = 0.0;
+            const double W0 = now_seconds();
+            HIP_TRY(wait_result(m, ctx->stream, &sum));
+            if (g_small_dbg) {
+                static int cnt = 0;
+                if ((++cnt % 100) == 0) std::fprintf(stderr, "[small] wait %.2f us\n", 1e6 * (now_seconds() - W0));
+            }
+            m->done_generation = m->set_generation;
+            if (out) std::memcpy(out, m->svals_h, sizeof(float) * (size_t)n_pairs);
+            *mean = sum / (double)n_pairs;
+            return ECC_OK;
+        }
+    }
+    rc = ensure_e1(m);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(m->indices_d, idx4, sizeof(int32_t) * 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     m->rec_valid = false;  // the list's records overwrite the kept ones
     rc = ensure_capacity(&m->records_d, &m->records_capacity, n_pairs, ctx->stream);
     if (rc) return rc;
@@ -2459,4 +2642,12 @@ ECC_EXPORT int ecc_metric_debug_polynomials(ecc_metric* m, int64_t first, int64_
             for (int k = 0; k < ECC_POLY_DEG + 2; ++k) *o++ = r.cd[v][k];
     }
     return ECC_OK;
+}
+
+/* Experiments (ECC_SMALL_DEBUG=1): the wall-clock stamps (100 MHz) of the last small_eval_kernel launch, 4 per workgroup. */
+ECC_EXPORT int ecc_debug_small_stamps(unsigned long long* out, int n_blocks)
+{
+    if (!g_small_dbg || !out || n_blocks < 1 || n_blocks > 4096) return ECC_ERR_INVALID_ARGUMENT;
+    if (hipDeviceSynchronize() != hipSuccess) return ECC_ERR_HIP;
+    return hipMemcpy(out, g_small_dbg, sizeof(unsigned long long) * 4 * n_blocks, hipMemcpyDeviceToHost) == hipSuccess ? ECC_OK : ECC_ERR_HIP;
 }

@@ -140,6 +140,25 @@ struct EccPairParams {
     int wide_offsets;          // a row-paired copy is 2^24 bytes or more: integer instead of fp32 offset arithmetic
 };
 
+// ---- one-launch evaluation of small pair sets (small_eval_kernel.hip) ---------------------------
+#define ECC_SMALL_EVAL_MAX_PAIRS 4096
+#define ECC_SMALL_PATCH_MAX 16
+#define ECC_SMALL_MAGIC 0x45434353u
+struct EccSmallEval {
+    double* sum_out;     // float64 sum of the pair values: the pinned result slot the host polls or a device scalar; null: no sum
+    unsigned* ticket;    // device counter, zero between launches
+    float* values_host;  // optional pinned, device-mapped array: the workgroup that sums also copies all values there
+    int stage_stride;    // floats per pair of the LDS stage (set by the launcher)
+    unsigned long long* dbg;  // optional (ECC_SMALL_DEBUG): 4 wall-clock stamps per workgroup (start, records done, value stored, sum stored)
+    int dbg_mode;        // experiments (ECC_SMALL_DBG_MODE): 1 / 2 / 3 = workgroup 0 reports at entry / after the records / after its value
+    unsigned magic;      // ECC_SMALL_MAGIC (set by the launcher): the kernel reads the patch list in place in its argument segment
+    // E1 of the views whose matrix changed since the device arrays PinvTs / Cs were made, computed on the host
+    // (ecc_host_geometry.h) and handed over in the kernel arguments: (P^+)^T (12) + C (4) per entry
+    int patch_count;
+    int patch_views[ECC_SMALL_PATCH_MAX];
+    float patch_geo[ECC_SMALL_PATCH_MAX][16];
+};
+
 // ---- projection pre-processing ------------------------------------------------
 #define ECC_PRE_MAX_CHUNKS 32  // workgroups per image of the maximum search in front of PreProccess::process (normalize)
 struct EccPreprocessParams {

@@ -250,6 +250,18 @@ int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
  * cannot hide the refit's launches: measured 2016 pairs, 61 us per step with two streams, 40 us refitting everything; a
  * 10 873-pair shard 63 us with, 77 us without); 2 = the two-stream form for every size (tests). */
 int ecc_metric_set_record_reuse(ecc_metric* m, int on);
+
+/* One launch per small evaluation (default on).  An evaluation of at most 4096 pairs -- ecc_metric_evaluate_all of up to 91
+ * views, ecc_metric_evaluate_range[_async] shards, ecc_metric_evaluate_pairs index lists; not with use_corr -- runs as ONE
+ * kernel instead of the stream-ordered launches E1, K01, pairs, sum (the reference: two kernels, two device-wide syncs and
+ * a host loop, ref: EpipolarConsistencyRadonIntermediate.cu:300-409, ...RadonIntermediate.cpp:197-224; its working
+ * optimiser caller evaluates a handful of pairs per objective call, ref: tools/FluoroTracking/FluoroTracking.cpp:179-211):
+ * E1 of the views whose matrix changed is computed on the host (the same code, bit-identical) into pinned memory the kernel
+ * reads, each workgroup fits its pairs' records, samples them with 4 / 2 / 1 waves per pair and the workgroup that arrives
+ * last adds the values in the sum kernel's order.  Index lists and the pair values a caller asks for travel through pinned
+ * memory (no copy commands).  Every value and every sum has the bits of the multi-launch path
+ * (tests/test_gpu_small_eval.py); on = 0 keeps that path. */
+int ecc_metric_set_small_eval(ecc_metric* m, int on);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */
 int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);

@@ -9,7 +9,8 @@ n, S, B = 400, 1024, 768
 dev = torch.device("cuda", 0)
 Ps = synthetic.short_scan(n, S, S, 0.308)
 ph = synthetic.sphere_phantom()
-ctx = E.Context(0)
+torch.cuda.set_stream(torch.cuda.Stream(dev))  # a stream of our own, not the legacy default stream
+ctx = E.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 slabs = torch.zeros((n, E.slab_floats(B, B)), dtype=torch.float32, device=dev)
 dtrs = []
 for a in range(0, n, 50):
