@@ -54,6 +54,7 @@ extern "C" hipError_t ecc_launch_direct_transpose(const float* src, float* dst, 
 extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* total, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, void* scratch, hipStream_t stream);
+extern "C" hipError_t ecc_launch_sum_pairs_to_host(const float* vals, long long count, double* out, float* values_host, hipStream_t stream);
 extern "C" hipError_t ecc_launch_publish_scalar(const double* value_d, double* host_slot_dev, hipStream_t stream);
 extern "C" size_t ecc_sum_scratch_bytes();
 extern "C" hipError_t ecc_launch_e1(const double* Ps_d, int n, float* PinvTs_d, float* Cs_d, hipStream_t stream);
@@ -236,6 +237,7 @@ struct ecc_metric {
     float* svals_h_dev = nullptr;
     int64_t svals_capacity = 0;
     unsigned* small_ticket_d = nullptr;
+    int64_t small_pending_count = 0;  // > 0: the result slot will receive the "done" word of a one-launch evaluation of that many pairs
 };
 
 namespace {
@@ -1231,14 +1233,95 @@ int ensure_reuse_list(ecc_metric* m, int b, int64_t words)
 // beyond that (the first call, a new trajectory) e1_kernel runs in front.  The kept records are not touched.
 // *taken = false: the evaluation does not qualify and nothing was launched.
 unsigned long long* g_small_dbg = nullptr;
-int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, double* sum_d, bool values_to_host, bool synchronous,
-                   bool* taken)
+
+// Pinned, device-mapped staging of index-list evaluations: the list (4 ints per pair) and the pair values.
+int ensure_small_host_buffers(ecc_metric* m, int64_t idx_pairs, int64_t value_pairs)
+{
+    if (m->sidx_capacity < idx_pairs) {
+        HIP_TRY(wait_stream_spin(m->ctx->stream));  // nothing may still be reading the old buffer
+        if (m->sidx_h) HIP_TRY(hipHostFree(m->sidx_h));
+        m->sidx_h = nullptr;
+        m->sidx_capacity = 0;
+        const int64_t cap = std::max<int64_t>(2 * idx_pairs, 1024);
+        HIP_TRY(hipHostMalloc((void**)&m->sidx_h, sizeof(int32_t) * 4 * cap, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&m->sidx_h_dev, m->sidx_h, 0));
+        m->sidx_capacity = cap;
+    }
+    if (m->svals_capacity < value_pairs) {
+        HIP_TRY(wait_stream_spin(m->ctx->stream));
+        if (m->svals_h) HIP_TRY(hipHostFree(m->svals_h));
+        m->svals_h = nullptr;
+        m->svals_capacity = 0;
+        const int64_t cap = std::max<int64_t>(2 * value_pairs, 1024);
+        HIP_TRY(hipHostMalloc((void**)&m->svals_h, sizeof(float) * cap, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&m->svals_h_dev, m->svals_h, 0));
+        m->svals_capacity = cap;
+    }
+    return ECC_OK;
+}
+constexpr unsigned long long ECC_SMALL_DONE_TOKEN = 0x7ff8ecc0d04e0001ull;  // a NaN payload: not a sum, not ECC_RESULT_PENDING
+
+// The float64 sum of `count` <= 4096 pair values exactly as sum_pairs_kernel forms it (pairs_kernel.hip; ref:
+// ...RadonIntermediate.cpp:216-224): thread t of its 1024 holds ((0 + v[4t]) + (0 + v[4t+1])) + ((0 + v[4t+2]) + (0 + v[4t+3]))
+// (one float4 at most for such a count), thread 0 then adds the up to three values past the last float4, the 64 threads
+// of a wave are combined by the shuffle-down tree (offsets 32 ... 1), the 16 wave sums are added in order.  IEEE binary64
+// additions in the same order: the same bits.
+double small_sum_on_host(const float* v, int64_t count)
+{
+    const int64_t n4 = count >> 2;
+    double tot = 0.0;
+    for (int w = 0; w < 16; ++w) {
+        double a[64];
+        for (int l = 0; l < 64; ++l) {
+            const int64_t t = 64 * w + l;
+            double acc = 0.0;
+            if (t < n4) {
+                const double a0 = 0.0 + (double)v[4 * t], a1 = 0.0 + (double)v[4 * t + 1], a2 = 0.0 + (double)v[4 * t + 2],
+                             a3 = 0.0 + (double)v[4 * t + 3];
+                acc = (a0 + a1) + (a2 + a3);
+            }
+            if (t == 0)
+                for (int64_t k = n4 << 2; k < count; ++k) acc += (double)v[k];
+            a[l] = acc;
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            for (int l = 0; l < off; ++l) a[l] += a[l + off];  // what lane 0 of __shfl_down's tree ends up with
+        tot += a[0];
+    }
+    return tot;
+}
+
+// Waits for the "done" word of the one-launch evaluation (the result slot, armed by the caller) and adds the values.
+hipError_t wait_small_eval(ecc_metric* m, int64_t count, double* sum)
+{
+    double token = 0.0;
+    const hipError_t e = wait_result(m, m->ctx->stream, &token);
+    if (e != hipSuccess) return e;
+    unsigned long long bits;
+    std::memcpy(&bits, &token, sizeof(bits));
+    if (bits != ECC_SMALL_DONE_TOKEN) return hipErrorUnknown;  // the kernel found its argument views inconsistent
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *sum = small_sum_on_host(m->svals_h, count);
+    return hipSuccess;
+}
+
+// What the synchronous evaluate calls wait for: the sum kernel's store, or the hand-over of a one-launch evaluation.
+hipError_t wait_sum(ecc_metric* m, double* sum)
+{
+    if (m->small_pending_count > 0) {
+        const int64_t count = m->small_pending_count;
+        m->small_pending_count = 0;
+        return wait_small_eval(m, count, sum);
+    }
+    return wait_result(m, m->ctx->stream, sum);
+}
+int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, bool* taken)
 {
     *taken = false;
     int wpp = 0;
     size_t lds = 0;
     if (!m->small_eval || !ecc_small_eval_plan(&p, &wpp, &lds)) return ECC_OK;
-    const double T0 = now_seconds();
+
     ecc_ctx* ctx = m->ctx;
     const int n = m->n_views;
     if (!m->small_ticket_d) {
@@ -1272,34 +1355,20 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, dou
     }
     p.PinvTs = m->PinvTs_d;
     p.Cs = m->Cs_d;
+    {
+        const int rcb = ensure_small_host_buffers(m, idx4_host ? p.count : 0, p.count);
+        if (rcb) return rcb;
+    }
     p.indices = nullptr;
     if (idx4_host) {
-        if (m->sidx_capacity < p.count) {
-            if (m->sidx_h) HIP_TRY(hipHostFree(m->sidx_h));
-            m->sidx_h = nullptr;
-            m->sidx_capacity = 0;
-            const int64_t cap = std::max<int64_t>(2 * p.count, 1024);
-            HIP_TRY(hipHostMalloc((void**)&m->sidx_h, sizeof(int32_t) * 4 * cap, hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer((void**)&m->sidx_h_dev, m->sidx_h, 0));
-            m->sidx_capacity = cap;
-        }
         std::memcpy(m->sidx_h, idx4_host, sizeof(int32_t) * 4 * (size_t)p.count);
         p.indices = m->sidx_h_dev;
     }
-    x.sum_out = sum_d;
     x.ticket = m->small_ticket_d;
-    if (values_to_host) {
-        if (m->svals_capacity < p.count) {
-            if (m->svals_h) HIP_TRY(hipHostFree(m->svals_h));
-            m->svals_h = nullptr;
-            m->svals_capacity = 0;
-            const int64_t cap = std::max<int64_t>(2 * p.count, 1024);
-            HIP_TRY(hipHostMalloc((void**)&m->svals_h, sizeof(float) * cap, hipHostMallocMapped));
-            HIP_TRY(hipHostGetDevicePointer((void**)&m->svals_h_dev, m->svals_h, 0));
-            m->svals_capacity = cap;
-        }
-        x.values_host = m->svals_h_dev;
-    }
+    x.values_host = m->svals_h_dev;
+    // the "done" word: the metric's pinned result slot, armed by the caller; the token is never a value a sum kernel stores
+    x.done_out = reinterpret_cast<unsigned long long*>(m->sum_h_dev);
+    x.done_token = ECC_SMALL_DONE_TOKEN;
     static unsigned long long* dbg_d = [] {  // experiments only: ECC_SMALL_DEBUG=1, read back by ecc_debug_small_stamps
         unsigned long long* d = nullptr;
         if (std::getenv("ECC_SMALL_DEBUG")) (void)hipMalloc((void**)&d, sizeof(unsigned long long) * 4 * 4096);
@@ -1307,26 +1376,17 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, dou
     }();
     x.dbg = dbg_d;
     g_small_dbg = dbg_d;
-    {
-        const char* e = std::getenv("ECC_SMALL_DBG_MODE");  // experiments only (read per call: the script changes it)
-        x.dbg_mode = e ? std::atoi(e) : 0;
-    }
+
     std::atomic_thread_fence(std::memory_order_seq_cst);  // the host's writes to pinned memory before the doorbell
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    const double T1 = now_seconds();
     HIP_TRY(ecc_launch_small_eval(&p, &x, ctx->stream));
-    const double T2 = now_seconds();
-    if (dbg_d) {
-        static int cnt = 0;
-        if ((++cnt % 100) == 0) std::fprintf(stderr, "[small] prep %.2f us launch %.2f us\n", 1e6 * (T1 - T0), 1e6 * (T2 - T1));
-    }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;
     }
-    (void)synchronous;
     m->eager_e1 = false;  // the views that changed are patched by the next launch: ecc_metric_set_projections does not launch E1
     m->last_evaluated_pairs = p.count;
+    m->small_pending_count = p.count;
     *taken = true;
     return ECC_OK;
 }
@@ -1362,9 +1422,11 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     p.K01_out = K01_d;
     p.records = m->records_d;
     m->last_evaluated_pairs = count;
-    if (sum_d && pair_values_d) {  // few pairs: ONE launch (small_eval_kernel.hip), the kept records are not touched
+    if (sum_d && sum_d == m->sum_h_dev && pair_values_d) {
+        // few pairs, a caller that waits for the result: ONE launch (small_eval_kernel.hip); the kept records are not touched.
+        // The result slot then receives the "done" word and the caller's wait_sum adds the values on the host.
         bool taken = false;
-        rc = try_small_eval(m, p, nullptr, sum_d, false, synchronous, &taken);
+        rc = try_small_eval(m, p, nullptr, &taken);
         if (rc) return rc;
         if (taken) return ECC_OK;
     }
@@ -1701,7 +1763,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
         HIP_TRY(hipMemcpyAsync(pair_values, vals_d, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(wait_stream_spin(ctx->stream));  // the copy has to land too
     }
-    HIP_TRY(wait_result(m, ctx->stream, partial_sum));
+    HIP_TRY(wait_sum(m, partial_sum));
     // an empty shard launches no kernel behind e1_kernel: its result slot says nothing about the stream
     if (count == 0) HIP_TRY(wait_stream_spin(ctx->stream));
     m->done_generation = m->set_generation;
@@ -1748,7 +1810,7 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
         HIP_TRY(wait_stream_spin(ctx->stream));
     }
     double sum = 0.0;
-    HIP_TRY(wait_result(m, ctx->stream, &sum));
+    HIP_TRY(wait_sum(m, &sum));
     m->done_generation = m->set_generation;
     *mean = sum / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
     return ECC_OK;
@@ -1782,16 +1844,11 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
         q.pair_values = m->pair_values_d;
         bool taken = false;
         arm_result(m);
-        rc = try_small_eval(m, q, idx4, m->sum_h_dev, out != nullptr, /*synchronous=*/true, &taken);
+        rc = try_small_eval(m, q, idx4, &taken);
         if (rc) return rc;
         if (taken) {
             double sum = 0.0;
-            const double W0 = now_seconds();
-            HIP_TRY(wait_result(m, ctx->stream, &sum));
-            if (g_small_dbg) {
-                static int cnt = 0;
-                if ((++cnt % 100) == 0) std::fprintf(stderr, "[small] wait %.2f us\n", 1e6 * (now_seconds() - W0));
-            }
+            HIP_TRY(wait_sum(m, &sum));
             m->done_generation = m->set_generation;
             if (out) std::memcpy(out, m->svals_h, sizeof(float) * (size_t)n_pairs);
             *mean = sum / (double)n_pairs;
@@ -1800,11 +1857,23 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     }
     rc = ensure_e1(m);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(m->indices_d, idx4, sizeof(int32_t) * 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
     m->rec_valid = false;  // the list's records overwrite the kept ones
     rc = ensure_capacity(&m->records_d, &m->records_capacity, n_pairs, ctx->stream);
     if (rc) return rc;
-    p.indices = m->indices_d;
+    // Up to 32 768 pairs the list is read by k01_kernel straight from pinned host memory (16 bytes per pair over PCIe) and the
+    // values come back through the sum kernel, which stores what it loads into pinned memory in front of the result:
+    // no copy commands (they cost an index-list evaluation 25 us: 512 pairs 57 -> ~30 us).
+    const bool pinned = n_pairs < 32768;
+    if (pinned) {
+        rc = ensure_small_host_buffers(m, n_pairs, n_pairs);
+        if (rc) return rc;
+        std::memcpy(m->sidx_h, idx4, sizeof(int32_t) * 4 * (size_t)n_pairs);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        p.indices = m->sidx_h_dev;
+    } else {
+        HIP_TRY(hipMemcpyAsync(m->indices_d, idx4, sizeof(int32_t) * 4 * n_pairs, hipMemcpyHostToDevice, ctx->stream));
+        p.indices = m->indices_d;
+    }
     p.first = 0;
     p.count = n_pairs;
     p.pair_values = m->pair_values_d;
@@ -1817,13 +1886,21 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
         ctx->ev_valid[0] = true;
     }
     arm_result(m);
-    HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, m->sum_scratch_d, ctx->stream));
-    if (out) {
-        HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(wait_stream_spin(ctx->stream));
+    if (pinned) {
+        HIP_TRY(ecc_launch_sum_pairs_to_host(m->pair_values_d, n_pairs, m->sum_h_dev, out ? m->svals_h_dev : nullptr, ctx->stream));
+    } else {
+        HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, m->sum_scratch_d, ctx->stream));
+        if (out) {
+            HIP_TRY(hipMemcpyAsync(out, m->pair_values_d, sizeof(float) * n_pairs, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(wait_stream_spin(ctx->stream));
+        }
     }
     double sum = 0.0;
     HIP_TRY(wait_result(m, ctx->stream, &sum));
+    if (pinned && out) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        std::memcpy(out, m->svals_h, sizeof(float) * (size_t)n_pairs);
+    }
     m->done_generation = m->set_generation;
     *mean = sum / (double)n_pairs;
     return ECC_OK;

@@ -141,16 +141,25 @@ struct EccPairParams {
 };
 
 // ---- one-launch evaluation of small pair sets (small_eval_kernel.hip) ---------------------------
-#define ECC_SMALL_EVAL_MAX_PAIRS 4096
+// Where the one launch beats the stream-ordered launches (measured on one MI355X, us per setProjectionMatrices + evaluate):
+// all pairs of n views at 512^2 (724 samples per pair) 1 pair 22.9 against 27.6, 28 pairs 25.6 / 28.7, 190 pairs 29.5 / 27.8,
+// 528 pairs 38 / 28.5, 2016 pairs 66 / 31 (every value is a PCIe write of its own, every workgroup costs the dispatcher
+// 11 ns); index lists on 400 views at 1024^2 (1448 samples per pair: four waves per pair pay more) 1 pair 26 / 29, 399
+// pairs 34 / 36, 512 pairs 35 / 46.  Hence a bound that grows with the samples per pair (k_limit / 2: the launch bound on the
+// kappa index is twice the number of samples, ref: ...RadonIntermediate.cu:320,349): 192 pairs at 724 samples, 576 at 1448,
+// at least 64, at most ECC_SMALL_EVAL_MAX_PAIRS.
+#define ECC_SMALL_EVAL_MAX_PAIRS 1024
+#define ECC_SMALL_EVAL_PAIR_BOUND(k_limit) \
+    ((((k_limit) / 2 - 384) / 2) < 64 ? 64 : ((((k_limit) / 2 - 384) / 2) > ECC_SMALL_EVAL_MAX_PAIRS ? ECC_SMALL_EVAL_MAX_PAIRS : (((k_limit) / 2 - 384) / 2)))
 #define ECC_SMALL_PATCH_MAX 16
 #define ECC_SMALL_MAGIC 0x45434353u
 struct EccSmallEval {
-    double* sum_out;     // float64 sum of the pair values: the pinned result slot the host polls or a device scalar; null: no sum
+    unsigned long long* done_out;   // pinned, device-mapped word the host polls: done_token once every value is on its way; null: no hand-over
+    unsigned long long done_token;
     unsigned* ticket;    // device counter, zero between launches
-    float* values_host;  // optional pinned, device-mapped array: the workgroup that sums also copies all values there
+    float* values_host;  // pinned, device-mapped array: every pair value, system scope (the host adds them)
     int stage_stride;    // floats per pair of the LDS stage (set by the launcher)
-    unsigned long long* dbg;  // optional (ECC_SMALL_DEBUG): 4 wall-clock stamps per workgroup (start, records done, value stored, sum stored)
-    int dbg_mode;        // experiments (ECC_SMALL_DBG_MODE): 1 / 2 / 3 = workgroup 0 reports at entry / after the records / after its value
+    unsigned long long* dbg;  // optional (experiments, -DECC_SMALL_STAMPS): 4 wall-clock stamps per workgroup
     unsigned magic;      // ECC_SMALL_MAGIC (set by the launcher): the kernel reads the patch list in place in its argument segment
     // E1 of the views whose matrix changed since the device arrays PinvTs / Cs were made, computed on the host
     // (ecc_host_geometry.h) and handed over in the kernel arguments: (P^+)^T (12) + C (4) per entry

@@ -138,14 +138,25 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
 
 // Deterministic float64 sum of `count` pair values (single workgroup, fixed tree).
 // ref: ...RadonIntermediate.cpp:216-224 (host loop; weights are all 1).
+// values_host (optional, pinned and device-mapped): the kernel also hands the values themselves to the host -- every thread
+// stores what it loads, 16 contiguous bytes per lane, drained before the barrier in front of the result's store; writes of
+// one device to host memory arrive in order, so a host that sees the result sees the values (index lists: no copy command).
 __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict__ vals, long long count,
-                                                         double* __restrict__ out)
+                                                         double* __restrict__ out, float* __restrict__ values_host)
 {
     __shared__ double s[1024 / 64];
     // 16-byte loads, four independent float64 accumulators per thread (fixed order => deterministic)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const long long n4 = count >> 2;
     const float4* __restrict__ v4 = reinterpret_cast<const float4*>(vals);
+    if (values_host) {  // uniform; its own pass, so that the arithmetic below is the one code path it always was
+        // system-scope stores (plain stores to host memory may sit in the L2 until the kernel ends; the host reads the
+        // values as soon as it sees the result)
+        for (long long q = threadIdx.x; q < count; q += 1024)
+            __hip_atomic_store(reinterpret_cast<unsigned*>(values_host) + q, __float_as_uint(vals[q]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // eight loads in flight per thread: the kernel is one workgroup reading what other XCDs have just written
     // (HBM latency each time), issued one at a time it took 10 us for 79 800 values
     long long k = threadIdx.x;
@@ -536,12 +547,18 @@ extern "C" hipError_t ecc_launch_publish_scalar(const double* value_d, double* h
 extern "C" size_t ecc_sum_scratch_bytes() { return sizeof(SumScratch); }
 
 // scratch: ecc_sum_scratch_bytes() of zeroed device memory owned by the caller (one per stream of launches), or null.
+extern "C" hipError_t ecc_launch_sum_pairs_to_host(const float* vals, long long count, double* out, float* values_host, hipStream_t stream)
+{
+    hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, stream, vals, count, out, values_host);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t ecc_launch_sum_pairs(const float* vals, long long count, double* out, void* scratch, hipStream_t stream)
 {
     if (scratch && count >= 32768)
         hipLaunchKernelGGL(sum_pairs_split_kernel, dim3(SUM_BLOCKS), dim3(1024), 0, stream, vals, count, out,
                            static_cast<SumScratch*>(scratch));
     else
-        hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, stream, vals, count, out);
+        hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, stream, vals, count, out, (float*)nullptr);
     return hipGetLastError();
 }

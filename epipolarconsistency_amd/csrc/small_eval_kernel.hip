@@ -16,15 +16,18 @@
 //   * phase A: the pair records of the workgroup's pairs by k01_fit_block<8> -- the code of k01_kernel<8>, 8 lanes per fit
 //     -- into LDS;
 //   * phase B: the sampling loops of pairs_kernel (pair_accumulate) or of pairs_reference_kernel<.., 4> (reference_loop).
-//     With few pairs most SIMDs would idle, so WPP = 4 / 2 / 1 waves share a pair (up to 1024 / 2048 / 4096 pairs): wave
+//     With few pairs most SIMDs would idle, so the four waves of a workgroup share ONE pair (WPP = 4): wave
 //     `sub` takes the 64-sample trips sub, sub + WPP, ... and stores every sample's term in LDS; the pair's first wave
 //     then adds the terms per lane in the order ONE wave accumulates them (k = lane, lane + 64, ...), so the pair value has
 //     the bits of pairs_kernel's.  The reference arithmetic keeps its own grouping (thread T: k = T, T + 256, ...; wave
 //     sums in wave order), which is what pairs_reference_kernel<.., 4> does for the same evaluation sizes;
-//   * phase C: each value is stored at agent scope and drained, the workgroup takes a ticket, and the workgroup that
-//     arrives last adds all values in sum_pairs_kernel's order (the float4 layout of its 1024 threads, its shuffle tree,
-//     its 16 wave sums in order) and stores the float64 sum -- to the pinned result slot the host polls, or to the
-//     caller's device scalar.
+//   * phase C: each value goes to the device array (plain store) and, at system scope, into pinned host memory; the
+//     workgroup drains its stores and takes a ticket, and the workgroup that arrives last writes a "done" word the host
+//     polls.  The HOST then adds the values in sum_pairs_kernel's order (the float4 layout of its 1024 threads, its shuffle
+//     tree, its 16 wave sums in order: ecc_capi.hip, small_sum_on_host) -- at most 4096 values, under 2 us.  (First form,
+//     measured: the last arriver added the values itself with agent-scope loads -- 55 us for 399 values; loads that must
+//     bypass the XCD's L2 cost microseconds each.  Asynchronous callers, who want the sum in device memory, keep the
+//     stream-ordered launches.)
 // Every result is bit-identical to the multi-launch path (tests/test_gpu_small_eval.py); ecc_metric_set_small_eval(0)
 // keeps the old path.
 #include <hip/hip_runtime.h>
@@ -39,14 +42,6 @@
 
 namespace {
 
-__device__ __forceinline__ void store_agent(float* dst, float v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned*>(dst), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float load_agent(const float* src)
-{
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
 __device__ __forceinline__ void store_system(float* dst, float v)
 {
     __hip_atomic_store(reinterpret_cast<unsigned*>(dst), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -65,8 +60,6 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
     __shared__ K01Shared<8> ks;
     __shared__ int32_t idx_lds[4 * PPW];
     __shared__ double part[4];
-    __shared__ double wsum[16];
-    __shared__ unsigned s_ticket;
 
 #ifdef ECC_SMALL_STAMPS  // experiments (scripts/exp_small_phases.py); the stamps cost registers: not in the product build
 #define ECC_SMALL_STAMP(i) do { if (x.dbg && threadIdx.x == 0) x.dbg[4 * blockIdx.x + (i)] = wall_clock64(); } while (0)
@@ -74,9 +67,7 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
 #define ECC_SMALL_STAMP(i)
 #endif
     ECC_SMALL_STAMP(0);
-#define ECC_SMALL_EARLY(i) do { if (x.dbg_mode == (i) && blockIdx.x == 0 && threadIdx.x == 0 && x.sum_out) \
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.sum_out), 0x3ff0000000000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
-    ECC_SMALL_EARLY(1);
+
     // ---- phase A: records of this workgroup's pairs (k01_kernel<8>'s code; dead slots take part in its exchanges) ----
     const long long blk_first = (long long)blockIdx.x * PPW;
     if (p.indices) {  // uniform over the launch: the tuples of this workgroup's pairs, one read of the pinned list
@@ -92,7 +83,6 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
     k01_fit_block<8>(p, blk_first, PPW, ks, xs, p.indices ? idx_lds : nullptr);  // ends with a barrier
 
     ECC_SMALL_STAMP(1);
-    ECC_SMALL_EARLY(2);
     // ---- phase B ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = wave / WPP, sub = wave % WPP;  // wave-uniform
@@ -144,68 +134,28 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
         val = (float)acc;
     }
 
-    // ---- phase C: the pair values, then the float64 sum by the workgroup that arrives last ----
+    // ---- phase C: the pair values; the workgroup that arrives last announces them ----
     if (live && sub == 0 && lane == 0) {
-        if (p.pair_values) {
-            store_agent(p.pair_values + local, val);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drained before this workgroup's ticket
-        }
+        if (p.pair_values) p.pair_values[local] = val;  // the device copy (later list launches, copies to the caller): visible at kernel end
         if (p.cost && !p.indices) {
             const int ci = rec->ci, cj = rec->cj;
             p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
         }
-    }
-    if (!x.sum_out) return;  // uniform over the launch
-    __syncthreads();
-    ECC_SMALL_STAMP(2);
-    ECC_SMALL_EARLY(3);
-    if (x.dbg_mode) return;
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(x.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;  // uniform over the workgroup
-    // Every other workgroup's values were drained before its ticket add: all are visible to agent-scope loads.
-    // sum_pairs_kernel's order for count <= 4096 (at most one float4 per thread of its 1024): thread t holds
-    // ((0 + v[4t]) + (0 + v[4t+1])) + ((0 + v[4t+2]) + (0 + v[4t+3])), thread 0 then adds the up to three values past the
-    // last float4, the 64 threads of a wave are combined by the shuffle tree, the 16 wave sums are added in order.
-    const long long count = p.count, n4 = count >> 2;
-    const float* vals = p.pair_values;
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        const int vw = wave + 4 * r;  // virtual wave of the 1024-thread sum
-        const long long t = 64ll * vw + lane;
-        double a = 0.0;
-        if (t < n4) {
-            const float v0 = load_agent(vals + 4 * t), v1 = load_agent(vals + 4 * t + 1), v2 = load_agent(vals + 4 * t + 2),
-                        v3 = load_agent(vals + 4 * t + 3);
-            if (x.values_host) {  // the values a caller wants on the host: pinned memory, system scope
-                store_system(x.values_host + 4 * t, v0);
-                store_system(x.values_host + 4 * t + 1, v1);
-                store_system(x.values_host + 4 * t + 2, v2);
-                store_system(x.values_host + 4 * t + 3, v3);
-            }
-            const double a0 = 0.0 + (double)v0, a1 = 0.0 + (double)v1, a2 = 0.0 + (double)v2, a3 = 0.0 + (double)v3;
-            a = (a0 + a1) + (a2 + a3);
+        if (x.values_host) {
+            store_system(x.values_host + local, val);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // on its way to the host before this workgroup's ticket
         }
-        if (t == 0)
-            for (long long k = n4 << 2; k < count; ++k) {
-                const float v = load_agent(vals + k);
-                if (x.values_host) store_system(x.values_host + k, v);
-                a += (double)v;
-            }
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-        if (lane == 0) wsum[vw] = a;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the values on their way to the host before the sum that announces them
+    if (!x.done_out) return;  // uniform over the launch
     __syncthreads();
     if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int w = 0; w < 16; ++w) tot += wsum[w];
-        if (!args_ok) tot = __longlong_as_double(0x7ff8000000000bad);
-        ECC_SMALL_STAMP(3);
-        __hip_atomic_store(x.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero between launches
-        // pinned host memory that the host polls, or the caller's device scalar: one 8-byte store at system scope
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x.sum_out), (unsigned long long)__double_as_longlong(tot),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned ticket = __hip_atomic_fetch_add(x.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1) {
+            // every other workgroup's values were drained before its ticket add, and writes of one device to host memory
+            // arrive in order: the host that sees this word sees all values
+            __hip_atomic_store(x.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero between launches
+            __hip_atomic_store(x.done_out, args_ok ? x.done_token : ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -215,7 +165,7 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
 // evaluation cannot take this path (the caller falls back to the stream-ordered launches).
 extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds_bytes)
 {
-    if (p->count < 1 || p->count > ECC_SMALL_EVAL_MAX_PAIRS || p->use_corr || p->K01_out || p->record_slots || p->value_slots ||
+    if (p->count < 1 || p->count > ECC_SMALL_EVAL_PAIR_BOUND(p->k_limit) || p->use_corr || p->K01_out || p->record_slots || p->value_slots ||
         p->patch_count || p->skip_enabled)
         return 0;
     if (p->reference_arithmetic) {
@@ -224,8 +174,8 @@ extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds
         *lds_bytes = 0;
         return 1;
     }
-    const int w = p->count <= 1024 ? 4 : (p->count <= 2048 ? 2 : 1);
-    const size_t bytes = w == 1 ? 0 : sizeof(float) * (size_t)(4 / w) * (size_t)((p->k_limit + 63) & ~63);
+    const int w = 4;  // waves per pair (the kernel has forms with 2 and 1 for larger launches: measured slower than the stream-ordered path there)
+    const size_t bytes = sizeof(float) * (size_t)((p->k_limit + 63) & ~63);
     if (bytes > 40 * 1024) return 0;  // user-chosen dkappa with tens of thousands of samples per pair
     *wpp = w;
     *lds_bytes = bytes;
@@ -244,15 +194,8 @@ extern "C" hipError_t ecc_launch_small_eval(const EccPairParams* p, const EccSma
     const dim3 grid(blocks), block(256);
 #define ECC_SMALL(D, W, R) hipLaunchKernelGGL((small_eval_kernel<D, W, R>), grid, block, lds, stream, *p, xx)
     if (p->reference_arithmetic) ECC_SMALL(true, 4, true);  // (the reference arithmetic takes is_derivative at run time)
-    else if (p->is_derivative) {
-        if (wpp == 4) ECC_SMALL(true, 4, false);
-        else if (wpp == 2) ECC_SMALL(true, 2, false);
-        else ECC_SMALL(true, 1, false);
-    } else {
-        if (wpp == 4) ECC_SMALL(false, 4, false);
-        else if (wpp == 2) ECC_SMALL(false, 2, false);
-        else ECC_SMALL(false, 1, false);
-    }
+    else if (p->is_derivative) ECC_SMALL(true, 4, false);
+    else ECC_SMALL(false, 4, false);
 #undef ECC_SMALL
     return hipGetLastError();
 }

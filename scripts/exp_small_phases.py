@@ -1,4 +1,6 @@
-"""Phase time-line of small_eval_kernel (experiments; needs ECC_SMALL_DEBUG=1): wall-clock stamps (100 MHz) per workgroup --
+"""Phase time-line of small_eval_kernel (experiments; needs a library built with -DECC_SMALL_STAMPS -- python -c "from
+epipolarconsistency_amd import build; build.build_library(force=True, extra_flags=['-DECC_SMALL_STAMPS'])" -- and ECC_SMALL_DEBUG=1;
+the stamps cost registers (occupancy 3 instead of 5), so launches of more than 768 workgroups run in two rounds here): wall-clock stamps (100 MHz) per workgroup --
 start, records done (phase A), value stored (phase B), and for the last arriver the sum stored."""
 import ctypes as C, os, sys
 os.environ["ECC_SMALL_DEBUG"] = "1"
@@ -47,4 +49,4 @@ for rep in range(6):
           "last value stored at %.2f us; sum stored at %.2f us (workgroup %d)"
           % (rep, blocks, wpp, (t[:, 0].max() - t0) / 100.0, np.median(t[:, 1] - t[:, 0]) / 100.0, (t[:, 1] - t[:, 0]).max() / 100.0,
              np.median(t[:, 2] - t[:, 1]) / 100.0, (t[:, 2] - t[:, 1]).max() / 100.0, (t[:, 2].max() - t0) / 100.0,
-             (t[last, 3] - t0) / 100.0, last))
+             0.0, last))
