@@ -48,6 +48,9 @@ SIGNATURES = {
     "ecc_radon_compute_into": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ecc_radon_set_arithmetic": (_i, [_vp, _i]),
     "ecc_radon_get_arithmetic": (_i, [_vp, _pi]),
+    "ecc_radon_compute_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ecc_dtr_from_device_linear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "ecc_metric_evaluate_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, C.c_float, C.c_float, _i]),
     "ecc_dtr_from_host": (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "ecc_dtr_readback": (_i, [_vp, _vp]),
     "ecc_dtr_info": (_i, [_vp, _pi, _pi, _pi, _pi, _pi, _pd, _pd]),
@@ -109,6 +112,7 @@ SIGNATURES = {
     "ecc_group_metric_rebalance": (_i, [_vp]),
     "ecc_group_metric_evaluate_poses": (_i, [_vp, _i, _vp, _i, _vp]),
     "ecc_group_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),
+    "ecc_group_debug_force_replica": (_i, [_i]),
     "ecc_group_metric_destroy": (_i, [_vp]),
     "ecc_group_metric_set_projections": (_i, [_vp, _vp, _i]),
     "ecc_group_metric_set_params": (_i, [_vp, _d, _d, _i]),

@@ -130,7 +130,7 @@ inline bool saveProjectionsOneMatrixPerLine(const std::vector<Geometry::Projecti
 {
     std::ofstream file(path.c_str());
     if (!file) return false;
-    file.precision(12);
+    file.precision(17);  // max_digits10: a saved table loads back bit for bit (the reference writes 12 digits; readers take either)
     if (!first_line_comment.empty()) file << "#" << first_line_comment << std::endl;
     if (spacing != 0.0) {
         file << "#> spacing=\"" << spacing << "\"";

@@ -124,6 +124,9 @@ struct ecc_ctx {
     // transposed copy of (a sub-batch of) the projection images for the Radon kernel's transposed tiles
     float* radon_T_d = nullptr;
     size_t radon_T_cap = 0;  // floats
+    // one slab of scratch for ecc_radon_compute_linear
+    float* linear_scratch_d = nullptr;
+    size_t linear_scratch_cap = 0;  // floats
 };
 
 struct ecc_dtr {
@@ -627,6 +630,7 @@ ECC_EXPORT int ecc_ctx_destroy(ecc_ctx* ctx)
     for (float* b : ctx->pre_scratch_d)
         if (b) (void)hipFree(b);
     if (ctx->radon_T_d) (void)hipFree(ctx->radon_T_d);
+    if (ctx->linear_scratch_d) (void)hipFree(ctx->linear_scratch_d);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -760,6 +764,68 @@ ECC_EXPORT int ecc_dtr_from_host(ecc_ctx* ctx, const float* data, int n_alpha, i
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(staging);
     HIP_TRY(e);
+    ecc_dtr* d = new (std::nothrow) ecc_dtr();
+    if (!d) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
+    d->ctx = ctx;
+    d->owner = owner;
+    d->base = owner->ptr;
+    d->n_alpha = n_alpha;
+    d->n_t = n_t;
+    d->n_u = n_u;
+    d->n_v = n_v;
+    d->filter = filter;
+    d->pitch = ecc_layout_pitch(n_t);
+    *out = d;
+    return ECC_OK;
+}
+
+// The reference's launcher seam (ref: RadonIntermediate.cpp:12, RadonIntermediate.cu:149-170): image and result in device
+// memory owned by the caller, the result in the REFERENCE's layout -- n_t rows of n_alpha floats, angle fastest, exactly
+// n_t * n_alpha floats (what RadonIntermediate::compute allocates, ref: RadonIntermediate.cpp:208, and readback copies
+// verbatim, :148-163).  Computed in a scratch slab of the context and transposed out; stream-ordered.
+ECC_EXPORT int ecc_radon_compute_linear(ecc_ctx* ctx, const float* image_d, int n_u, int n_v, int n_alpha, int n_t, int filter,
+                                        int post_process, float* out_linear_d)
+{
+    ecc_dtr* dummy = nullptr;
+    int rc = check_radon_args(ctx, image_d, 1, n_u, n_v, n_alpha, n_t, filter, post_process, &dummy);
+    if (rc) return rc;
+    if (!out_linear_d) return fail(ECC_ERR_INVALID_ARGUMENT, "out_linear_d is null");
+    rc = set_device(ctx);
+    if (rc) return rc;
+    const int64_t slab = ecc_layout_floats(n_alpha, n_t);
+    if (ctx->linear_scratch_cap < (size_t)slab) {
+        if (ctx->linear_scratch_d) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->linear_scratch_d));
+            ctx->linear_scratch_d = nullptr;
+            ctx->linear_scratch_cap = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&ctx->linear_scratch_d, sizeof(float) * (size_t)slab));
+        ctx->linear_scratch_cap = (size_t)slab;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->linear_scratch_d, 0, (size_t)slab * sizeof(float), ctx->stream));
+    rc = radon_launch(ctx, image_d, 1, n_u, n_v, n_alpha, n_t, filter, post_process, ctx->linear_scratch_d, slab);
+    if (rc) return rc;
+    HIP_TRY(ecc_launch_dtr_export(ctx->linear_scratch_d, out_linear_d, n_alpha, n_t, ecc_layout_pitch(n_t), ctx->stream));
+    return ECC_OK;
+}
+
+// A Radon intermediate from DEVICE memory in the reference's layout (n_t x n_alpha, angle fastest): what the reference
+// turns into a texture (ref: RadonIntermediate.cpp:188-196 getTexture: a copy into a cudaArray -- a snapshot, like here).
+ECC_EXPORT int ecc_dtr_from_device_linear(ecc_ctx* ctx, const float* data_d, int n_alpha, int n_t, int n_u, int n_v, int filter,
+                                          ecc_dtr** out)
+{
+    if (!ctx || !data_d || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_alpha < 1 || n_t < 1 || n_alpha > 16384 || n_t > 16384)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "Radon bin counts must be in [1, 16384]");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const int64_t slab = ecc_layout_floats(n_alpha, n_t);
+    auto owner = std::make_shared<Slab>();
+    owner->device = ctx->device;
+    HIP_TRY(hipMalloc((void**)&owner->ptr, (size_t)slab * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(owner->ptr, 0, (size_t)slab * sizeof(float), ctx->stream));
+    HIP_TRY(ecc_launch_dtr_import(data_d, owner->ptr, n_alpha, n_t, ecc_layout_pitch(n_t), ctx->stream));
     ecc_dtr* d = new (std::nothrow) ecc_dtr();
     if (!d) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
     d->ctx = ctx;
@@ -1470,11 +1536,16 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             // 512-bit kernel argument.)
             bool split = C > 0 && !cost_d && !p.reference_arithmetic && n <= 32 * ECC_SKIP_WORDS &&
                          (m->record_reuse >= 2 || count >= ECC_RECORD_REUSE_SPLIT_PAIRS);
-            if (split && !m->side_stream) {
+            if (split && (!m->side_stream || !m->fork_ev || !m->join_ev)) {  // all three or none (advisor, round 3)
                 if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
                     hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming) != hipSuccess) {
                     (void)hipGetLastError();
+                    if (m->side_stream) (void)hipStreamDestroy(m->side_stream);
+                    if (m->fork_ev) (void)hipEventDestroy(m->fork_ev);
+                    if (m->join_ev) (void)hipEventDestroy(m->join_ev);
+                    m->side_stream = nullptr;
+                    m->fork_ev = m->join_ev = nullptr;
                     split = false;
                 }
             }
@@ -1546,15 +1617,26 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 q.cost = nullptr;
                 q.pair_values = nullptr;
                 hipStream_t ks = split ? m->side_stream : ctx->stream;
-                if (split) HIP_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
-                HIP_TRY(ecc_launch_k01(&q, ks));
+                // from here on an early return must not leave side-stream work un-joined (the list buffers are reused
+                // by later calls, which wait on the context's stream only): SIDE_TRY drains the side stream first
+#define SIDE_TRY(expr)                                                        \
+    do {                                                                      \
+        const hipError_t _s = (expr);                                         \
+        if (_s != hipSuccess) {                                               \
+            if (split) (void)hipStreamSynchronize(m->side_stream);            \
+            HIP_TRY(_s);                                                      \
+        }                                                                     \
+    } while (0)
+                if (split) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
+                SIDE_TRY(ecc_launch_k01(&q, ks));
                 if (split) {  // the changed pairs' own launch: records and values in their slots
                     q.pair_values = pair_values_d;
                     q.value_slots = q.record_slots;
-                    HIP_TRY(ecc_launch_pairs(&q, m->side_stream));
-                    HIP_TRY(hipEventRecord(m->join_ev, m->side_stream));
-                    HIP_TRY(hipStreamWaitEvent(ctx->stream, m->join_ev, 0));
+                    SIDE_TRY(ecc_launch_pairs(&q, m->side_stream));
+                    SIDE_TRY(hipEventRecord(m->join_ev, m->side_stream));
+                    SIDE_TRY(hipStreamWaitEvent(ctx->stream, m->join_ev, 0));
                 }
+#undef SIDE_TRY
                 if (!synchronous) {
                     if (!m->reuse_ev[b]) HIP_TRY(hipEventCreateWithFlags(&m->reuse_ev[b], hipEventDisableTiming));
                     HIP_TRY(hipEventRecord(m->reuse_ev[b], ks));
@@ -1903,6 +1985,60 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     }
     m->done_generation = m->set_generation;
     *mean = sum / (double)n_pairs;
+    return ECC_OK;
+}
+
+// The reference's launcher seam for the metric (ref: EpipolarConsistencyRadonIntermediate.cpp:16-37 epipolarConsistency(...),
+// .cu:300-409): everything in device memory owned by the caller, the per-view geometry already made by the caller's host
+// class (culaut, ref: ...RadonIntermediate.cpp:134-163).  indices_d == null: all n (n - 1) / 2 pairs, out_d is the n x n
+// cost image (entry i + j n, i < j, overwritten; the rest untouched); else out_d receives num_pairs values.  K01s_d
+// (nullable): the 16 floats per pair the reference keeps between its two kernels.  Returns after the stream has run (the
+// reference synchronises the device after each of its kernels).  No E1, no kept records, no host result: the caller's
+// epilogue reads out_d back and forms the mean (ref: ...RadonIntermediate.cpp:197-224).
+ECC_EXPORT int ecc_metric_evaluate_external(ecc_metric* m, int num_Ps, const float* Cs_d, const float* PinvTs_d, int num_pairs,
+                                            const int32_t* indices_d, float* K01s_d, float* out_d, float object_radius_mm,
+                                            float dkappa, int use_corr)
+{
+    if (!m || !Cs_d || !PinvTs_d || !out_d) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (num_Ps < 2 || num_pairs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least two views and one pair");
+    if ((int)m->dtrs.size() < num_Ps && !indices_d)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "fewer Radon intermediates than projection matrices");
+    if (!indices_d && (int64_t)num_pairs != (int64_t)num_Ps * (num_Ps - 1) / 2)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "all-pairs form: num_pairs must be n (n - 1) / 2");
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    // parameters of this call only (the metric's own are restored below)
+    const double keep_radius = m->object_radius_mm, keep_dkappa = m->dkappa;
+    const int keep_corr = m->use_corr, keep_n = m->n_views;
+    m->object_radius_mm = object_radius_mm > 0 ? object_radius_mm : 1e-30;  // the seam has no "automatic": the caller passes its radius
+    m->dkappa = dkappa;
+    m->use_corr = use_corr;
+    m->n_views = num_Ps;
+    EccPairParams p;
+    rc = fill_pair_params(m, &p, num_pairs, /*need_e1=*/false);
+    m->object_radius_mm = keep_radius;
+    m->dkappa = keep_dkappa;
+    m->use_corr = keep_corr;
+    m->n_views = keep_n;
+    if (rc) return rc;
+    p.object_radius_mm = object_radius_mm;
+    p.Cs = Cs_d;
+    p.PinvTs = PinvTs_d;
+    p.n_views = num_Ps;
+    m->rec_valid = false;  // the records below overwrite the kept ones
+    rc = ensure_capacity(&m->records_d, &m->records_capacity, num_pairs, ctx->stream);
+    if (rc) return rc;
+    p.indices = indices_d;
+    p.first = 0;
+    p.count = num_pairs;
+    p.records = m->records_d;
+    p.K01_out = K01s_d;
+    if (indices_d) p.pair_values = out_d;
+    else p.cost = out_d;
+    HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+    HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
+    HIP_TRY(wait_stream_spin(ctx->stream));
     return ECC_OK;
 }
 

@@ -45,6 +45,18 @@ struct ecc_group {
 };
 
 namespace {
+std::atomic<int> g_force_replica{0};
+}
+
+/* Debug / test hook (not an environment variable: nothing a deployment can set by accident): the ranks of groups created
+ * from now on copy the Radon-intermediate stack even when it already lives on their device. */
+extern "C" __attribute__((visibility("default"))) int ecc_group_debug_force_replica(int on)
+{
+    g_force_replica.store(on ? 1 : 0);
+    return 0;
+}
+
+namespace {
 
 // Runs job(rank) for every rank (rank 0 on the calling thread) and returns the first failure, its message recorded
 // for ecc_last_error() on the calling thread.
@@ -265,9 +277,9 @@ ECC_EXPORT int ecc_group_metric_create(ecc_group* g, int n_dtrs, ecc_dtr* const*
         if (hipSetDevice(dev) != hipSuccess) return ecc_set_error(ECC_ERR_HIP, "hipSetDevice failed");
         bool all_local = true;
         for (int k = 0; k < n_dtrs; ++k) all_local = all_local && src_dev[k] == dev;
-        // ECC_GROUP_FORCE_REPLICA=1 (tests): replicate even what is already here, so that the replica path -- allocation,
-        // copies, probes, metrics on the copy -- runs on a one-GPU box too
-        if (const char* e = std::getenv("ECC_GROUP_FORCE_REPLICA")) all_local = all_local && e[0] != '1';
+        // ecc_group_debug_force_replica (tests): replicate even what is already here, so that the replica path --
+        // allocation, copies, probes, metrics on the copy -- runs on a one-GPU box too
+        if (g_force_replica.load()) all_local = false;
         if (!all_local) {
             if (hipMalloc((void**)&raw->replicas[r], sizeof(float) * (size_t)slab * n_dtrs) != hipSuccess) {
                 (void)hipGetLastError();

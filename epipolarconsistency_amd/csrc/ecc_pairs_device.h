@@ -355,7 +355,8 @@ __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_
 // (Non-temporal loads for the view whose band no later pair of the XCD re-uses were measured: they bypass the L1 as
 // well and lose the reuse between neighbouring lanes, 0.397 vs 0.338 ms.)
 template <bool DERIV, int PITCH4>
-__device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f)
+__device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f,
+                                           float xa_max)
 {
     float fx, fy;
     unsigned off;
@@ -366,6 +367,10 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
         // coordinate is >= 0.5 in padded texel units; the distance coordinate is clamped at 0.5 instead of 0 (cell 0 is
         // the replicated border: both its bins hold the same bits, the value does not depend on the fraction there).
         yd = __builtin_amdgcn_fmed3f(yd, 0.5f, n_t_f);
+        // the angle coordinate is within [0.5, n_alpha + 0.5] wherever the fitted polynomial is the mapping it was checked
+        // against; between the check points nothing guarantees it, and the index below is 24 mantissa bits times the row
+        // pitch: one v_med3 keeps a misbehaving fit inside the slab (advisor, round 3; values in range are not changed)
+        xa = __builtin_amdgcn_fmed3f(xa, 0.5f, xa_max);
         const float ma = xa + 8388607.5f, md = yd + 8388607.5f;
         fx = xa - (ma - 8388608.f);
         fy = yd - (md - 8388608.f);
@@ -375,6 +380,7 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
         off = __umul24(__float_as_uint(ma), (unsigned)PITCH4) + bin8;
     } else {
         yd = __builtin_amdgcn_fmed3f(yd, 0.f, n_t_f);
+        xa = __builtin_amdgcn_fmed3f(xa, 0.5f, xa_max);
         fx = __builtin_amdgcn_fractf(xa);
         fy = __builtin_amdgcn_fractf(yd);
         off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
@@ -402,8 +408,8 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
 template <bool DERIV, bool CORR, int PITCH4, int DEG, int WPP = 1>
 __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
                                                 float kappa_max, float w06, const SlabView sv0, const SlabView sv1,
-                                                float n_t_f, float pitch4_f, double& acc, double& mom2, double& mom3,
-                                                double& mom4, int sub = 0, float* stage = nullptr)
+                                                float n_alpha_f, float n_t_f, float pitch4_f, double& acc, double& mom2,
+                                                double& mom3, double& mom4, int sub = 0, float* stage = nullptr)
 {
     static_assert(WPP == 1 || !CORR, "the shared-pair form carries one term per sample");
     float ca[2][ECC_POLY_DEG + 3], cd[2][ECC_POLY_DEG + 2];
@@ -420,6 +426,7 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         ca[v][ECC_POLY_DEG + 2] = uniformf(rec->ca[v][ECC_POLY_DEG + 2]);
     }
     const float xs = uniformf(rec->x_scale);
+    const float xa_max = n_alpha_f + 0.5f;  // padded texel units: row n_alpha of the paired copy is the last one
     for (int k = lane + 64 * sub; k < k_limit; k += 64 * WPP) {
         const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
         if (kappa >= kappa_max) break;
@@ -429,10 +436,10 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         poly_pm<DEG>(cd[0], cd[0][ECC_POLY_DEG + 1], 0.f, true, x, z, yd0p, yd0m);
         poly_pm<DEG>(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa1p, xa1m);
         poly_pm<DEG>(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd1p, yd1m);
-        const float v0p = sample_at<DERIV, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f);
-        const float v1p = sample_at<DERIV, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f);
-        const float v0m = sample_at<DERIV, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f);
-        const float v1m = sample_at<DERIV, PITCH4>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f);
+        const float v0p = sample_at<DERIV, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f, xa_max);
+        const float v1p = sample_at<DERIV, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f, xa_max);
+        const float v0m = sample_at<DERIV, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f, xa_max);
+        const float v1m = sample_at<DERIV, PITCH4>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f, xa_max);
         if (!CORR) {
             const float vp = v0p - v1p, vm = v0m - v1m;
             const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
@@ -958,7 +965,7 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
     const int poly_ok = __builtin_amdgcn_readfirstlane(rec->poly_ok);
     if (poly_ok) {
 #define ECC_POLY_LOOP(P4, DEG) \
-    kappa_loop_poly<DERIV, CORR, P4, DEG, WPP>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_t_f, pitch4_f, acc, mom2, mom3, mom4, sub, stage)
+    kappa_loop_poly<DERIV, CORR, P4, DEG, WPP>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_alpha_f, n_t_f, pitch4_f, acc, mom2, mom3, mom4, sub, stage)
         if (p.wide_offsets) {
             if (poly_ok <= 6) ECC_POLY_LOOP(-1, 6);
             else ECC_POLY_LOOP(-1, ECC_POLY_DEG);

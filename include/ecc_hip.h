@@ -56,6 +56,14 @@ int ecc_version(void);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int ecc_device_count(void);
 
+/* Environment variables the library reads (all optional; none changes a result):
+ *   ECC_RECORD_REUSE = 0 | 1 | 2   default of ecc_metric_set_record_reuse for new metrics
+ *   ECC_RESULT_WAIT = stream       wait for the stream instead of polling the pinned result slot (A/B measurements)
+ *   ECC_QUAD_COPIES = 1            metrics also build row-quad copies of their Radon intermediates (4x the memory)
+ *   ECC_EXCHANGE_TIMEOUT_S         time-out of ecc_exchange_sum
+ *   ECC_HIP_DEVICES                (C++ adapter) devices of the process-wide default group
+ *   ECC_POLY_TOL, ECC_SMALL_DEBUG  experiments only */
+
 /* ---- context ------------------------------------------------------------------------------ */
 /* `stream` is a hipStream_t (may be NULL = the device's default stream).  All launches and
  * copies of objects created from this context are ordered on it.  Replaces the reference's
@@ -105,6 +113,19 @@ int ecc_radon_compute_into(ecc_ctx* ctx, const float* images_d, int n, int n_u, 
 enum { ECC_RADON_EXACT = 0, ECC_RADON_FMA = 1 };
 int ecc_radon_set_arithmetic(ecc_ctx* ctx, int mode);
 int ecc_radon_get_arithmetic(const ecc_ctx* ctx, int* mode);
+
+/* The reference's launcher seam, device memory in and out (Option B): replaces
+ *   void computeDerivLineIntegrals(cudaTextureObject_t in, int n_x, int n_y, int n_alpha, int n_t, int filter, int post, float* out_d)
+ * (ref: RadonIntermediate.cpp:12, RadonIntermediate.cu:149-170) with the image as a linear device buffer in place of the
+ * texture.  out_linear_d receives the result in the REFERENCE's layout: n_t rows of n_alpha floats, angle fastest,
+ * n_t * n_alpha floats -- the buffer RadonIntermediate::compute allocates (ref: RadonIntermediate.cpp:208) and readback
+ * copies verbatim (:148-163).  Stream-ordered. */
+int ecc_radon_compute_linear(ecc_ctx* ctx, const float* image_d, int n_u, int n_v, int n_alpha, int n_t, int filter,
+                             int post_process, float* out_linear_d);
+/* A Radon intermediate from device memory in the reference's layout: what RadonIntermediate::getTexture turns into a
+ * texture (ref: RadonIntermediate.cpp:188-196) -- a snapshot, as there. */
+int ecc_dtr_from_device_linear(ecc_ctx* ctx, const float* data_d, int n_alpha, int n_t, int n_u, int n_v, int filter,
+                               ecc_dtr** out);
 
 /* Wraps existing host data (alpha-fast, n_t x n_alpha), ref: RadonIntermediate(ImageView<float>)
  * + replaceRadonIntermediateData (RadonIntermediate.cpp:69-80,105-123). */
@@ -182,6 +203,20 @@ int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count);
  * asynchronously and the pre-compute runs on the device, one thread per view (bit-identical to
  * ecc_host_pinvT / ecc_host_source_position). */
 int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n_views);
+/* The reference's launcher seam for the metric (Option B): what
+ *   void epipolarConsistency(int n_x, int n_y, int num_dtrs, char* dtrs_d, int n_alpha, int n_t, float step_alpha, float step_t,
+ *                            int num_Ps, float* Cs_d, float* PinvTs_d, int num_pairs, int* indices_d, float* K01s_d, float* out_d,
+ *                            float object_radius_mm, float dkappa, bool isDerivative, bool use_corr, float* out_corr_d)
+ * (ref: EpipolarConsistencyRadonIntermediate.cpp:16-37, .cu:300-409) does with the caller's device buffers: Cs_d / PinvTs_d
+ * are the per-view geometry the caller's host class made (ref: ...RadonIntermediate.cpp:134-163), indices_d the optional
+ * int4 list, K01s_d (nullable) the 16 floats per pair, out_d the n x n cost image (all pairs: entry i + j n, i < j; the rest
+ * untouched) or num_pairs values (index list).  The Radon intermediates are the metric's (ecc_dtr_from_device_linear +
+ * ecc_metric_create, once per data set: the reference builds its textures once too).  Synchronous, like the reference's
+ * launcher.  With use_corr the value is the finished cost 1 - cc (the reference hands five moments to its host epilogue,
+ * ref: .cu:116-149, .cpp:199-210: that epilogue goes).  The rest of the caller's host epilogue stays (ref: .cpp:197-224). */
+int ecc_metric_evaluate_external(ecc_metric* m, int num_Ps, const float* Cs_d, const float* PinvTs_d, int num_pairs,
+                                 const int32_t* indices_d, float* K01s_d, float* out_d, float object_radius_mm, float dkappa,
+                                 int use_corr);
 /* Debug: the device-side result of the pre-compute (12 + 4 floats per view, host output). */
 int ecc_metric_debug_geometry(ecc_metric* m, float* PinvTs, float* Cs);
 
@@ -434,6 +469,9 @@ int ecc_metric_balanced_shards(ecc_metric* m, int world, int64_t* bounds);
  * a rank whose device already holds all of them borrows them instead) and its own ecc_metric.  Same borrowing
  * contract as ecc_metric_create. */
 int ecc_group_metric_create(ecc_group* g, int n_dtrs, ecc_dtr* const* dtrs, ecc_group_metric** out);
+/* Debug / test hook: groups metrics created while it is on copy the Radon-intermediate stack on every rank even when it
+ * is already on the rank's device (the code path of a real multi-GPU group on a one-GPU box; doubles the memory). */
+int ecc_group_debug_force_replica(int on);
 int ecc_group_metric_destroy(ecc_group_metric* gm);
 /* ref: setProjectionMatrices.  The matrices are copied and handed to the devices together with the next
  * evaluation (one hand-off to the rank threads per optimiser step). */

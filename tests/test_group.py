@@ -144,17 +144,20 @@ def test_multi_rank_group_on_one_device(gpu_ctx, oracle_mod, small_scan, ranks):
 
 
 @pytest.mark.gpu
-def test_replica_path_on_one_device(gpu_ctx, small_scan, monkeypatch):
-    """ECC_GROUP_FORCE_REPLICA=1: every rank copies the Radon-intermediate stack although it is already on its device --
+def test_replica_path_on_one_device(gpu_ctx, small_scan):
+    """ecc_group_debug_force_replica(1): every rank copies the Radon-intermediate stack although it is already on its device --
     the code the ranks of a real multi-GPU group run (allocation, device-to-device copies, read-back probes against the
     source, metrics built on the copy), minus the peer-to-peer flavour of the copy."""
     import epipolarconsistency_amd as E
     s = small_scan
-    monkeypatch.setenv("ECC_GROUP_FORCE_REPLICA", "1")
-    g = E.Group([0, 0])
-    dtrs = g.compute_batch(s["imgs"], s["n_alpha"], s["n_t"])
-    gm = E.GroupMetricRadonIntermediate(g, s["Ps"], dtrs)
-    monkeypatch.delenv("ECC_GROUP_FORCE_REPLICA")
+    from epipolarconsistency_amd import _lib
+    _lib.lib().ecc_group_debug_force_replica(1)
+    try:
+        g = E.Group([0, 0])
+        dtrs = g.compute_batch(s["imgs"], s["n_alpha"], s["n_t"])
+        gm = E.GroupMetricRadonIntermediate(g, s["Ps"], dtrs)
+    finally:
+        _lib.lib().ecc_group_debug_force_replica(0)
     m = E.MetricRadonIntermediate(gpu_ctx, s["Ps"], [E.RadonIntermediate.from_host(gpu_ctx, d, s["n_u"], s["n_v"])
                                                      for d in s["dtrs"]])
     bnd = m.balanced_shards(2)
