@@ -127,7 +127,7 @@ def load_pmc(kernel_prefix):
     return None
 
 
-def live_pmc(args):
+def live_pmc(args, counters=("FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD")):
     """One rocprofv3 --pmc pass over a short run of THIS bench (child process: python3 bench.py --steps 3 --no-live-pmc):
     per-launch averages of FETCH_SIZE, SQ_INSTS_VALU and SQ_INSTS_VMEM_RD of the pair kernel, measured on this box in
     this run.  FETCH_SIZE (TCC) and the SQ counters fit one pass; WRITE_SIZE cannot ride along (TCC slots,
@@ -148,7 +148,7 @@ def live_pmc(args):
         return None
     out_dir = tempfile.mkdtemp(prefix="ecc_pmc_", dir="/tmp")
     try:
-        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "--output-format", "csv",
+        cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv",
                "-d", out_dir, "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--blocks", "3",
                "--no-cpu-baseline", "--no-live-pmc", "--views", str(args.views), "--size", str(args.size), "--bins", str(args.bins)]
         env = dict(os.environ, TMPDIR="/tmp")
@@ -166,17 +166,50 @@ def live_pmc(args):
         big = max(grids.values()) if grids else 0
         per = {k: v for k, v in per.items() if 2 * grids.get(k[0], 0) >= big}
         res = {}
-        for name in ("FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD"):
+        for name in counters:
             v = [val for (d, c), val in per.items() if c == name]
             if not v:
                 return None
             res[name] = sum(v) / len(v)
-        res["dispatches"] = len([1 for (d, c) in per if c == "FETCH_SIZE"])
+        res["dispatches"] = len([1 for (d, c) in per if c == counters[0]])
         return res
     except Exception:
         return None
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def host_cpu_info():
+    """Model string, physical cores and usable CPUs of this box (printed with every CPU number)."""
+    model, phys, logical = None, set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                logical += 1
+            elif line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical or (os.cpu_count() or 1)
+    quota = None
+    try:  # cgroup v2 CPU quota of the container, in CPUs
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    sockets = len({p for p, _ in phys}) or 1
+    return {"model": model or "unknown", "sockets": sockets, "physical_cores": len(phys) or None, "logical_cpus": logical or None,
+            "usable_cpus": usable, "cgroup_cpu_quota": quota}
 
 
 def n_kappa_auto(n_u, n_v, n_t):
@@ -642,16 +675,25 @@ def main():
                                  % (pmc["SQ_INSTS_VALU"], pmc["_tag"], VALU_CYCLES_PER_WAVE_INSTR, N_CU * SIMD_PER_CU)}
         if "SQ_INSTS_VMEM_RD" in pmc:
             roofs["l1"]["gathers_per_launch"] = pmc["SQ_INSTS_VMEM_RD"]
+    # L2 hit rate of the pair kernel: a second, separate pass (the TCC counters do not fit beside FETCH_SIZE)
+    live_tcc = live_pmc(args, ("TCC_HIT_sum", "TCC_MISS_sum")) if live else None
     if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         traffic = int(2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024)
         traffic_src = "2 x FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 counts 128-B fabric reads as 64 B); " + pmc_origin
         roofs["hbm_measured"] = {"achieved": traffic / pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": traffic / pair_s / 1e9 / HBM_PEAK_GBS}
+    # SURVEY.md 8(d)'s compulsory figure: every Radon intermediate read once + the per-view geometry + one float per pair
+    hbm_compulsory = 4 * n * B * B + 64 * n + 4 * count
     bound = max(roofs, key=lambda r: roofs[r]["frac"])
     roofline = {"bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"],
                 "unit": roofs[bound]["unit"], "frac": roofs[bound]["frac"], "traffic": traffic,
                 "traffic_source": traffic_src, "kernel": "pairs_kernel<true, false>", "kernel_ms": pair_ms,
                 "algorithmic_bytes_per_launch": launch_bytes, "roofs": roofs,
+                "hbm_compulsory_bytes": hbm_compulsory,
+                "traffic_over_compulsory": (traffic / hbm_compulsory) if traffic else None,
+                "l2_hit_rate": (live_tcc["TCC_HIT_sum"] / (live_tcc["TCC_HIT_sum"] + live_tcc["TCC_MISS_sum"])) if live_tcc else None,
+                "l2_hit_rate_source": ("measured in this run: a second rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum pass over a child run "
+                                       "of this bench, %d launches averaged" % live_tcc["dispatches"]) if live_tcc else None,
                 # SURVEY.md 8(d)'s figure against HBM peak: > 1 means the gather's reuse is captured on chip
                 "hbm_algorithmic": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "reuse_factor_vs_hbm_peak": achieved / HBM_PEAK_GBS}}
@@ -758,6 +800,12 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         import oracle
         oracle.build(native=True)
+        cpu = host_cpu_info()
+        # threads = physical cores, but no more than this process may run on (affinity mask, cgroup quota)
+        threads = min(cpu["physical_cores"] or cpu["usable_cpus"], cpu["usable_cpus"])
+        if cpu["cgroup_cpu_quota"]:
+            threads = max(1, min(threads, int(cpu["cgroup_cpu_quota"])))
+        oracle.lib(native=True).eccor_set_num_threads(int(threads))
         views = list(range(0, n, args.cpu_sample_stride))
         host_dtrs = [dtrs[v].readback() for v in views]
         Psub = [Ps[v] for v in views]
@@ -774,7 +822,10 @@ def main():
         metric.setProjectionMatrices(Ps)
         gpu_mean = metric.evaluate(set(views)) if args.cpu_sample_stride > 1 else metric.evaluate()
         out["cpu_baseline"] = {
-            "value": cpu_evals, "unit": "evaluations/s", "cores": oracle.lib().eccor_num_threads(), "kind": "port",
+            "value": cpu_evals, "unit": "evaluations/s", "cores": oracle.lib(native=True).eccor_num_threads(), "kind": "port",
+            "cpu_model": cpu["model"], "sockets": cpu["sockets"], "physical_cores": cpu["physical_cores"],
+            "logical_cpus": cpu["logical_cpus"], "usable_cpus": cpu["usable_cpus"], "cgroup_cpu_quota": cpu["cgroup_cpu_quota"],
+            "threads_used": oracle.lib(native=True).eccor_num_threads(),
             "sample": "%d x all %d pairs among every %d-th view (%d of %d pairs per evaluation) in %.1f s, "
                       "scaled by pair count; oracle/ecc_oracle.c -O3 -march=native -fopenmp"
                       % (reps, sub_pairs, args.cpu_sample_stride, sub_pairs, n_pairs, cpu_s),

@@ -1364,6 +1364,15 @@ ECCOR_API int eccor_direct_pair(const double *P0, const double *P1, const float 
     return n_lines;
 }
 
+ECCOR_API void eccor_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ECCOR_API int eccor_num_threads(void)
 {
 #ifdef _OPENMP
