@@ -250,13 +250,21 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for q, Pq in zip(mine, poses):
-        values[q] = metric.setProjectionMatrices(Pq).evaluate()
+    # ecc_metric_evaluate_poses: the rank's poses two deep on its one context -- the hand-over of pose k + 1 overlaps the
+    # device's work on pose k; the same launches in the same order as one setProjectionMatrices + evaluate per pose
+    values[mine] = metric.evaluate_poses(poses)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # the same poses one at a time (what round 3 timed), and the proof that nothing but the waiting changed
+    t1 = time.perf_counter()
+    one_by_one = np.array([metric.setProjectionMatrices(Pq).evaluate() for Pq in poses])
+    torch.cuda.synchronize()
+    elapsed_seq = time.perf_counter() - t1
+    if not np.array_equal(one_by_one, values[mine]):
+        raise SystemExit("rank %d: two-deep pose evaluation changed %d of %d values" % (rank, int((one_by_one != values[mine]).sum()), len(mine)))
     if world > 1:
         on = dev if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=on)
@@ -277,6 +285,11 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
                       "k01_record_reuse": "on (library default)", "ranks_seen_by_collective_backend": ranks_seen,
                       "devices": devices_seen},
            "ms_per_step_note": "per rank: each rank evaluates %d poses" % len(mine),
+           "timing": {"value_is": "ecc_metric_evaluate_poses: this rank's poses two deep on its context",
+                      "one_pose_at_a_time": {"value": len(mine) * world / elapsed_seq if elapsed_seq > 0 else None,
+                                             "ms_per_pose": 1e3 * elapsed_seq / len(mine),
+                                             "note": "rank 0's poses by setProjectionMatrices + evaluate each, after the timed "
+                                                     "run; all values bit-identical to the two-deep run"}},
            "min_at_step": [int(np.argmin(values[p])) for p in range(6)],
            "values_checksum": float(values.sum())}
     if rank == 0 and not args.no_cpu_baseline:
@@ -711,10 +724,10 @@ def main():
                                                % (LDS_READ_B64_BYTES_PER_CLK_CU, N_CU, ENGINE_CLOCK_GHZ)},
                "lds_algorithmic_b32": {"achieved": lds_ach, "peak": lds_peak_b32, "unit": "GB/s", "frac": lds_ach / lds_peak_b32,
                                        "note": "the same bytes against the ds_read2_b32 rate (128 B/clk/CU) rounds 1-2 were priced on"}}
-    roofline_radon = {"kernel": "radon_kernel<true>", "kernel_ms_per_image": ms_per_radon,
+    roofline_radon = {"kernel": "radon_kernel<true, false> (derivative, exact arithmetic)", "kernel_ms_per_image": ms_per_radon,
                       "algorithmic_bytes_per_image": 16 * fetches, "bilinear_fetches_per_image": fetches,
                       "compulsory_hbm_bytes_per_image": 4 * (S * S + B * B)}
-    rp = load_pmc("radon_kernel<true>") if (S, B) == (1024, 768) else None
+    rp = load_pmc("radon_kernel<true, false>") if (S, B) == (1024, 768) else None
     if rp and rp.get("SQ_LDS_IDX_ACTIVE"):
         roofline_radon["lds_bank_conflict_ratio"] = rp["SQ_LDS_BANK_CONFLICT"] / rp["SQ_LDS_IDX_ACTIVE"]
         roofline_radon["pmc_source"] = ("SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE, SQ_INSTS_VALU per 50-image launch: separate rocprofv3 --pmc "
@@ -730,6 +743,17 @@ def main():
             roofs_r["valu"] = {"achieved": valu_ach, "peak": valu_peak, "unit": "G wave-instr/s", "frac": valu_ach / valu_peak,
                                "note": "SQ_INSTS_VALU = %.4g per image at 2 cycles per wave64 instruction on 1024 SIMDs (the 4-cycle "
                                        "v_floor_f32 count as 2: a lower bound of the pipe's occupancy)" % (rp["SQ_INSTS_VALU"] / sub)}
+    # the contracted-arithmetic mode (ecc_radon_set_arithmetic(ECC_RADON_FMA)) against the same two roofs, from its own PMC pass
+    rf = load_pmc("radon_kernel<true, true>") if (S, B) == (1024, 768) else None
+    if rf and rf.get("SQ_INSTS_VALU") and rf.get("SQ_LDS_IDX_ACTIVE") and ms_per_radon_fma > 0:
+        img_f = ms_per_radon_fma * 1e-3
+        roofline_radon["fma_mode"] = {
+            "kernel": "radon_kernel<true, true>", "kernel_ms_per_image": ms_per_radon_fma,
+            "valu_frac": rf["SQ_INSTS_VALU"] / sub / img_f / 1e9 / (N_CU * SIMD_PER_CU * ENGINE_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_INSTR),
+            "lds_pipe_active_frac": rf["SQ_LDS_IDX_ACTIVE"] / sub / (N_CU * ENGINE_CLOCK_GHZ * 1e9 * img_f),
+            "wave_instructions_per_image": rf["SQ_INSTS_VALU"] / sub,
+            "note": "both pipes are 0.6-0.7 busy: the contracted loop (40 instead of 52 vector instructions per step) is no longer "
+                    "bound by vector issue alone"}
     binding = max(roofs_r, key=lambda r: roofs_r[r]["frac"] if r != "lds_algorithmic_b32" else -1.0)
     roofline_radon.update({"bound": {"valu": "valu", "lds_pipe_active": "lds"}.get(binding, "lds"), "binding": binding,
                            "achieved": roofs_r[binding].get("achieved"), "peak": roofs_r[binding].get("peak"),

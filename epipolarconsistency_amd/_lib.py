@@ -73,6 +73,7 @@ SIGNATURES = {
     "ecc_metric_last_evaluated_pairs": (_i, [_vp, C.POINTER(_i64)]),
     "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
+    "ecc_metric_evaluate_poses": (_i, [_vp, _i, _vp, _i, _vp]),
     "ecc_metric_evaluate_range": (_i, [_vp, _i64, _i64, _vp, _pd]),
     "ecc_metric_evaluate_range_async": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "ecc_metric_evaluate_pairs": (_i, [_vp, _vp, _i, _vp, _pd]),

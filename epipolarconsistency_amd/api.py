@@ -498,6 +498,19 @@ class MetricRadonIntermediate:
                                           C.c_void_p(out.ctypes.data), C.byref(mean)))
         return mean.value
 
+    def evaluate_poses(self, poses):
+        """ecc_metric_evaluate_poses: independent all-pairs evaluations of several poses on this metric, two deep (the
+        hand-over of pose k + 1 overlaps the device's work on pose k); poses: a sequence of (n, 12) column-major arrays
+        (pack_projection_matrices) or lists of 3x4 matrices; returns the means (bit-identical to evaluating them one by
+        one).  The last pose's matrices stay current."""
+        flat = np.ascontiguousarray(np.stack([p if (isinstance(p, np.ndarray) and p.ndim == 2 and p.shape[1] == 12)
+                                              else _Ps_colmajor(p) for p in poses]), np.float64)
+        means = np.zeros(len(flat), np.float64)
+        check(_lib.lib().ecc_metric_evaluate_poses(self._h, len(flat), C.c_void_p(flat.ctypes.data), flat.shape[1],
+                                                   C.c_void_p(means.ctypes.data)))
+        self._Ps = flat[-1]
+        return means
+
     def evaluateForImagePair(self, i, j):
         """ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas, radon_samples0,
         radon_samples1) (...RadonIntermediate.cpp:324-393, visualisation).  Returns (ecc, dict) with the

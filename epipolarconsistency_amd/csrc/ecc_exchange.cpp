@@ -29,7 +29,7 @@
 
 #define ECC_EXPORT extern "C" __attribute__((visibility("default")))
 
-int ecc_set_error(int code, const char* msg);  // ecc_capi.hip: records the message for ecc_last_error()
+extern "C" int ecc_set_error(int code, const char* msg);  // ecc_capi.hip: records the message for ecc_last_error()
 
 namespace {
 

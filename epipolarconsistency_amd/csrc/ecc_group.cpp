@@ -33,7 +33,7 @@
 
 #define ECC_EXPORT extern "C" __attribute__((visibility("default")))
 
-int ecc_set_error(int code, const char* msg);  // ecc_capi.hip: records the message for ecc_last_error()
+extern "C" int ecc_set_error(int code, const char* msg);  // ecc_capi.hip: records the message for ecc_last_error()
 
 struct ecc_group {
     std::vector<int> devices;

@@ -143,8 +143,18 @@ __device__ __forceinline__ void sincos_quadrant(float kappa, float& s, float& c)
     c = swap ? sn : cs;
 }
 
+// The copies the pair kernel samples live in GLOBAL memory, and the pointer type says so: their base comes out of a device
+// table (p.dtrs[i]), which leaves a plain pointer's address space unknown to the compiler -- flat loads with 64-bit vector
+// address arithmetic instead of global_load saddr + 32-bit voffset (round 4: +6 % vector instructions, +9 % kernel time
+// when the sampling code moved behind a reference parameter and the kernel-argument promotion no longer saw through it).
+typedef const __attribute__((address_space(1))) char* GlobalBytes;
+typedef const __attribute__((address_space(1))) float* GlobalFloats;
+// one bilinear footprint (16 bytes, 4-byte aligned) as a built-in vector: loadable through a global-address-space pointer in
+// the host pass of the compiler too (a struct would need a constructor from that address space)
+typedef float ecc_v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const __attribute__((address_space(1))) ecc_v4f_a4* GlobalF4;
 struct SlabView {
-    const char* origin;  // base of the dtr's ROW-PAIRED copy: padded element (row 0, column 0) = (ix = -1, iy = -1)
+    GlobalBytes origin;  // base of the dtr's ROW-PAIRED copy: padded element (row 0, column 0) = (ix = -1, iy = -1)
     unsigned pitch4;     // row pitch of the paired copy in bytes (8 bytes per distance bin)
 };
 
@@ -202,7 +212,7 @@ __device__ __forceinline__ unsigned footprint_offset(float row_f, float bin_f, u
 // PITCH4 > 0: row pitch in bytes known at
 // compile time (the 768-bin default), the second row's load then uses an immediate offset.
 struct LineTap {
-    const F4* ptr;  // the 2x2 footprint in the row-paired copy
+    GlobalF4 ptr;  // the 2x2 footprint in the row-paired copy
     float fx, fy;   // bilinear weights
     unsigned m;     // sign bit of the fold
 };
@@ -262,7 +272,7 @@ __device__ __forceinline__ LineTap sample_line_prep(float l0, float l1, float l2
     // byte offset floor(xa)*pitch4 + floor(yd)*8 in the row-paired copy; ONE 16-byte load fetches the whole 2x2 footprint
     const unsigned off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
     LineTap t;
-    t.ptr = reinterpret_cast<const F4*>(sv.origin + off);
+    t.ptr = (GlobalF4)(sv.origin + off);
     t.fx = fx;
     t.fy = fy;
     t.m = m;
@@ -285,7 +295,9 @@ __device__ __forceinline__ float sample_line(float l0, float l1, float l2, const
     const LineTap t = sample_line_prep<PITCH4>(l0, l1, l2, sv, n_alpha_f, n_t_f, dist_scale, dist_bias, pitch4_f);
     // (non-temporal gathers for the kappa_max > pi/4 pairs, whose lines nobody re-uses, were measured inside the
     // benchmark's mixed launch: 0.344 vs 0.333 ms -- they lose their own L1 hits)
-    return line_tap_finish<DERIV>(*t.ptr, t);
+    const ecc_v4f_a4 q4 = *t.ptr;
+    const F4 q = {q4.x, q4.y, q4.z, q4.w};
+    return line_tap_finish<DERIV>(q, t);
 }
 
 // One kappa sample (four bilinear samples) of the pair loop; returns false when kappa is past kappa_max.
@@ -385,7 +397,8 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
         fy = __builtin_amdgcn_fractf(yd);
         off = footprint_offset<PITCH4>(xa - fx, yd - fy, sv.pitch4, pitch4_f);
     }
-    const F4 q = *reinterpret_cast<const F4*>(sv.origin + off);
+    const ecc_v4f_a4 q4 = *(GlobalF4)(sv.origin + off);
+    const F4 q = {q4.x, q4.y, q4.z, q4.w};
     const float r0 = fmaf(fx, q.y, q.x);  // q.y, q.w: the row differences, formed when the copy is built
     const float r1 = fmaf(fx, q.w, q.z);
     const float v = fmaf(fy, r1 - r0, r0);
@@ -954,8 +967,8 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
         K1[i] = uniformf(rec->K1[i]);
     }
     const unsigned pitch4 = (unsigned)p.pitch * 8u;  // row pitch of the paired copies in bytes
-    const SlabView sv0 = {reinterpret_cast<const char*>(p.dtrs[iD0]), pitch4};
-    const SlabView sv1 = {reinterpret_cast<const char*>(p.dtrs[iD1]), pitch4};
+    const SlabView sv0 = {(GlobalBytes)p.dtrs[iD0], pitch4};
+    const SlabView sv1 = {(GlobalBytes)p.dtrs[iD1], pitch4};
     const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
     const float dist_scale = n_t_f / p.range_t, dist_bias = fmaf(0.5f, n_t_f, 0.5f);
     const float pitch4_f = (float)pitch4;
@@ -989,8 +1002,8 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
         // 0.331 ms) -- there they cost 5 % as their own wave time and 5 % by slowing everybody else down
         // (scripts/exp_wave_timeline.py: a degree-8 wave takes 26.2 us next to them, 25.0 us without), whichever copy
         // they sample.  Useful for per-sample / index-list workloads made of such pairs.
-        const SlabView q0 = {reinterpret_cast<const char*>(p.quads[iD0]), p.quad_group_bytes};
-        const SlabView q1 = {reinterpret_cast<const char*>(p.quads[iD1]), p.quad_group_bytes};
+        const SlabView q0 = {(GlobalBytes)p.quads[iD0], p.quad_group_bytes};
+        const SlabView q1 = {(GlobalBytes)p.quads[iD1], p.quad_group_bytes};
         kappa_loop<DERIV, CORR, true, ECC_QUAD_LAYOUT, WPP>(lane, p.k_limit, K0, K1, q0, q1, n_alpha_f, n_t_f, dist_scale, dist_bias,
                                                        pitch4_f, acc, mom2, mom3, mom4, sub, stage);
     } else if (p.wide_offsets) {
@@ -1010,7 +1023,7 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
 }
 
 
-__device__ __forceinline__ float slab_texel(const float* slab, int pitch, int n_alpha, int n_t, int i, int j)
+__device__ __forceinline__ float slab_texel(GlobalFloats slab, int pitch, int n_alpha, int n_t, int i, int j)
 {
     i = min(max(i, 0), n_alpha - 1);
     j = min(max(j, 0), n_t - 1);
@@ -1018,7 +1031,7 @@ __device__ __forceinline__ float slab_texel(const float* slab, int pitch, int n_
 }
 
 // (a, d) in normalised texture coordinates -> value; W = n_alpha (x), H = n_t (y).
-__device__ float slab_tex2d_norm(const float* slab, int pitch, int n_alpha, int n_t, float s, float t)
+__device__ float slab_tex2d_norm(GlobalFloats slab, int pitch, int n_alpha, int n_t, float s, float t)
 {
     const float x = s * (float)n_alpha, y = t * (float)n_t;
     const float xb = x - 0.5f, yb = y - 0.5f;
@@ -1035,7 +1048,7 @@ __device__ float slab_tex2d_norm(const float* slab, int pitch, int n_alpha, int 
 }
 
 // ref: EpipolarConsistencyCommon.hxx:152-171 (lineToSampleDtr) + RadonIntermediate.h:86-105 (sample)
-__device__ float sample_line_plain(const float* K, float x0, float x1, const float* slab, int pitch, int n_alpha,
+__device__ float sample_line_plain(const float* K, float x0, float x1, GlobalFloats slab, int pitch, int n_alpha,
                                    int n_t, float range_t, bool derivative, float* a_out, float* d_out)
 {
     const float Pi = 3.14159265359f;
@@ -1064,7 +1077,7 @@ __device__ float sample_line_plain(const float* K, float x0, float x1, const flo
 // exact fp32 bilinear rule with index clamps on the dtr's own slab); float64 partial sums of this thread.
 template <bool CORR>
 __device__ __forceinline__ void reference_loop(const EccPairParams& p, const float (&K0)[8], const float (&K1)[8],
-                                               const float* __restrict__ d0, const float* __restrict__ d1, int first_k, int stride,
+                                               GlobalFloats d0, GlobalFloats d1, int first_k, int stride,
                                                double& acc, double& mom2, double& mom3, double& mom4)
 {
     const float dkappa = K1[6], kappa_max = K1[7];

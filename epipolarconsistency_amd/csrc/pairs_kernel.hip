@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256) void pair_samples_kernel(EccPairSamplesParams 
     if (!(kappa + dkappa < kappa_max) || k + 1 == p.capacity) *p.n_out = k + 1;  // exactly one thread: the last sample
     const float x0 = (float)cos((double)kappa), x1 = (float)sin((double)kappa);
     float a0, d0, a1, d1;
-    const float v0 = sample_line_plain(K0, x0, x1, p.dtr0, p.pitch, p.n_alpha, p.n_t, p.range_t, p.derivative0 != 0, &a0, &d0);
-    const float v1 = sample_line_plain(K1, x0, x1, p.dtr1, p.pitch, p.n_alpha, p.n_t, p.range_t, p.derivative1 != 0, &a1, &d1);
+    const float v0 = sample_line_plain(K0, x0, x1, (GlobalFloats)p.dtr0, p.pitch, p.n_alpha, p.n_t, p.range_t, p.derivative0 != 0, &a0, &d0);
+    const float v1 = sample_line_plain(K1, x0, x1, (GlobalFloats)p.dtr1, p.pitch, p.n_alpha, p.n_t, p.range_t, p.derivative1 != 0, &a1, &d1);
     p.out[0 * (size_t)p.capacity + k] = v0;
     p.out[1 * (size_t)p.capacity + k] = v1;
     p.out[2 * (size_t)p.capacity + k] = kappa;
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairPara
     }
     const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
     const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
-    const float* __restrict__ d0 = p.slabs[iD0];
-    const float* __restrict__ d1 = p.slabs[iD1];
+    const GlobalFloats d0 = (GlobalFloats)p.slabs[iD0];
+    const GlobalFloats d1 = (GlobalFloats)p.slabs[iD1];
     double acc = 0.0, mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;
     reference_loop<CORR>(p, K0, K1, d0, d1, SPLIT == 1 ? lane : (int)threadIdx.x, 64 * SPLIT, acc, mom2, mom3, mom4);
     if (!CORR) {

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
                 K1[i] = uniformf(rec->K1[i]);
             }
             const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
-            reference_loop<false>(p, K0, K1, p.slabs[iD0], p.slabs[iD1], (int)threadIdx.x, 256, acc, m2, m3, m4);
+            reference_loop<false>(p, K0, K1, (GlobalFloats)p.slabs[iD0], (GlobalFloats)p.slabs[iD1], (int)threadIdx.x, 256, acc, m2, m3, m4);
         }
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         if (lane == 0) part[wave] = acc;

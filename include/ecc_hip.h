@@ -312,6 +312,13 @@ int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);
  * contiguous slices and the slice sums are added in slice order.  A sum over G shards is the rank-ordered sum of G such
  * sums.  So one-device and sharded sums of the same pair values agree to float64 rounding (~1e-16), not bit for bit. */
 int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean);
+/* n_poses INDEPENDENT all-pairs evaluations (Ps_batch: n_poses x n_views x 12 float64; means: n_poses results) on this one
+ * metric, evaluated two deep: while the device runs pose k the host already hands over pose k + 1, and only then polls pose
+ * k's result -- the ~20 us between a result and the next evaluation's first kernel are hidden.  Same launches in the same
+ * order as n_poses x (ecc_metric_set_projections + ecc_metric_evaluate_all): every mean has the same bits.  The matrices
+ * of the last pose stay the metric's current ones.  (ref: Gui/Visualization.h:78-98 plotCostFunction -- BASELINE config 5 --
+ * or the probes of a finite-difference gradient; with ecc_metric_set_incremental the poses are evaluated one at a time.) */
+int ecc_metric_evaluate_poses(ecc_metric* m, int n_poses, const double* Ps_batch, int n_views, double* means);
 
 /* Multi-GPU building block: evaluate only pairs ij in [first, first+count) of the get_ij order
  * (ref: EpipolarConsistencyCommon.hxx:52-79); returns the partial sum (float64) -- the caller

@@ -13,7 +13,7 @@ for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    m=re.search(r"(radon_kernel<\w+>)", r["Kernel_Name"])
+    m=re.search(r"(radon_kernel<[\w, ]+>)", r["Kernel_Name"])
     if m: acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$GRAFT_REPO_ROOT/gpurun_out/pmcr_$tag.summary.txt","w") as f:
     for k,v in sorted(acc.items()):

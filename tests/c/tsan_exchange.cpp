@@ -12,7 +12,7 @@
 #include "../../include/ecc_hip.h"
 
 static thread_local std::string g_err;
-int ecc_set_error(int code, const char* msg)  // the library's error slot (ecc_capi.hip) stands outside this build
+extern "C" int ecc_set_error(int code, const char* msg)  // the library's error slot (ecc_capi.hip) stands outside this build
 {
     g_err = msg ? msg : "";
     return code;

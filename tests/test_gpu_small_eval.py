@@ -174,3 +174,32 @@ def test_with_incremental_mode_and_group(gpu_ctx, small_scan):
         parts = [ref.evaluate_range(bnd[r], bnd[r + 1] - bnd[r]) for r in range(3)]
         assert a == (parts[0] + parts[1] + parts[2]) / 28, views
     gm.close(); ref.close(); g.close()
+
+
+def test_poses_two_deep_are_the_one_by_one_values(gpu_ctx):
+    """ecc_metric_evaluate_poses: the same launches in the same order, only the host's waiting moves -- every mean bit-identical
+    to setProjectionMatrices + evaluate per pose, at sizes that take the one-stream and the two-stream refit, with reuse
+    off, and in the pose-delta mode (which evaluates them one at a time)."""
+    import epipolarconsistency_amd as E
+    for n, B in ((20, 48), (150, 32)):  # 190 pairs / 11 175 pairs (two-stream record reuse)
+        Ps, base, dtrs = _scan(gpu_ctx, n, B=B)
+        P0 = E.pack_projection_matrices(Ps)
+        poses = []
+        for k in range(17):
+            P = P0.copy()
+            for v in ([k % n] if k % 4 else [k % n, (3 * k + 1) % n, 0]):
+                P[v] = (P[v].reshape(4, 3).T @ E.geometry.rigid_transform(tx=0.1 * (k + 1), rz=0.002 * k)).T.reshape(12)
+            poses.append(P)
+        for setup in (lambda m: m, lambda m: m.setRecordReuse(False), lambda m: m.setIncremental(True), lambda m: m.setSampling("per_sample")):
+            a = setup(E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("polynomial"))
+            b = setup(E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("polynomial"))
+            got = a.evaluate_poses(poses)
+            want = np.array([b.setProjectionMatrices(P).evaluate() for P in poses])
+            assert np.array_equal(got, want), (n, got - want)
+            assert a.evaluate() == b.evaluate()  # the last pose's matrices stay current
+            got2 = a.evaluate_poses(poses[::-1])  # and again, starting from kept state
+            want2 = np.array([b.setProjectionMatrices(P).evaluate() for P in poses[::-1]])
+            assert np.array_equal(got2, want2)
+            a.close(); b.close()
+        for d in base:
+            d.close()
