@@ -30,6 +30,8 @@ def test_pmc_summary_reader():
     b = _bench()
     p = b.load_pmc("pairs_kernel<true, false>")
     assert p is not None and p["SQ_INSTS_VALU"] > 1e8 and p["FETCH_SIZE"] > 1e5 and p["_tag"]
-    r = b.load_pmc("radon_kernel<true>")
-    assert r is not None and 0 < r["SQ_LDS_BANK_CONFLICT"] < r["SQ_LDS_IDX_ACTIVE"]
+    for name in ("radon_kernel<true, false>", "radon_kernel<true, true>"):  # exact and contracted arithmetic
+        r = b.load_pmc(name)
+        assert r is not None and 0 < r["SQ_LDS_BANK_CONFLICT"] < r["SQ_LDS_IDX_ACTIVE"] and r["SQ_INSTS_VALU"] > 1e10
+    assert b.load_pmc("radon_kernel<true, true>")["SQ_INSTS_VALU"] < 0.8 * b.load_pmc("radon_kernel<true, false>")["SQ_INSTS_VALU"]
     assert b.load_pmc("no_such_kernel") is None
