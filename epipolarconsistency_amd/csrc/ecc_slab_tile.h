@@ -35,8 +35,14 @@ namespace ecc_slab {
 
 constexpr int THREADS = 256;               // threads (= lines) per workgroup
 constexpr int WAVES = THREADS / 64;
-constexpr int TILE_CAP = 5056;             // texel pairs per workgroup: 40 448 B, four workgroups per CU
-constexpr int N_PRE = 26;                  // texels a thread stages per slab (registers that live across the sampling loop)
+#ifndef ECC_SLAB_TILE_CAP
+#define ECC_SLAB_TILE_CAP 5056
+#endif
+#ifndef ECC_SLAB_N_PRE
+#define ECC_SLAB_N_PRE 26
+#endif
+constexpr int TILE_CAP = ECC_SLAB_TILE_CAP; // texel pairs per workgroup: 40 448 B, four workgroups per CU
+constexpr int N_PRE = ECC_SLAB_N_PRE;       // texels a thread stages per slab (registers that live across the sampling loop)
 static_assert(N_PRE <= 32, "stage_regs is a 32-float vector");
 constexpr int S_MIN = 64, S_MAX = 256;     // row stride of the tile in pairs (multiples of 32)
 constexpr int MAX_SLABS = 8192;            // bound on the slab loop (every loop is bounded)

@@ -169,8 +169,11 @@ __device__ __forceinline__ void radon_body(const EccRadonParams& p, Shared& sh)
 // FMA: the sampling loop in contracted arithmetic (ecc_radon_set_arithmetic(ECC_RADON_FMA); oracle:
 // eccor_set_radon_contract(1)) -- positions fmaf(t, d, o), lerps T00 + fx * (T10 - T00) as one fma each: 40 instead of
 // 52 vector instructions per step.  The per-bin set-up above the loop is the same unfused code in both.
+#ifndef ECC_RADON_MIN_WAVES
+#define ECC_RADON_MIN_WAVES 1
+#endif
 template <bool DERIV, bool FMA>
-__global__ __launch_bounds__(RT_THREADS) void radon_kernel(EccRadonParams p)
+__global__ __launch_bounds__(RT_THREADS, ECC_RADON_MIN_WAVES) void radon_kernel(EccRadonParams p)
 {
     __shared__ Shared sh;
     // Line normal of the workgroup's middle angle: (nx, ny) = (-sin a, cos a).  The tile's fast axis is the image
