@@ -202,6 +202,12 @@ inline ecc_ctx* default_context()
 }
 }  // namespace detail
 
+/// Not in the reference: ecc_radon_set_arithmetic of the default context -- RadonIntermediates computed afterwards use the
+/// exact (default; unfused fp32, the CPU reading of ref: RadonIntermediate.cu:118-123) or the contracted convention
+/// (positions fmaf(t, d, o), lerps as one fma each: the arithmetic class of the reference's GPU build; ~11 % faster, the
+/// ECC metric moves by < 2e-6 relative on means over pairs).
+inline void setRadonArithmetic(bool contracted) { detail::check(ecc_radon_set_arithmetic(detail::default_context(), contracted ? ECC_RADON_FMA : ECC_RADON_EXACT)); }
+
 /// Not in the reference: evaluate() of every MetricRadonIntermediate created afterwards is sharded over these HIP
 /// devices (one host thread per device inside the library).  Call before the first dtr / metric is created.
 inline void setDefaultDevices(const std::vector<int>& devices)
@@ -558,6 +564,7 @@ class MetricRadonIntermediate : public Metric {
     int sampling;
     bool incremental;
     int record_reuse = -1;    // -1: the library's default
+    int small_eval = -1;      // -1: the library's default (on)
     ecc_metric* m_h;          // single-device metric, or the group's rank-0 metric (borrowed) when m_gh is set
     ecc_group_metric* m_gh;   // sharded over a group of devices (ecc_group_*), else null
     ecc_ctx* m_ctx;
@@ -574,6 +581,7 @@ class MetricRadonIntermediate : public Metric {
             detail::check(ecc_metric_set_sampling(m_h, sampling));
             detail::check(ecc_metric_set_incremental(m_h, incremental ? 1 : 0));
             if (record_reuse >= 0) detail::check(ecc_metric_set_record_reuse(m_h, record_reuse));
+            if (small_eval >= 0) detail::check(ecc_metric_set_small_eval(m_h, small_eval));
         }
     }
     void push_projections()
@@ -632,6 +640,28 @@ public:
     /// Not in the reference: ecc_metric_set_record_reuse (library default: on) -- the per-pair geometry of pairs whose
     /// matrices did not change is kept between evaluate() calls; every pair is still sampled, bit-identical results.
     MetricRadonIntermediate& setRecordReuse(bool on = true, bool always = false) { record_reuse = on ? (always ? 2 : 1) : 0; push_params(); return *this; }
+    /// Not in the reference: ecc_metric_set_small_eval (library default: on) -- evaluations of a few pairs (index lists,
+    /// evaluate() of a handful of views: the FluoroTracking pattern) go out as ONE kernel launch; bit-identical results.
+    MetricRadonIntermediate& setSmallEval(bool on = true) { small_eval = on ? 1 : 0; push_params(); return *this; }
+    /// Not in the reference: ecc_metric_evaluate_poses -- independent all-pairs evaluations of several sets of projection
+    /// matrices (a sweep as in Gui/Visualization.h:78-98 plotCostFunction, the probes of a finite-difference gradient),
+    /// each value bit-identical to setProjectionMatrices(poses[k]) + evaluate().  The last pose stays current.
+    std::vector<double> evaluatePoses(const std::vector<std::vector<Geometry::ProjectionMatrix> >& poses)
+    {
+        std::vector<double> means(poses.size(), 0.0);
+        if (poses.empty()) return means;
+        const size_t n = poses[0].size();
+        std::vector<double> flat(12 * n * poses.size());
+        for (size_t p = 0; p < poses.size(); ++p) {
+            if (poses[p].size() != n) throw std::runtime_error("evaluatePoses: all poses need the same number of views");
+            for (size_t i = 0; i < n; ++i)
+                for (int k = 0; k < 12; ++k) flat[12 * (n * p + i) + k] = poses[p][i].data()[k];
+        }
+        if (m_gh) detail::check(ecc_group_metric_evaluate_poses(m_gh, (int)poses.size(), flat.data(), (int)n, means.data()));
+        else detail::check(ecc_metric_evaluate_poses(m_h, (int)poses.size(), flat.data(), (int)n, means.data()));
+        Ps = poses.back();
+        return means;
+    }
 
     /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
     MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)

@@ -719,7 +719,10 @@ ECC_EXPORT int ecc_metric_evaluate_poses(ecc_metric* m, int n_poses, const doubl
     int rc = set_device(ctx);
     if (rc) return rc;
     const int64_t n = n_views, n_pairs = n * (n - 1) / 2;
-    if (m->incremental || result_slots(m) < 2) {  // the pose-delta mode keeps values of ONE previous evaluation: one at a time
+    // one at a time: the pose-delta mode (it keeps the values of ONE previous evaluation), and evaluations small enough
+    // for the one-launch path (its hand-over goes through result slot 0 and the host's sum; a few microseconds of device
+    // work leave nothing to overlap anyway)
+    if (m->incremental || result_slots(m) < 2 || n_pairs <= ECC_SMALL_EVAL_MAX_PAIRS) {
         for (int k = 0; k < n_poses; ++k) {
             rc = ecc_metric_set_projections(m, Ps_batch + (size_t)12 * n * k, n_views);
             if (rc) return rc;

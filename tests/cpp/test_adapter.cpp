@@ -94,6 +94,28 @@ int main(int argc, char** argv)
             printf("incremental %d %.17g %.17g\n", (full_values[0] == inc_values[0] && full_values[1] == inc_values[1] &&
                    full_values[2] == inc_values[2] && full_values[0] != full_values[1]) ? 1 : 0, full_values[2], inc_values[2]);
         }
+        {   // round 4: the one-launch path on / off and a batch of poses -- the same bits as one call per pose
+            std::vector<std::vector<ProjectionMatrix> > poses;
+            for (int step = 0; step < 4; ++step) {
+                std::vector<ProjectionMatrix> moved = Ps;
+                moved[1].data()[10] += 0.2 * (step + 1);
+                poses.push_back(moved);
+            }
+            double one_by_one[4], small_off[4];
+            for (int pass = 0; pass < 2; ++pass) {
+                ecc.setSmallEval(pass == 0);
+                for (int step = 0; step < 4; ++step) {
+                    ecc.setProjectionMatrices(poses[step]);
+                    (pass ? small_off : one_by_one)[step] = ecc.evaluate();
+                }
+            }
+            ecc.setSmallEval(true);
+            const std::vector<double> batch = ecc.evaluatePoses(poses);
+            bool same = batch.size() == 4;
+            for (int step = 0; same && step < 4; ++step) same = batch[step] == one_by_one[step] && small_off[step] == one_by_one[step];
+            ecc.setProjectionMatrices(Ps);
+            printf("round4 %d %.17g\n", (same && one_by_one[0] != one_by_one[1]) ? 1 : 0, batch[3]);
+        }
         {   // PreProccess (Gui/PreProccess.h): the two image calls one after the other on image 1, the fused stack call on
             // all images -- results written next to the input file for the driver to compare
             PreProccess pre;

@@ -185,6 +185,7 @@ def test_adapter_matches_oracle(tmp_path, oracle_mod, small_scan):
         assert np.array_equal(got_pre[k], oracle_mod.preprocess(imgs[k], Ps[k], scale=0.5, bias=0.125, zero=(3, 1, 1, 1), flip_u=True))
     # setIncremental (pose-delta evaluation): the optimiser pattern gives the same bits with and without it
     assert val["incremental"].split()[0] == "1", val["incremental"]
+    assert val["round4"].split()[0] == "1", val["round4"]  # setSmallEval on / off and evaluatePoses: the same bits
     # the same program, unchanged, over a default group of two ranks (ECC_HIP_DEVICES; both on device 0 here): evaluate()
     # is sharded inside the library, everything else is served by rank 0
     out2 = subprocess.run([exe, ipath, str(n), str(s["n_u"]), str(s["n_v"]), str(s["n_alpha"]), str(s["n_t"]), ppath],

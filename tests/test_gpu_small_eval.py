@@ -181,7 +181,7 @@ def test_poses_two_deep_are_the_one_by_one_values(gpu_ctx):
     to setProjectionMatrices + evaluate per pose, at sizes that take the one-stream and the two-stream refit, with reuse
     off, and in the pose-delta mode (which evaluates them one at a time)."""
     import epipolarconsistency_amd as E
-    for n, B in ((20, 48), (150, 32)):  # 190 pairs / 11 175 pairs (two-stream record reuse)
+    for n, B in ((5, 48), (20, 48), (150, 32)):  # 10 / 190 pairs (one at a time: the one-launch path's sizes), 11 175 pairs (two-stream reuse)
         Ps, base, dtrs = _scan(gpu_ctx, n, B=B)
         P0 = E.pack_projection_matrices(Ps)
         poses = []
