@@ -18,7 +18,7 @@ make -s -C oracle asan || fail=1
 ASAN_RT=$(gcc -print-file-name=libasan.so)
 LD_PRELOAD=$ASAN_RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   ECC_ORACLE_LIB=$PWD/oracle/libecc_oracle_asan.so OMP_NUM_THREADS=4 \
-  python -m pytest tests/test_oracle_pins.py tests/test_oracle_properties.py tests/test_oracle_independent.py tests/test_golden.py -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4
+  python -m pytest tests/test_oracle_pins.py tests/test_oracle_properties.py tests/test_oracle_independent.py tests/test_oracle_radon_contract.py tests/test_golden.py -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -4
 [ ${PIPESTATUS[0]} -eq 0 ] || fail=1
 
 echo; echo "== 2. ecc_exchange.cpp: -fsanitize=thread (tests/c/tsan_exchange.cpp)"
