@@ -63,6 +63,7 @@ struct EccRadonParams {
 // 11 coefficients each plus a low part of the constant term (the constant is ~n/2 bins; its float rounding alone
 // would shift a whole curve by up to 1.5e-5 bins).
 #define ECC_SKIP_WORDS 16
+#define ECC_PAIRS_SPLIT_MAX 4096  // launches up to here: several waves per pair (pairs_split_kernel)
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
 
@@ -141,16 +142,15 @@ struct EccPairParams {
 };
 
 // ---- one-launch evaluation of small pair sets (small_eval_kernel.hip) ---------------------------
-// Where the one launch beats the stream-ordered launches (measured on one MI355X, us per setProjectionMatrices + evaluate):
-// all pairs of n views at 512^2 (724 samples per pair) 1 pair 22.9 against 27.6, 28 pairs 25.6 / 28.7, 190 pairs 29.5 / 27.8,
-// 528 pairs 38 / 28.5, 2016 pairs 66 / 31 (every value is a PCIe write of its own, every workgroup costs the dispatcher
-// 11 ns); index lists on 400 views at 1024^2 (1448 samples per pair: four waves per pair pay more) 1 pair 26 / 29, 399
-// pairs 34 / 36, 512 pairs 35 / 46.  Hence a bound that grows with the samples per pair (k_limit / 2: the launch bound on the
-// kappa index is twice the number of samples, ref: ...RadonIntermediate.cu:320,349): 192 pairs at 724 samples, 576 at 1448,
-// at least 64, at most ECC_SMALL_EVAL_MAX_PAIRS.
-#define ECC_SMALL_EVAL_MAX_PAIRS 1024
-#define ECC_SMALL_EVAL_PAIR_BOUND(k_limit) \
-    ((((k_limit) / 2 - 384) / 2) < 64 ? 64 : ((((k_limit) / 2 - 384) / 2) > ECC_SMALL_EVAL_MAX_PAIRS ? ECC_SMALL_EVAL_MAX_PAIRS : (((k_limit) / 2 - 384) / 2)))
+// Where the one launch beats the stream-ordered launches (measured on one MI355X, us per setProjectionMatrices + evaluate,
+// Python caller; the stream-ordered path with pairs_split_kernel and pinned index lists, i.e. as it is at the end of round 4):
+// all pairs of n views at 512^2 (724 samples per pair): 1 pair 22.7 against 27.3, 28 pairs 25.1 / 28.0, 190 pairs 25.5 / 27.2,
+// 528 pairs 30.9 / 25.6; index lists on 400 views at 1024^2 (1448 samples per pair): 1 pair 26.1 / 27.4, 399 pairs 33-40 / 30.0,
+// 512 pairs 34.9 / 33.0.  (Every value of the one launch is a PCIe write of its own and every workgroup costs the dispatcher
+// 11 ns; before the split kernel and the pinned lists the stream-ordered path took 46 / 54 / 58 us for these lists and the
+// one launch won up to 576 pairs.)
+#define ECC_SMALL_EVAL_MAX_PAIRS 192
+#define ECC_SMALL_EVAL_PAIR_BOUND(k_limit) ECC_SMALL_EVAL_MAX_PAIRS
 #define ECC_SMALL_PATCH_MAX 16
 #define ECC_SMALL_MAGIC 0x45434353u
 struct EccSmallEval {

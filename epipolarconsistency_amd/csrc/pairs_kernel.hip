@@ -136,6 +136,50 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
     // fences per wave 3.15 ms: a cross-XCD release writes the L2 back.  The sum stays a 8-us kernel of its own.)
 }
 
+// Launches of at most ECC_PAIRS_SPLIT_MAX pairs (small all-pairs evaluations, shards of them, index lists, the moved view's
+// pairs of the pose-delta mode): one wave per pair leaves most SIMDs idle and the launch lasts as long as one wave's 12 - 23
+// dependent trips.  Here WPP = 4 or 2 waves share a pair: wave `sub` takes the 64-sample trips sub, sub + WPP, ... and
+// stores every sample's term in LDS; the pair's first wave then adds the terms per lane in the order ONE wave accumulates
+// them (k = lane, lane + 64, ... while kappa < kappa_max), so the value has pairs_kernel's bits
+// (tests/test_gpu_small_eval.py: the same pairs through both kernels).  Round 4, config 2 (2016 pairs): 16.9 -> ~7 us.
+template <bool DERIV, int WPP>
+__global__ __launch_bounds__(PK_THREADS) void pairs_split_kernel(EccPairParams p, int stage_stride)
+{
+    constexpr int PPW = 4 / WPP;  // pairs per workgroup
+    extern __shared__ float stage_all[];  // PPW * stage_stride floats
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = wave / WPP, sub = wave % WPP;  // wave-uniform
+    long long local = (long long)blockIdx.x * PPW + slot;
+    const bool live = local < p.count;
+    local = ((long long)__builtin_amdgcn_readfirstlane((int)(local >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)local);
+    double acc = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0;
+    const EccPairRecord* __restrict__ rec = nullptr;
+    float* stage = stage_all + (size_t)slot * stage_stride;
+    if (live) {
+        const long long rec_index = p.record_slots ? (long long)__builtin_amdgcn_readfirstlane(p.record_slots[local]) : local;
+        rec = p.records + rec_index;
+        const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
+        pair_accumulate<DERIV, false, WPP>(p, rec, iD0, iD1, lane, acc, m2, m3, m4, sub, stage);
+    }
+    __syncthreads();  // every wave of the pair has stored its trips
+    if (!live || sub != 0) return;
+    const float dkappa = uniformf(rec->K1[6]), kappa_max = uniformf(rec->K1[7]);
+    for (int k = lane; k < p.k_limit; k += 64) {
+        const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
+        if (kappa >= kappa_max) break;
+        acc += (double)stage[k];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) {
+        const float val = (float)acc;
+        if (p.pair_values) p.pair_values[p.value_slots ? (long long)p.value_slots[local] : local] = val;
+        if (p.cost && !p.indices) {
+            const int ci = rec->ci, cj = rec->cj;
+            p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
+        }
+    }
+}
+
 // Deterministic float64 sum of `count` pair values (single workgroup, fixed tree).
 // ref: ...RadonIntermediate.cpp:216-224 (host loop; weights are all 1).
 // values_host (optional, pinned and device-mapped): the kernel also hands the values themselves to the host -- every thread
@@ -434,6 +478,23 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
             else hipLaunchKernelGGL((pairs_reference_kernel<false, 1>), dim3((unsigned)nblk), dim3(PK_THREADS), 0, stream, *p);
         }
         return hipGetLastError();
+    }
+    if (!p->use_corr && !p->skip_enabled && p->count <= ECC_PAIRS_SPLIT_MAX) {
+        // few pairs: several waves per pair (pairs_split_kernel); four while that fits one round of resident waves
+        const int wpp = p->count <= 1792 ? 4 : 2;
+        const int stride = (p->k_limit + 63) & ~63;
+        const size_t lds = sizeof(float) * (size_t)(4 / wpp) * (size_t)stride;
+        if (lds <= 48 * 1024) {  // (a user-chosen dkappa with tens of thousands of samples per pair: the one-wave kernel)
+            const dim3 grid((unsigned)((p->count + (4 / wpp) - 1) / (4 / wpp))), block(PK_THREADS);
+            if (p->is_derivative) {
+                if (wpp == 4) hipLaunchKernelGGL((pairs_split_kernel<true, 4>), grid, block, lds, stream, *p, stride);
+                else hipLaunchKernelGGL((pairs_split_kernel<true, 2>), grid, block, lds, stream, *p, stride);
+            } else {
+                if (wpp == 4) hipLaunchKernelGGL((pairs_split_kernel<false, 4>), grid, block, lds, stream, *p, stride);
+                else hipLaunchKernelGGL((pairs_split_kernel<false, 2>), grid, block, lds, stream, *p, stride);
+            }
+            return hipGetLastError();
+        }
     }
     nblk = (p->count + PK_MAIN_WAVES - 1) / PK_MAIN_WAVES;
     long long per_xcd = (nblk + 7) / 8;

@@ -32,6 +32,7 @@
 // keeps the old path.
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <cstdlib>
 
 #include "ecc_layout.h"
 #include "ecc_pairs_device.h"
@@ -165,7 +166,9 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
 // evaluation cannot take this path (the caller falls back to the stream-ordered launches).
 extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds_bytes)
 {
-    if (p->count < 1 || p->count > ECC_SMALL_EVAL_PAIR_BOUND(p->k_limit) || p->use_corr || p->K01_out || p->record_slots || p->value_slots ||
+    static const long long forced_bound = [] { const char* e = std::getenv("ECC_SMALL_MAX_PAIRS"); return e ? std::atoll(e) : -1ll; }();  // experiments
+    const long long bound = forced_bound >= 0 ? forced_bound : ECC_SMALL_EVAL_PAIR_BOUND(p->k_limit);
+    if (p->count < 1 || p->count > bound || p->count > ECC_SMALL_EVAL_MAX_PAIRS || p->use_corr || p->K01_out || p->record_slots || p->value_slots ||
         p->patch_count || p->skip_enabled)
         return 0;
     if (p->reference_arithmetic) {

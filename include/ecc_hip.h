@@ -286,19 +286,19 @@ int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
  * 10 873-pair shard 63 us with, 77 us without); 2 = the two-stream form for every size (tests). */
 int ecc_metric_set_record_reuse(ecc_metric* m, int on);
 
-/* One launch per small evaluation (default on).  An evaluation of few pairs -- up to (samples per pair - 384) / 2, i.e. 192
- * pairs at 768 distance bins of a 512^2 image, 576 pairs at a 1024^2 image, at least 64: ecc_metric_evaluate_all of a few
- * views, small ecc_metric_evaluate_range shards, ecc_metric_evaluate_pairs index lists; not with use_corr, not the
+/* One launch per small evaluation (default on).  An evaluation of at most 192 pairs -- ecc_metric_evaluate_all of up to 20
+ * views, small ecc_metric_evaluate_range shards, short ecc_metric_evaluate_pairs index lists; not with use_corr, not the
  * asynchronous form -- runs as ONE kernel instead of the stream-ordered launches E1, K01, pairs, sum (the reference: two
  * kernels, two device-wide syncs and a host loop, ref: EpipolarConsistencyRadonIntermediate.cu:300-409,
  * ...RadonIntermediate.cpp:197-224; its working optimiser caller evaluates a handful of pairs per objective call, ref:
  * tools/FluoroTracking/FluoroTracking.cpp:179-211): E1 of the views whose matrix changed is computed on the host (the same
  * code, bit-identical) and travels in the kernel arguments, each workgroup fits its pair's record and samples it with four
  * waves, every value goes to the device array and -- at system scope -- to pinned host memory, the workgroup that arrives
- * last writes the word the host polls, and the host adds the values in the sum kernel's order.  Larger index lists keep the
- * stream-ordered launches but without copy commands (the list is read from pinned memory, the sum kernel hands the values
- * back).  Every value and every sum has the bits of the multi-launch path (tests/test_gpu_small_eval.py,
- * tests/test_gpu_stress_sequences.py); on = 0 keeps that path for everything. */
+ * last writes the word the host polls, and the host adds the values in the sum kernel's order.  Larger evaluations keep the
+ * stream-ordered launches, up to 4096 pairs with several waves per pair (pairs_split_kernel), index lists without copy
+ * commands (the list is read from pinned memory, the sum kernel hands the values back).  Every value and every sum has the
+ * bits of the multi-launch one-wave-per-pair path (tests/test_gpu_small_eval.py, tests/test_gpu_stress_sequences.py); on = 0
+ * keeps the stream-ordered launches for everything. */
 int ecc_metric_set_small_eval(ecc_metric* m, int on);
 /* ref: Metric::getObjectRadius (EpipolarConsistency.cpp:76-84): user value, or the estimate
  * from the FIRST projection matrix. */

@@ -203,3 +203,30 @@ def test_poses_two_deep_are_the_one_by_one_values(gpu_ctx):
             a.close(); b.close()
         for d in base:
             d.close()
+
+
+@pytest.mark.parametrize("mode", ["polynomial", "per_sample"])
+def test_split_kernel_has_the_one_wave_kernels_bits(gpu_ctx, mode):
+    """Launches of at most 4096 pairs sample a pair with 4 or 2 waves (pairs_split_kernel, LDS-ordered sums); larger launches
+    with one (pairs_kernel).  The same pairs through both -- all 4950 pairs of 100 views in one launch against index lists and
+    sub-ranges of 50 ... 4000 of them -- must give the same bits."""
+    import epipolarconsistency_amd as E
+    n = 100
+    Ps, base, dtrs = _scan(gpu_ctx, n, B=64, seed=11)
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling(mode).setSmallEval(False).setRecordReuse(False)
+    n_pairs = n * (n - 1) // 2
+    total, vals = m.evaluate_range(0, n_pairs, want_pairs=True)  # 4950 pairs: one wave per pair
+    assert np.isfinite(vals).all()
+    for first, count in ((0, 50), (17, 1500), (1000, 1792), (2000, 1793), (900, 4000), (4900, 50)):
+        s, v = m.evaluate_range(first, count, want_pairs=True)
+        assert np.array_equal(v, vals[first:first + count]), (mode, first, count)
+    rng = np.random.default_rng(1)
+    for L in (1, 77, 1792, 1793, 4096):
+        sel = np.sort(rng.choice(n_pairs, size=L, replace=False))
+        idx = np.array([(*E.get_ij(int(q), n), *E.get_ij(int(q), n)) for q in sel], np.int32)
+        out = np.empty(L, np.float32)
+        m.evaluate(idx, out)
+        assert np.array_equal(out, vals[sel]), (mode, L)
+    m.close()
+    for d in base:
+        d.close()
