@@ -64,6 +64,9 @@ struct EccRadonParams {
 // would shift a whole curve by up to 1.5e-5 bins).
 #define ECC_SKIP_WORDS 16
 #define ECC_PAIRS_SPLIT_MAX 4096  // launches up to here: several waves per pair (pairs_split_kernel)
+#ifndef ECC_PAIRS_SPLIT4_MAX
+#define ECC_PAIRS_SPLIT4_MAX 1792  // ... four of them up to here, two beyond
+#endif
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
 

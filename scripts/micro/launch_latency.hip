@@ -10,7 +10,7 @@ struct Big { unsigned long long* flag; unsigned* ticket; const int* host_list; i
 struct Small { unsigned long long* flag; unsigned* ticket; const int* host_list; int mode; int pad; };
 
 template <class A>
-__global__ __launch_bounds__(256) void k(A a, unsigned long long token)
+__global__ __launch_bounds__(1024) void k(A a, unsigned long long token)
 {
     extern __shared__ float lds[];
     // mode 0: block 0 stores the flag at once.  mode 1: last-arriver (ticket) stores it.  mode 2: every block first reads 16
@@ -37,7 +37,7 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 
 template <class A>
 double run(int grid, size_t lds, int mode, unsigned long long* flag_h, unsigned long long* flag_d, unsigned* ticket, const int* list_d,
-           hipStream_t s, int idle_us)
+           hipStream_t s, int idle_us, int threads = 256)
 {
     A a;
     std::memset(&a, 0, sizeof(a));
@@ -49,7 +49,7 @@ double run(int grid, size_t lds, int mode, unsigned long long* flag_h, unsigned 
         const double w = now();
         while (now() - w < idle_us * 1e-6) {}  // the host's share between two evaluations: the GPU idles
         const double t0 = now();
-        hipLaunchKernelGGL((k<A>), dim3(grid), dim3(256), lds, s, a, token);
+        hipLaunchKernelGGL((k<A>), dim3(grid), dim3(threads), lds, s, a, token);
         while (*(volatile unsigned long long*)flag_h != token) {}
         if (r >= 20) tot += now() - t0;
     }
@@ -73,5 +73,10 @@ int main()
                    run<Big>(grid, 6144, 2, flag_h, flag_d, ticket, list_d, s, idle));
         }
     }
+    printf("workgroup size at a fixed number of waves (ticket form, small arguments, no LDS):\n");
+    for (int waves : {1024, 4096, 8192, 16384})
+        printf("  %5d waves: 64 threads per workgroup %6.1f us | 256 %6.1f | 512 %6.1f | 1024 %6.1f\n", waves,
+               run<Small>(waves, 0, 1, flag_h, flag_d, ticket, list_d, s, 0, 64), run<Small>(waves / 4, 0, 1, flag_h, flag_d, ticket, list_d, s, 0, 256),
+               run<Small>(waves / 8, 0, 1, flag_h, flag_d, ticket, list_d, s, 0, 512), run<Small>(waves / 16, 0, 1, flag_h, flag_d, ticket, list_d, s, 0, 1024));
     return 0;
 }

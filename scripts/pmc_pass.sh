@@ -21,7 +21,7 @@ per=collections.defaultdict(float)   # a dispatch's counter can come in several 
 for r in rows:
     k=r["Kernel_Name"]
     if 2*grid(r) < gmax[k]: continue
-    m=re.search(r"(pairs_kernel<[\w, ]+>|small_eval_kernel<[\w, ]+>|k01_kernel<\d+>|k01_kernel|radon_kernel<[\w, ]+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w, ]+>)", k)
+    m=re.search(r"(pairs_split_kernel<[\w, ]+>|pairs_kernel<[\w, ]+>|small_eval_kernel<[\w, ]+>|k01_kernel<\d+>|k01_kernel|radon_kernel<[\w, ]+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess_kernel<[-\w, ]+>)", k)
     if m:
         per[(m.group(1), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

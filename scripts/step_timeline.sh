@@ -14,7 +14,7 @@ f = glob.glob("$out/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
-    for k in ("small_eval_kernel", "sum_pairs_split_kernel", "sum_pairs_kernel", "e1_kernel", "k01_kernel", "pairs_reference_kernel", "pairs_kernel"):
+    for k in ("small_eval_kernel", "sum_pairs_split_kernel", "sum_pairs_kernel", "e1_kernel", "k01_kernel", "pairs_reference_kernel", "pairs_split_kernel", "pairs_kernel"):
         if k in n: return k
     return None
 ours = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if short(r["Kernel_Name"])]

@@ -11,12 +11,12 @@ python3 - <<PY
 import csv, glob, re
 f = glob.glob("$out/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-ours = [r for r in rows if re.search(r"pairs_kernel|k01_kernel|sum_pairs|e1_kernel|small_eval", r["Kernel_Name"])]
+ours = [r for r in rows if re.search(r"pairs_kernel|pairs_split_kernel|k01_kernel|sum_pairs|e1_kernel|small_eval", r["Kernel_Name"])]
 sel = ours[$first:$first + $count]
 t0 = int(sel[0]["Start_Timestamp"]); prev = None
 for r in sel:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    m = re.search(r"(small_eval_kernel|k01_kernel<\d+>|pairs_reference_kernel|pairs_kernel|sum_pairs\w*|e1_kernel)", r["Kernel_Name"])
+    m = re.search(r"(small_eval_kernel|k01_kernel<\d+>|pairs_reference_kernel|pairs_split_kernel|pairs_kernel|sum_pairs\w*|e1_kernel)", r["Kernel_Name"])
     g = int(float(r.get("Grid_Size") or r.get("Grid_Size_X") or 0))
     print("%9.1f us  dur %7.1f  gap %7.1f  grid %8d  queue %s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev) / 1e3 if prev else 0, g, r.get("Queue_Id", "?"), m.group(1)))
     prev = e
