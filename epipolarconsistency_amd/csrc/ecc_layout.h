@@ -63,7 +63,9 @@ struct EccRadonParams {
 // 11 coefficients each plus a low part of the constant term (the constant is ~n/2 bins; its float rounding alone
 // would shift a whole curve by up to 1.5e-5 bins).
 #define ECC_SKIP_WORDS 16
+#ifndef ECC_PAIRS_SPLIT_MAX
 #define ECC_PAIRS_SPLIT_MAX 4096  // launches up to here: several waves per pair (pairs_split_kernel)
+#endif
 #ifndef ECC_PAIRS_SPLIT4_MAX
 #define ECC_PAIRS_SPLIT4_MAX 1792  // ... four of them up to here, two beyond
 #endif

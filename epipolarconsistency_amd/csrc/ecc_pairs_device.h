@@ -513,8 +513,19 @@ struct CurvePoint {
 // evaluated point made k01_kernel three times as long.)
 #define ECC_TRIG_STEP (3.14159265358979323846 / (2.0 * ECC_TRIG_STEPS))
 
+// The fit's tables as its code sees them: what is indexed per lane (the trig table, the nodes, the check abscissae) staged
+// in LDS by the workgroup (a dependent global load costs the fit's chain ~0.6 us each time, and there are five of them
+// in a row: theta_ref, a node's sin/cos, its angle, a check's sin/cos, its angle), the inverse Vandermonde matrices --
+// indexed by compile-time constants, i.e. scalar loads -- where they are.
+struct PolyT {
+    const EccPolyTables* g;
+    const double (*sc)[2];
+    const double* nodes;
+    const double* checks;
+};
+
 // sin and cos of t in [0, pi/2 + 1e-6]
-__device__ __forceinline__ void sincos_table(const EccPolyTables& T, double t, double& s, double& c)
+__device__ __forceinline__ void sincos_table(const PolyT& T, double t, double& s, double& c)
 {
     int k = (int)(t * (1.0 / ECC_TRIG_STEP) + 0.5);
     k = min(max(k, 0), ECC_TRIG_STEPS);  // (a NaN converts to 0)
@@ -528,7 +539,7 @@ __device__ __forceinline__ void sincos_table(const EccPolyTables& T, double t, d
 
 // Angle of the vector (x, y) in (-pi, pi]: crude float estimate -> rotation back by
 // the nearest table angle -> atan of the small remainder by its series; the reciprocal by two Newton steps.
-__device__ __forceinline__ double angle_table(const EccPolyTables& T, double x, double y)
+__device__ __forceinline__ double angle_table(const PolyT& T, double x, double y)
 {
     const float ax = fabsf((float)x), ay = fabsf((float)y);
     // angle of (|x|, |y|) in units of pi, [0, 1/2], good to 1.3e-3: atan(q) ~ q (pi/4 + 0.273 (1 - q)) on [0, 1] --
@@ -577,7 +588,7 @@ __device__ __forceinline__ void curve_geometry(const float* K, CurveGeom& g)
     g.k5 = K[5];
 }
 
-__device__ __forceinline__ double exact_angle_coord(const EccPolyTables& T, const CurveGeom& g, double c, double s, bool& fold,
+__device__ __forceinline__ double exact_angle_coord(const PolyT& T, const CurveGeom& g, double c, double s, bool& fold,
                                                     bool& valid)
 {
     const double pi = 3.14159265358979323846, inv_Pi_f = 1.0 / (double)3.14159265359f;
@@ -616,7 +627,7 @@ __device__ __forceinline__ double exact_distance_coord(const CurveGeom& g, doubl
 // combinations fe, fo of the values at +-x_j); the node loop stays rolled: unrolled, the kernel spilled 150 scalar
 // registers and spent a fifth of its instructions moving constants.
 template <bool ANGLE>
-__device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, double km, bool& fold0, double* c)
+__device__ bool fit_coordinate(const PolyT& T, const CurveGeom& g, double km, bool& fold0, double* c)
 {
     constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
     bool ok = true;
@@ -640,16 +651,16 @@ __device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, doubl
         }
         const double fe = 0.5 * (fp + fm), fo = (fp - fm) * (0.5 / xj);
 #pragma unroll
-        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + j], fe, c[2 * k]);
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.g->Ae[k * (H + 1) + j], fe, c[2 * k]);
 #pragma unroll
-        for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.Ao[k * H + j], fo, c[2 * k + 1]);
+        for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.g->Ao[k * H + j], fo, c[2 * k + 1]);
     }
     {   // the centre node, kappa = 0
         bool f1 = false, v1 = true;
         const double f0 = ANGLE ? exact_angle_coord(T, g, 1.0, 0.0, f1, v1) : exact_distance_coord(g, 1.0, 0.0, false);
         if (ANGLE) ok = ok && v1 && f1 == fold0;
 #pragma unroll
-        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + H], f0, c[2 * k]);
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.g->Ae[k * (H + 1) + H], f0, c[2 * k]);
     }
     // the check measures the interpolation error (float64 coefficients); the float rounding of the
     // coefficients is evaluation noise of the same kind as the exact path's own fp32 rounding
@@ -675,7 +686,7 @@ __device__ bool fit_coordinate(const EccPolyTables& T, const CurveGeom& g, doubl
 // lane accumulates the coefficients in the order fit_coordinate does (j = 0 .. H-1, then the centre), so c -- and with it
 // every pair value -- is bit-identical to the one-thread fit; check q runs on lane q.  The verdict is the AND over the group.
 template <bool ANGLE, int LANES>
-__device__ bool fit_coordinate_wide(const EccPolyTables& T, const CurveGeom& g, double km, bool& fold0, double* c, int j)
+__device__ bool fit_coordinate_wide(const PolyT& T, const CurveGeom& g, double km, bool& fold0, double* c, int j)
 {
     constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
     static_assert(LANES >= H + 1 && LANES >= ECC_POLY_CHECKS && (LANES & (LANES - 1)) == 0, "one lane per node and per check");
@@ -711,14 +722,14 @@ __device__ bool fit_coordinate_wide(const EccPolyTables& T, const CurveGeom& g, 
     for (int jj = 0; jj < H; ++jj) {
         const double fej = __shfl(fe, base + jj), foj = __shfl(fo, base + jj);
 #pragma unroll
-        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + jj], fej, c[2 * k]);
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.g->Ae[k * (H + 1) + jj], fej, c[2 * k]);
 #pragma unroll
-        for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.Ao[k * H + jj], foj, c[2 * k + 1]);
+        for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.g->Ao[k * H + jj], foj, c[2 * k + 1]);
     }
     {
         const double f0 = __shfl(fe, base + H);
 #pragma unroll
-        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.Ae[k * (H + 1) + H], f0, c[2 * k]);
+        for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.g->Ae[k * (H + 1) + H], f0, c[2 * k]);
     }
     if (j < ECC_POLY_CHECKS) {
         const double x = T.checks[j];
@@ -774,6 +785,10 @@ template <int LANES>
 struct K01Shared {
     EccPairRecord recs[64 / LANES];
     int ok_flags[4][64 / LANES];
+    // the per-lane-indexed tables of the fit (PolyT)
+    double sc[ECC_TRIG_STEPS + 1][2];
+    double nodes[ECC_POLY_DEG + 1];
+    double checks[ECC_POLY_CHECKS];
 };
 
 // The records of the pairs blk_first + slot, slot < min(live_slots, 64 / LANES), of the launch p, assembled in sh.recs
@@ -793,6 +808,13 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
     const bool angle_role = role < 2;
     const long long local = blk_first + slot;
     const bool live = slot < live_slots && local < p.count;
+    if (p.poly) {  // uniform over the launch: stage the tables (complete at the barrier in front of the fit)
+        constexpr int N_SC = 2 * (ECC_TRIG_STEPS + 1);
+        const int q = threadIdx.x;
+        if (q < N_SC) (&sh.sc[0][0])[q] = (&p.poly->sc[0][0])[q];
+        else if (q < N_SC + ECC_POLY_DEG + 1) sh.nodes[q - N_SC] = p.poly->nodes[q - N_SC];
+        else if (q < N_SC + ECC_POLY_DEG + 1 + ECC_POLY_CHECKS) sh.checks[q - N_SC - ECC_POLY_DEG - 1] = p.poly->checks[q - N_SC - ECC_POLY_DEG - 1];
+    }
     int iP0 = 0, iP1 = 0, iD0 = 0, iD1 = 0, ci = 0, cj = 0;
     if (live) {
         if (idx_lds) {
@@ -868,16 +890,18 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
     double c[N];
     bool fold0 = false;
     int ok = 0;
+    if (p.poly) __syncthreads();  // the staged tables are complete (uniform over the launch)
+    const PolyT T = {p.poly, sh.sc, sh.nodes, sh.checks};
     if (live && p.poly && kappa_max > 0.f && dkappa > 0.f) {
         CurveGeom g;
-        g.theta_ref = angle_role ? angle_table(*p.poly, (double)Kv[0], (double)Kv[1]) : 0.0;
+        g.theta_ref = angle_role ? angle_table(T, (double)Kv[0], (double)Kv[1]) : 0.0;
         g.inv_range_t = 1.0 / (double)p.range_t;
         g.n_alpha = (double)p.n_alpha;
         g.n_t = (double)p.n_t;
         curve_geometry(Kv, g);
         if (LANES == 1) {
-            if (angle_role) ok = fit_coordinate<true>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;  // wave-uniform branch
-            else ok = fit_coordinate<false>(*p.poly, g, (double)kappa_max, fold0, c) ? 1 : 0;
+            if (angle_role) ok = fit_coordinate<true>(T, g, (double)kappa_max, fold0, c) ? 1 : 0;  // wave-uniform branch
+            else ok = fit_coordinate<false>(T, g, (double)kappa_max, fold0, c) ? 1 : 0;
         }
     } else {
 #pragma unroll
@@ -888,14 +912,13 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         // the same for all its lanes) discards the result
         const bool fit = live && kappa_max > 0.f && dkappa > 0.f;
         CurveGeom g;
-        g.theta_ref = (fit && angle_role) ? angle_table(*p.poly, (double)Kv[0], (double)Kv[1]) : 0.0;
+        g.theta_ref = (fit && angle_role) ? angle_table(T, (double)Kv[0], (double)Kv[1]) : 0.0;
         g.inv_range_t = 1.0 / (double)p.range_t;
         g.n_alpha = (double)p.n_alpha;
         g.n_t = (double)p.n_t;
         curve_geometry(Kv, g);
         double cw[N];
         bool fw = false;
-        const EccPolyTables& T = *p.poly;
         const bool okw = angle_role ? fit_coordinate_wide<true, LANES>(T, g, fit ? (double)kappa_max : 0.0, fw, cw, jl)
                                     : fit_coordinate_wide<false, LANES>(T, g, fit ? (double)kappa_max : 0.0, fw, cw, jl);
         if (fit) {
