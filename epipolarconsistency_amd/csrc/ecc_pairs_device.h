@@ -440,8 +440,15 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
     }
     const float xs = uniformf(rec->x_scale);
     const float xa_max = n_alpha_f + 0.5f;  // padded texel units: row n_alpha of the paired copy is the last one
-    for (int k = lane + 64 * sub; k < k_limit; k += 64 * WPP) {
-        const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
+    // Round 4, -5 of 135 vector instructions per trip, the same bits: (i) the sample index as a float carried along (k < 2^24:
+    // exact) instead of a conversion per trip; (ii) the folds' signs.  With the derivative filter a sample is s_v * a_v, s_v = -1
+    // where view v's line is folded, both toggled together on the -kappa side; only the RELATIVE sign survives the square:
+    // (s0 a0 - s1 a1)^2 = (a0 - s0 s1 a1)^2, and rounding is sign-symmetric -- so the four sign flips per trip become the sign
+    // of one wave-uniform factor in the two differences (fma(a1, -+1, a0) is the rounded a0 -+ a1).
+    const float rel_sign = (DERIV && ((fold[0] ^ fold[1]) & 0x80000000u)) ? 1.0f : -1.0f;
+    float kf = (float)(lane + 64 * sub);
+    for (int k = lane + 64 * sub; k < k_limit; k += 64 * WPP, kf += (float)(64 * WPP)) {
+        const float kappa = dkappa * 0.5f + dkappa * kf;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
         if (kappa >= kappa_max) break;
         const float x = kappa * xs, z = x * x;
         float xa0p, xa0m, yd0p, yd0m, xa1p, xa1m, yd1p, yd1m;
@@ -449,12 +456,13 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         poly_pm<DEG>(cd[0], cd[0][ECC_POLY_DEG + 1], 0.f, true, x, z, yd0p, yd0m);
         poly_pm<DEG>(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa1p, xa1m);
         poly_pm<DEG>(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd1p, yd1m);
-        const float v0p = sample_at<DERIV, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f, xa_max);
-        const float v1p = sample_at<DERIV, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f, xa_max);
-        const float v0m = sample_at<DERIV, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f, xa_max);
-        const float v1m = sample_at<DERIV, PITCH4>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f, xa_max);
+        // (CORR keeps the signed samples: the cross moment sees the signs)
+        const float v0p = sample_at<DERIV && CORR, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f, xa_max);
+        const float v1p = sample_at<DERIV && CORR, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f, xa_max);
+        const float v0m = sample_at<DERIV && CORR, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f, xa_max);
+        const float v1m = sample_at<DERIV && CORR, PITCH4>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f, xa_max);
         if (!CORR) {
-            const float vp = v0p - v1p, vm = v0m - v1m;
+            const float vp = fmaf(v1p, rel_sign, v0p), vm = fmaf(v1m, rel_sign, v0m);
             const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
             if (WPP == 1) acc += (double)(consistency * dkappa);  // ref: ...RadonIntermediate.cu:269
             else stage[k] = consistency * dkappa;
