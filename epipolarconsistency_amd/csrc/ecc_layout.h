@@ -156,6 +156,11 @@ struct EccPairParams {
 // one launch won up to 576 pairs.)
 #define ECC_SMALL_EVAL_MAX_PAIRS 192
 #define ECC_SMALL_EVAL_PAIR_BOUND(k_limit) ECC_SMALL_EVAL_MAX_PAIRS
+// ECC_SAMPLING_REFERENCE launches of at most this many pairs use 1024 threads per pair (pairs_reference_wide_kernel, and the
+// one-launch form of small_eval_kernel.hip): two such workgroups per CU hold them all at once.  Same bits either way.
+#ifndef ECC_REFERENCE_WIDE_MAX_PAIRS
+#define ECC_REFERENCE_WIDE_MAX_PAIRS 512
+#endif
 #define ECC_SMALL_PATCH_MAX 16
 #define ECC_SMALL_MAGIC 0x45434353u
 struct EccSmallEval {

@@ -800,7 +800,9 @@ struct K01Shared {
 };
 
 // The records of the pairs blk_first + slot, slot < min(live_slots, 64 / LANES), of the launch p, assembled in sh.recs
-// (LDS).  Called by all 256 threads of a workgroup; ends with a barrier (the records are complete for everybody).
+// (LDS).  Called by all threads of a workgroup; the first 256 are its members (member: wave-uniform; workgroups of more
+// threads pass false for the others, which only take part in the barriers); ends with a barrier (the records are complete
+// for everybody).
 // small (small_eval_kernel.hip): the index tuples of the workgroup's pairs come from idx_lds (4 ints per slot, read from
 // the caller's list once per workgroup) and the geometry of the few views whose matrix changed from the kernel arguments
 // (small->patch_*); workgroup 0 copies those entries into the device arrays, which no thread reads for a patched view.
@@ -809,14 +811,14 @@ struct K01Shared {
 typedef const EccSmallEval __attribute__((address_space(4))) * EccSmallEvalArg;
 template <int LANES>
 __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long blk_first, int live_slots, K01Shared<LANES>& sh,
-                                              EccSmallEvalArg small = nullptr, const int32_t* idx_lds = nullptr)
+                                              EccSmallEvalArg small = nullptr, const int32_t* idx_lds = nullptr, const bool member = true)
 {
     constexpr int N = ECC_POLY_DEG + 1;
-    const int role = threadIdx.x >> 6, v = role & 1, slot = (threadIdx.x & 63) / LANES, jl = threadIdx.x & (LANES - 1);
+    const int role = (threadIdx.x >> 6) & 3, v = role & 1, slot = (threadIdx.x & 63) / LANES, jl = threadIdx.x & (LANES - 1);
     const bool angle_role = role < 2;
     const long long local = blk_first + slot;
-    const bool live = slot < live_slots && local < p.count;
-    if (p.poly) {  // uniform over the launch: stage the tables (complete at the barrier in front of the fit)
+    const bool live = member && slot < live_slots && local < p.count;
+    if (p.poly && member) {  // p.poly: uniform over the launch: stage the tables (complete at the barrier in front of the fit)
         constexpr int N_SC = 2 * (ECC_TRIG_STEPS + 1);
         const int q = threadIdx.x;
         if (q < N_SC) (&sh.sc[0][0])[q] = (&p.poly->sc[0][0])[q];
@@ -844,14 +846,14 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
     // Record reuse: views whose matrix changed since the kept records were made come from the host's patch list (the
     // same E1 arithmetic, ecc_host_geometry.h); workgroup 0 also copies the list into the device arrays, which no
     // thread of this launch reads for a patched view.
-    if (p.patch_count > 0 && blockIdx.x == 0)
+    if (p.patch_count > 0 && blockIdx.x == 0 && member)
         for (int q = threadIdx.x; q < 16 * p.patch_count; q += 256) {
             const int e = q >> 4, w = q & 15, view = p.patch_views[e];
             const float val = p.patch_geo[q];
             if (w < 12) const_cast<float*>(p.PinvTs)[12 * view + w] = val;
             else const_cast<float*>(p.Cs)[4 * view + (w - 12)] = val;
         }
-    if (small && small->patch_count > 0 && blockIdx.x == 0)
+    if (small && small->patch_count > 0 && blockIdx.x == 0 && member)
         for (int q = threadIdx.x; q < 16 * small->patch_count; q += 256) {
             const int e = q >> 4, w = q & 15, view = small->patch_views[e];
             const float val = small->patch_geo[e][w];
@@ -915,7 +917,7 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
 #pragma unroll
         for (int k = 0; k < N; ++k) c[k] = 0.0;
     }
-    if constexpr (LANES > 1) if (p.poly) {  // uniform over the launch
+    if constexpr (LANES > 1) if (p.poly && member) {  // p.poly: uniform over the launch
         // every lane takes part in the exchanges of the wide fit; a group without a fit (dead slot, empty kappa range --
         // the same for all its lanes) discards the result
         const bool fit = live && kappa_max > 0.f && dkappa > 0.f;
@@ -937,7 +939,7 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         }
     }
     if (ok) ok = economise(c, (double)p.economise_tol);
-    const bool writer = jl == 0;  // LANES > 1: the lanes of a group hold identical results
+    const bool writer = member && jl == 0;  // LANES > 1: the lanes of a group hold identical results
     if (writer) sh.ok_flags[role][slot] = ok;
     if (angle_role && writer) {
         r->fold[v] = fold0 ? 0x80000000u : 0u;
@@ -1106,18 +1108,24 @@ __device__ float sample_line_plain(const float* K, float x0, float x1, GlobalFlo
 // (oracle/ecc_oracle.c or_pair / or_redundancy, i.e. ref: ...RadonIntermediate.cu:87-113,257-270 +
 // EpipolarConsistencyCommon.hxx:152-171 as fp32 source expressions, sin / cos / atan2 through binary64 and rounded once,
 // exact fp32 bilinear rule with index clamps on the dtr's own slab); float64 partial sums of this thread.
-template <bool CORR>
+// STAGE: every sample's fp32 term(s) go to stage[k] (CORR: stage[k], stage[stage_stride + k], stage[2 * stage_stride + k])
+// instead of into the sums -- the wide forms (1024 threads per pair) add them afterwards with reference_resum in the
+// order of a 256-thread workgroup.
+template <bool CORR, bool STAGE = false>
 __device__ __forceinline__ void reference_loop(const EccPairParams& p, const float (&K0)[8], const float (&K1)[8],
                                                GlobalFloats d0, GlobalFloats d1, int first_k, int stride,
-                                               double& acc, double& mom2, double& mom3, double& mom4)
+                                               double& acc, double& mom2, double& mom3, double& mom4,
+                                               float* stage = nullptr, int stage_stride = 0)
 {
     const float dkappa = K1[6], kappa_max = K1[7];
     const bool deriv = p.is_derivative != 0;
     for (int k = first_k; k < p.k_limit; k += stride) {
         const float kappa = dkappa * 0.5f + dkappa * k;  // ref: ...RadonIntermediate.cu:259
         if (kappa >= kappa_max) break;
-        float x0 = (float)cos((double)kappa);
-        const float x1 = (float)sin((double)kappa);
+        double sk, ck;
+        sincos((double)kappa, &sk, &ck);  // the bits of sin() and cos(): one argument reduction, one pair of polynomials
+        float x0 = (float)ck;
+        const float x1 = (float)sk;
         float a, d;
         const float v0p = sample_line_plain(K0, x0, x1, d0, p.pitch, p.n_alpha, p.n_t, p.range_t, deriv, &a, &d);
         const float v1p = sample_line_plain(K1, x0, x1, d1, p.pitch, p.n_alpha, p.n_t, p.range_t, deriv, &a, &d);
@@ -1127,12 +1135,41 @@ __device__ __forceinline__ void reference_loop(const EccPairParams& p, const flo
         if (!CORR) {
             const float vp = v0p - v1p, vm = v0m - v1m;
             const float consistency = (vp * vp + vm * vm) * K0[6];  // ref: ...RadonIntermediate.cu:112
-            acc += (double)(consistency * dkappa);                  // ref: ...RadonIntermediate.cu:269
+            const float term = consistency * dkappa;                // ref: ...RadonIntermediate.cu:269
+            if (STAGE) stage[k] = term;
+            else acc += (double)term;
         } else {
             const float one_over_n = kappa_max / kappa;  // ref: ...RadonIntermediate.cu:211,274
-            mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
-            mom3 += (double)(one_over_n * (v1p * v1p + v1m * v1m));
-            mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
+            const float t2 = one_over_n * (v0p * v0p + v0m * v0m), t3 = one_over_n * (v1p * v1p + v1m * v1m);
+            const float t4 = one_over_n * (v0p * v1p + v0m * v1m);
+            if (STAGE) {
+                stage[k] = t2;
+                stage[stage_stride + k] = t3;
+                stage[2 * stage_stride + k] = t4;
+            } else {
+                mom2 += (double)t2;
+                mom3 += (double)t3;
+                mom4 += (double)t4;
+            }
+        }
+    }
+}
+
+// The staged terms of reference_loop<CORR, true>, added the way thread T of a 256-thread workgroup accumulates them
+// (k = T, T + 256, ... while kappa < kappa_max): the bits of pairs_reference_kernel<CORR, 4>'s per-thread sums.
+template <bool CORR>
+__device__ __forceinline__ void reference_resum(const EccPairParams& p, float dkappa, float kappa_max, int T, const float* stage,
+                                                int stage_stride, double& acc, double& mom2, double& mom3, double& mom4)
+{
+    for (int k = T; k < p.k_limit; k += 256) {
+        const float kappa = dkappa * 0.5f + dkappa * k;  // the fp32 operations of reference_loop
+        if (kappa >= kappa_max) break;
+        if (!CORR) {
+            acc += (double)stage[k];
+        } else {
+            mom2 += (double)stage[k];
+            mom3 += (double)stage[stage_stride + k];
+            mom4 += (double)stage[2 * stage_stride + k];
         }
     }
 }

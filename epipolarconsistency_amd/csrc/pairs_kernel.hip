@@ -380,6 +380,76 @@ __global__ __launch_bounds__(PK_THREADS) void pairs_reference_kernel(EccPairPara
     }
 }
 
+// The wide form of pairs_reference_kernel<CORR, 4> for launches that leave most of the chip idle (at most
+// ECC_REFERENCE_WIDE_MAX_PAIRS pairs: two such workgroups per CU hold them all at once): 1024 threads share ONE pair, thread
+// T takes k = T, T + 1024, ... and stores each sample's fp32 term(s) in LDS; the first 256 threads then add them in the
+// order of the 256-thread kernel (thread T: k = T, T + 256, ...; wave sums in wave order), so every pair value has its
+// bits.  The binary64 sin / cos / atan2 chains of a sample are a few hundred dependent instructions: at one wave per SIMD
+// they run at a quarter of the issue rate, and a pair's 1448 samples took six trips per thread instead of two.
+#define ECC_REFERENCE_WIDE_THREADS 1024
+template <bool CORR>
+__global__ __launch_bounds__(ECC_REFERENCE_WIDE_THREADS) void pairs_reference_wide_kernel(EccPairParams p, int stage_stride)
+{
+    extern __shared__ float ref_stage[];  // (CORR ? 3 : 1) * stage_stride floats
+    __shared__ double part[3][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long local = (long long)blockIdx.x;  // < p.count by the launch
+    const EccPairRecord* __restrict__ rec = p.records + local;
+    float K0[8], K1[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        K0[i] = uniformf(rec->K0[i]);
+        K1[i] = uniformf(rec->K1[i]);
+    }
+    const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
+    const int ci = __builtin_amdgcn_readfirstlane(rec->ci), cj = __builtin_amdgcn_readfirstlane(rec->cj);
+    double acc = 0.0, mom2 = 0.0, mom3 = 0.0, mom4 = 0.0;
+    reference_loop<CORR, true>(p, K0, K1, (GlobalFloats)p.slabs[iD0], (GlobalFloats)p.slabs[iD1], (int)threadIdx.x,
+                               ECC_REFERENCE_WIDE_THREADS, acc, mom2, mom3, mom4, ref_stage, stage_stride);
+    __syncthreads();
+    if (wave < 4) {  // wave-uniform
+        reference_resum<CORR>(p, K1[6], K1[7], (int)threadIdx.x, ref_stage, stage_stride, acc, mom2, mom3, mom4);
+        if (!CORR) {
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        } else {
+            for (int off = 32; off > 0; off >>= 1) {
+                mom2 += __shfl_down(mom2, off);
+                mom3 += __shfl_down(mom3, off);
+                mom4 += __shfl_down(mom4, off);
+            }
+        }
+        if (lane == 0) {
+            part[0][wave] = CORR ? mom2 : acc;
+            part[1][wave] = mom3;
+            part[2][wave] = mom4;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    acc = mom2 = part[0][0];
+    mom3 = part[1][0];
+    mom4 = part[2][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        acc += part[0][w];
+        mom2 += part[0][w];
+        mom3 += part[1][w];
+        mom4 += part[2][w];
+    }
+    float val;
+    if (!CORR) {
+        val = (float)acc;
+    } else {
+        const float xx = (float)mom2, yy = (float)mom3, xy = (float)mom4;
+        const float corr = (float)((double)xy / (sqrt((double)xx) * sqrt((double)yy)));
+        val = (1.0f - corr) * 1.0f;
+    }
+    if (lane == 0) {
+        if (p.pair_values) p.pair_values[p.value_slots ? (long long)p.value_slots[local] : local] = val;
+        if (p.cost && !p.indices) p.cost[(size_t)ci + (size_t)cj * p.n_views] = val;
+    }
+}
+
 }  // namespace
 
 extern "C" hipError_t ecc_launch_pair_samples(const EccPairSamplesParams* p, hipStream_t stream)
@@ -470,7 +540,14 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
     if (p->count <= 0) return hipSuccess;
     long long nblk = (p->count + 3) / 4;
     if (p->reference_arithmetic) {
-        if (p->reference_split > 1) {
+        const int stride = (p->k_limit + 63) & ~63;
+        const size_t wide_lds = sizeof(float) * (size_t)stride * (p->use_corr ? 3u : 1u);
+        if (p->reference_split > 1 && p->count <= ECC_REFERENCE_WIDE_MAX_PAIRS && wide_lds <= 48 * 1024) {
+            // the same bits from 1024 threads per pair (see pairs_reference_wide_kernel)
+            const dim3 grid((unsigned)p->count), block(ECC_REFERENCE_WIDE_THREADS);
+            if (p->use_corr) hipLaunchKernelGGL((pairs_reference_wide_kernel<true>), grid, block, wide_lds, stream, *p, stride);
+            else hipLaunchKernelGGL((pairs_reference_wide_kernel<false>), grid, block, wide_lds, stream, *p, stride);
+        } else if (p->reference_split > 1) {
             if (p->use_corr) hipLaunchKernelGGL((pairs_reference_kernel<true, 4>), dim3((unsigned)p->count), dim3(PK_THREADS), 0, stream, *p);
             else hipLaunchKernelGGL((pairs_reference_kernel<false, 4>), dim3((unsigned)p->count), dim3(PK_THREADS), 0, stream, *p);
         } else {

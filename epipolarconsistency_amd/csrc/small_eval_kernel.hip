@@ -20,7 +20,9 @@
 //     `sub` takes the 64-sample trips sub, sub + WPP, ... and stores every sample's term in LDS; the pair's first wave
 //     then adds the terms per lane in the order ONE wave accumulates them (k = lane, lane + 64, ...), so the pair value has
 //     the bits of pairs_kernel's.  The reference arithmetic keeps its own grouping (thread T: k = T, T + 256, ...; wave
-//     sums in wave order), which is what pairs_reference_kernel<.., 4> does for the same evaluation sizes;
+//     sums in wave order), which is what pairs_reference_kernel<.., 4> does for the same evaluation sizes -- from 1024
+//     threads per pair (pairs_reference_wide_kernel's scheme: terms staged in LDS, added by the first 256 threads in that
+//     order; the records are made by the first four waves);
 //   * phase C: each value goes to the device array (plain store) and, at system scope, into pinned host memory; the
 //     workgroup drains its stores and takes a ticket, and the workgroup that arrives last writes a "done" word the host
 //     polls.  The HOST then adds the values in sum_pairs_kernel's order (the float4 layout of its 1024 threads, its shuffle
@@ -48,16 +50,18 @@ __device__ __forceinline__ void store_system(float* dst, float v)
     __hip_atomic_store(reinterpret_cast<unsigned*>(dst), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// WPP: waves per pair (4, 2, 1); REF: ECC_SAMPLING_REFERENCE (WPP = 4 only: the grouping of pairs_reference_kernel<.., 4>).
+// WPP: waves per pair (4, 2, 1); REF: ECC_SAMPLING_REFERENCE (one pair per workgroup of 1024 threads, WPP = 4 names the
+// grouping of pairs_reference_kernel<.., 4> its sums reproduce).
 #ifndef ECC_SMALL_MIN_WAVES
 #define ECC_SMALL_MIN_WAVES 4
 #endif
 template <bool DERIV, int WPP, bool REF>
-__global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(EccPairParams p, EccSmallEval x)
+__global__ __launch_bounds__(REF ? 1024 : 256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(EccPairParams p, EccSmallEval x)
 {
     constexpr int PPW = 4 / WPP;  // pairs per workgroup
     static_assert(!REF || WPP == 4, "reference arithmetic: one pair per workgroup");
-    extern __shared__ float stage_all[];  // WPP > 1, !REF: PPW * x.stage_stride floats
+    extern __shared__ float stage_all[];  // WPP > 1 or REF: PPW * x.stage_stride floats
+    const bool member = !REF || threadIdx.x < 256;  // wave-uniform: the threads that make the records
     __shared__ K01Shared<8> ks;
     __shared__ int32_t idx_lds[4 * PPW];
     __shared__ double part[4];
@@ -81,12 +85,12 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
     static_assert(alignof(EccSmallEval) == 8 && alignof(EccPairParams) == 8, "layout of the kernel arguments");
     const EccSmallEvalArg xs = (EccSmallEvalArg)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(EccPairParams) + 7) & ~(size_t)7));
     const bool args_ok = xs->magic == ECC_SMALL_MAGIC && x.magic == ECC_SMALL_MAGIC && xs->patch_count == x.patch_count;
-    k01_fit_block<8>(p, blk_first, PPW, ks, xs, p.indices ? idx_lds : nullptr);  // ends with a barrier
+    k01_fit_block<8>(p, blk_first, PPW, ks, xs, p.indices ? idx_lds : nullptr, member);  // ends with a barrier
 
     ECC_SMALL_STAMP(1);
     // ---- phase B ----
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = wave / WPP, sub = wave % WPP;  // wave-uniform
+    const int slot = REF ? 0 : wave / WPP, sub = REF ? wave : wave % WPP;  // wave-uniform
     const long long local = blk_first + slot;
     const bool live = local < p.count;
     const EccPairRecord* rec = &ks.recs[slot];
@@ -101,10 +105,15 @@ __global__ __launch_bounds__(256, ECC_SMALL_MIN_WAVES) void small_eval_kernel(Ec
                 K1[i] = uniformf(rec->K1[i]);
             }
             const int iD0 = __builtin_amdgcn_readfirstlane(rec->iD0), iD1 = __builtin_amdgcn_readfirstlane(rec->iD1);
-            reference_loop<false>(p, K0, K1, (GlobalFloats)p.slabs[iD0], (GlobalFloats)p.slabs[iD1], (int)threadIdx.x, 256, acc, m2, m3, m4);
+            reference_loop<false, true>(p, K0, K1, (GlobalFloats)p.slabs[iD0], (GlobalFloats)p.slabs[iD1], (int)threadIdx.x, 1024, acc,
+                                        m2, m3, m4, stage_all, x.stage_stride);
         }
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) part[wave] = acc;
+        __syncthreads();  // every sample's term is staged
+        if (wave < 4) {   // the sums of a 256-thread workgroup
+            if (live) reference_resum<false>(p, uniformf(rec->K1[6]), uniformf(rec->K1[7]), (int)threadIdx.x, stage_all, x.stage_stride, acc, m2, m3, m4);
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+            if (lane == 0) part[wave] = acc;
+        }
         __syncthreads();
         acc = part[0];
 #pragma unroll
@@ -173,8 +182,10 @@ extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds
         return 0;
     if (p->reference_arithmetic) {
         if (p->reference_split != 4) return 0;
+        const size_t ref_bytes = sizeof(float) * (size_t)((p->k_limit + 63) & ~63);
+        if (ref_bytes > 40 * 1024) return 0;
         *wpp = 4;
-        *lds_bytes = 0;
+        *lds_bytes = ref_bytes;
         return 1;
     }
     const int w = 4;  // waves per pair (the kernel has forms with 2 and 1 for larger launches: measured slower than the stream-ordered path there)
@@ -194,7 +205,7 @@ extern "C" hipError_t ecc_launch_small_eval(const EccPairParams* p, const EccSma
     xx.stage_stride = (p->k_limit + 63) & ~63;
     xx.magic = ECC_SMALL_MAGIC;
     const unsigned blocks = (unsigned)((p->count + (4 / wpp) - 1) / (4 / wpp));
-    const dim3 grid(blocks), block(256);
+    const dim3 grid(blocks), block(p->reference_arithmetic ? 1024 : 256);
 #define ECC_SMALL(D, W, R) hipLaunchKernelGGL((small_eval_kernel<D, W, R>), grid, block, lds, stream, *p, xx)
     if (p->reference_arithmetic) ECC_SMALL(true, 4, true);  // (the reference arithmetic takes is_derivative at run time)
     else if (p->is_derivative) ECC_SMALL(true, 4, false);

@@ -31,6 +31,26 @@ __global__ __launch_bounds__(256) void k(float* out, float a0, float b0)
         } else if (MODE == 5) {  // 8 cndmask + cmp
             x0 = x0 > b0 ? x1 : x2; x1 = x1 > b0 ? x2 : x3; x2 = x2 > b0 ? x3 : x4; x3 = x3 > b0 ? x4 : x5;
             x4 = x4 > b0 ? x5 : x6; x5 = x5 > b0 ? x6 : x7; x6 = x6 > b0 ? x7 : x0; x7 = x7 > b0 ? x0 : x1;
+        } else if (MODE == 7) {  // 8 fract (v_fract_f32) + add
+#define F(x) x = __builtin_amdgcn_fractf(x) + 1.5f
+            F(x0); F(x1); F(x2); F(x3); F(x4); F(x5); F(x6); F(x7);
+#undef F
+        } else if (MODE == 8) {  // 8 rndne + add
+#define F(x) x = __builtin_rintf(x) + .25f
+            F(x0); F(x1); F(x2); F(x3); F(x4); F(x5); F(x6); F(x7);
+#undef F
+        } else if (MODE == 9) {  // 8 trunc + add
+#define F(x) x = __builtin_truncf(x) + .25f
+            F(x0); F(x1); F(x2); F(x3); F(x4); F(x5); F(x6); F(x7);
+#undef F
+        } else if (MODE == 10) {  // 8 cvt_i32_f32 + cvt_f32_i32
+#define F(x) x = (float)((int)x + 1)
+            F(x0); F(x1); F(x2); F(x3); F(x4); F(x5); F(x6); F(x7);
+#undef F
+        } else if (MODE == 11) {  // 16 add (the reference for the +add of the modes above)
+#define F(x) x = (x + .25f) + b0
+            F(x0); F(x1); F(x2); F(x3); F(x4); F(x5); F(x6); F(x7);
+#undef F
         } else if (MODE == 6) {  // 8 f64 add
             double d0 = x0, d1 = x1; d0 += d1; d1 += d0; d0 += d1; d1 += d0; d0 += d1; d1 += d0; d0 += d1; d1 += d0;
             x0 = (float)d0; x1 = (float)d1;
@@ -61,5 +81,10 @@ int main()
     run<4>("8 x (v_floor + v_add)", out);
     run<5>("8 x (v_cmp + v_cndmask)", out);
     run<6>("8 x v_add_f64 (+cvt)", out);
+    run<7>("8 x (v_fract + v_add)", out);
+    run<8>("8 x (v_rndne + v_add)", out);
+    run<9>("8 x (v_trunc + v_add)", out);
+    run<10>("8 x (cvt_i32 + add + cvt_f32)", out);
+    run<11>("16 x v_add_f32", out);
     return 0;
 }
