@@ -16,7 +16,7 @@ for f in glob.glob("$out/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 acc = collections.defaultdict(list)
 for r in rows:
-    m = re.search(r"(pairs_split_kernel<[\w, ]+>|pairs_kernel<[\w, ]+>|pairs_reference_kernel<[\w, ]+>|small_eval_kernel<[\w, ]+>|k01_kernel<\d+>|radon_kernel<[\w, ]+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess\w*kernel(?:<[-\w, ]+>)?|ramp_kernel<[\w, ]+>|direct_\w+kernel)", r["Kernel_Name"])
+    m = re.search(r"(pairs_split_kernel<[\w, ]+>|pairs_kernel<[\w, ]+>|pairs_reference_kernel<[\w, ]+>|pairs_reference_wide_kernel<[\w, ]+>|small_eval_kernel<[\w, ]+>|k01_kernel<\d+>|radon_kernel<[\w, ]+>|sum_pairs\w*kernel|e1_kernel|dtr_border_kernel|preprocess\w*kernel(?:<[-\w, ]+>)?|ramp_kernel<[\w, ]+>|direct_\w+kernel)", r["Kernel_Name"])
     if not m: continue
     g = [int(float(r.get(k) or 1)) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")] if "Grid_Size_X" in r else [int(float(r.get("Grid_Size") or 0)), 1, 1]
     acc[(m.group(1), g[0] * g[1] * g[2])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -29,7 +29,7 @@ cat $R/gpurun_out/${tag}_kernel_stats.csv
 # rocprofv3's own --stats table (aggregated by name only), our kernels
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 head -1 "$f" > $R/gpurun_out/${tag}_kernel_stats_rocprofv3.csv
-grep -E "small_eval_kernel|pairs_kernel|pairs_reference_kernel|k01_kernel|radon_kernel|sum_pairs|e1_kernel|dtr_border|preprocess_kernel|ramp_kernel" "$f" >> $R/gpurun_out/${tag}_kernel_stats_rocprofv3.csv || true
+grep -E "small_eval_kernel|pairs_kernel|pairs_split_kernel|pairs_reference_kernel|pairs_reference_wide_kernel|k01_kernel|radon_kernel|sum_pairs|e1_kernel|dtr_border|preprocess_kernel|ramp_kernel" "$f" >> $R/gpurun_out/${tag}_kernel_stats_rocprofv3.csv || true
 rm -rf $out
 cd $R
 scripts/pmc_pass.sh ${tag}_fetch FETCH_SIZE
