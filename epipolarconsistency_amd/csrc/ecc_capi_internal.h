@@ -37,6 +37,7 @@ extern "C" hipError_t ecc_launch_build_paired(const float* const* slabs_tbl_d, f
 extern "C" hipError_t ecc_launch_build_quad(const float* const* slabs_tbl_d, float* quads_d, int64_t quad_stride_floats, int n,
                                             int rows, int pitch, hipStream_t stream);
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream);
+extern "C" hipError_t ecc_launch_k01_patched(const EccPairParams* p, const EccSmallEval* x, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
 extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds_bytes);
 extern "C" hipError_t ecc_launch_small_eval(const EccPairParams* p, const EccSmallEval* x, hipStream_t stream);
@@ -212,6 +213,7 @@ struct ecc_metric {
     bool reuse_ev_used[2] = {false, false};
     uint64_t reuse_gen = 0;
     std::vector<int> scratch_patched;
+    std::vector<int> scratch_stale;     // small_eval_patches: views whose geometry on the device is behind
     std::vector<int32_t> scratch_refs;
     std::vector<int32_t> scratch_patch_of;
     // second stream of the reuse path: refit + list launch of the changed pairs run there while the all-pairs launch

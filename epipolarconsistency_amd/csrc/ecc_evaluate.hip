@@ -187,6 +187,57 @@ hipError_t wait_sum(ecc_metric* m, double* sum)
     }
     return wait_result(m, m->ctx->stream, sum);
 }
+// E1 for a launch that takes it in its kernel arguments (small_eval_kernel, k01_patched_kernel): the views whose geometry on
+// the device is behind the current matrices go into x->patch_*, computed here with the code e1_kernel compiles
+// (ecc_host_geometry.h, bit-identical; ref: ...RadonIntermediate.cpp:134-163); more than ECC_SMALL_PATCH_MAX of them (the
+// first call, a new trajectory): e1_kernel, ordered before the launch, and x->patch_count stays 0.
+int small_eval_patches(ecc_metric* m, EccSmallEval* x)
+{
+    const int n = m->n_views;
+    const double* Pcur = m->Ps_h[m->set_generation & 1];
+    std::vector<int>& stale = m->scratch_stale;
+    stale.clear();
+    const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * (int64_t)n;
+    if (dev_known && m->e1_pending)
+        for (int v = 0; v < n && (int)stale.size() <= ECC_SMALL_PATCH_MAX; ++v)
+            if (std::memcmp(Pcur + 12 * v, m->dev_Ps.data() + 12 * v, sizeof(double) * 12) != 0) stale.push_back(v);
+    if (!dev_known || (int)stale.size() > ECC_SMALL_PATCH_MAX) return ensure_e1(m);
+    for (size_t e = 0; e < stale.size(); ++e) {
+        const int v = stale[e];
+        ecc_host::pinv_transpose(Pcur + 12 * v, x->patch_geo[e]);
+        ecc_host::source_position(Pcur + 12 * v, x->patch_geo[e] + 12);
+        x->patch_views[e] = v;
+        std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);  // workgroup 0 stores the entry
+    }
+    x->patch_count = (int)stale.size();
+    m->e1_pending = false;
+    return ECC_OK;
+}
+
+// k01 over p on the context's stream, E1 included: small launches (8 lanes per fit) of a metric with the one-launch path on
+// take E1 of up to ECC_SMALL_PATCH_MAX changed views in their kernel arguments (no e1_kernel launch in front, and
+// ecc_metric_set_projections does not launch it either); everything else is e1_kernel (if due) + k01_kernel.
+int launch_k01_with_e1(ecc_metric* m, const EccPairParams& p)
+{
+    if (m->small_eval && p.count > 0 && p.count <= ECC_K01_WIDE_MAX_PAIRS && !p.patch_count) {
+        EccSmallEval x;
+        std::memset(&x, 0, sizeof(x));
+        const int rc = small_eval_patches(m, &x);
+        if (rc) return rc;
+        m->eager_e1 = false;  // the views that change next are patched by the next launch
+        EccPairParams q = p;
+        q.PinvTs = m->PinvTs_d;
+        q.Cs = m->Cs_d;
+        if (x.patch_count > 0) HIP_TRY(ecc_launch_k01_patched(&q, &x, m->ctx->stream));
+        else HIP_TRY(ecc_launch_k01(&q, m->ctx->stream));
+        return ECC_OK;
+    }
+    const int rc = ensure_e1(m);
+    if (rc) return rc;
+    HIP_TRY(ecc_launch_k01(&p, m->ctx->stream));
+    return ECC_OK;
+}
+
 int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, bool* taken)
 {
     *taken = false;
@@ -195,35 +246,15 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, boo
     if (!m->small_eval || !ecc_small_eval_plan(&p, &wpp, &lds)) return ECC_OK;
 
     ecc_ctx* ctx = m->ctx;
-    const int n = m->n_views;
     if (!m->small_ticket_d) {
         HIP_TRY(hipMalloc((void**)&m->small_ticket_d, sizeof(unsigned)));
         HIP_TRY(hipMemsetAsync(m->small_ticket_d, 0, sizeof(unsigned), ctx->stream));
     }
     EccSmallEval x;
     std::memset(&x, 0, sizeof(x));
-    const int slot = (int)(m->set_generation & 1);
-    const double* Pcur = m->Ps_h[slot];
-    // views whose geometry on the device is behind the current matrices
-    std::vector<int>& stale = m->scratch_changed;
-    stale.clear();
-    const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * (int64_t)n;
-    if (dev_known && m->e1_pending)
-        for (int v = 0; v < n && (int)stale.size() <= ECC_SMALL_PATCH_MAX; ++v)
-            if (std::memcmp(Pcur + 12 * v, m->dev_Ps.data() + 12 * v, sizeof(double) * 12) != 0) stale.push_back(v);
-    if (!dev_known || (int)stale.size() > ECC_SMALL_PATCH_MAX) {
-        const int rc = ensure_e1(m);  // the first call, a new trajectory: e1_kernel, ordered before the launch below
-        if (rc) return rc;
-    } else {
-        for (size_t e = 0; e < stale.size(); ++e) {  // ref: ...RadonIntermediate.cpp:134-163
-            const int v = stale[e];
-            ecc_host::pinv_transpose(Pcur + 12 * v, x.patch_geo[e]);
-            ecc_host::source_position(Pcur + 12 * v, x.patch_geo[e] + 12);
-            x.patch_views[e] = v;
-            std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);  // workgroup 0 stores the entry
-        }
-        x.patch_count = (int)stale.size();
-        m->e1_pending = false;
+    {
+        const int rcp = small_eval_patches(m, &x);
+        if (rcp) return rcp;
     }
     p.PinvTs = m->PinvTs_d;
     p.Cs = m->Cs_d;
@@ -457,14 +488,13 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         }
     }
     if (!reused) {
-        rc = ensure_e1(m);
-        if (rc) return rc;
         // (Replaying the three launches below as an instantiated hipGraph was measured on ROCm 7.2: 6-9 us SLOWER per
         // evaluation than launching them on the stream, at 79 800 pairs and at a 9 975-pair shard.)
         // (Round 3: pipelining a full refit over the two streams -- first eighth of the range k01 -> pairs on the context's
         // stream, the rest k01 -> pairs on the side stream beside it -- was measured too: 0.392 against 0.370 ms per step;
         // two concurrent pair-kernel launches cost more than the hidden 23 us of k01_kernel.)
-        HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+        rc = launch_k01_with_e1(m, p);  // (E1 first: e1_kernel, or the changed views in k01's own arguments)
+        if (rc) return rc;
         if (m->record_reuse && !K01_d && count > 0) {
             m->rec_Ps.assign(Pcur, Pcur + 12 * n);
             m->rec_first = first;
@@ -552,7 +582,7 @@ int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, 
                 std::memcpy(m->list_h, idx.data(), sizeof(int32_t) * 4 * L);
                 std::memcpy(m->list_h + 4 * L, slots.data(), sizeof(int32_t) * L);
                 EccPairParams p;
-                rc = fill_pair_params(m, &p, n * (n - 1) / 2);  // the sampling mode of the full evaluation
+                rc = fill_pair_params(m, &p, n * (n - 1) / 2, /*need_e1=*/false);  // the sampling mode of the full evaluation
                 if (rc) return rc;
                 m->rec_valid = false;  // the list's records overwrite the kept ones
                 rc = ensure_capacity(&m->records_d, &m->records_capacity, L, ctx->stream);
@@ -563,7 +593,8 @@ int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, 
                 p.count = L;
                 p.pair_values = m->cache_values_d;
                 p.records = m->records_d;
-                HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+                rc = launch_k01_with_e1(m, p);  // (the moved views' E1 in the launch's own arguments: no e1_kernel per step)
+                if (rc) return rc;
                 if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
                 HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
                 if (ctx->timing) {
@@ -818,8 +849,6 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
             return ECC_OK;
         }
     }
-    rc = ensure_e1(m);
-    if (rc) return rc;
     m->rec_valid = false;  // the list's records overwrite the kept ones
     rc = ensure_capacity(&m->records_d, &m->records_capacity, n_pairs, ctx->stream);
     if (rc) return rc;
@@ -841,7 +870,8 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     p.count = n_pairs;
     p.pair_values = m->pair_values_d;
     p.records = m->records_d;
-    HIP_TRY(ecc_launch_k01(&p, ctx->stream));
+    rc = launch_k01_with_e1(m, p);
+    if (rc) return rc;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
     if (ctx->timing) {

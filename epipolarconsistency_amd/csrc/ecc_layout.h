@@ -161,6 +161,11 @@ struct EccPairParams {
 #ifndef ECC_REFERENCE_WIDE_MAX_PAIRS
 #define ECC_REFERENCE_WIDE_MAX_PAIRS 512
 #endif
+// launches of at most this many pairs fit their records with 8 lanes per fit (k01_kernel<8>, pairs_kernel.hip), and take E1 of a
+// few changed views in their kernel arguments instead of an e1_kernel launch (k01_patched_kernel)
+#ifndef ECC_K01_WIDE_MAX_PAIRS
+#define ECC_K01_WIDE_MAX_PAIRS 4096
+#endif
 #define ECC_SMALL_PATCH_MAX 16
 #define ECC_SMALL_MAGIC 0x45434353u
 struct EccSmallEval {

@@ -39,22 +39,23 @@ namespace {
 // else is done redundantly by all of them: 2.6x the instructions in total, a third of the chain length -- the form for
 // launches of a few thousand pairs (index lists, pose-delta launches, the shard of one of 8 GPUs), where the kernel's
 // time IS the chain length.  Identical records either way.
-#ifndef ECC_K01_WIDE_MAX_PAIRS
-#define ECC_K01_WIDE_MAX_PAIRS 4096
-#endif
+// The records of the workgroup's pairs (k01_fit_block) out of LDS into p.records.
 template <int LANES>
-__global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
+__device__ __forceinline__ void k01_block(const EccPairParams& p, K01Shared<LANES>& sh, EccSmallEvalArg small, bool poison)
 {
     constexpr int K01_PAIRS = 64 / LANES;
     // The records are assembled in LDS and leave the workgroup as one contiguous, coalesced block: written straight
     // from the threads every store instruction would scatter its 64 lanes over 64 records 296 bytes apart.
-    __shared__ K01Shared<LANES> sh;
-    k01_fit_block<LANES>(p, (long long)blockIdx.x * K01_PAIRS, K01_PAIRS, sh);
+    k01_fit_block<LANES>(p, (long long)blockIdx.x * K01_PAIRS, K01_PAIRS, sh, small);
     const long long first_pair = (long long)blockIdx.x * K01_PAIRS;
     const long long n_here = min((long long)K01_PAIRS, p.count - first_pair);
     if (n_here > 0) {
         constexpr int RW = (int)(sizeof(EccPairRecord) / 8);
         const int words = (int)n_here * RW;
+        if (poison) {  // the kernel's two views of its argument list disagree: every value of the launch becomes NaN
+            if (threadIdx.x < n_here) sh.recs[threadIdx.x].K0[6] = __builtin_nanf("");
+            __syncthreads();
+        }
         const double* src = reinterpret_cast<const double*>(sh.recs);
         if (!p.record_slots) {
             double* dst = reinterpret_cast<double*>(p.records + first_pair);
@@ -66,6 +67,27 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
             }
         }
     }
+}
+
+template <int LANES>
+__global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
+{
+    __shared__ K01Shared<LANES> sh;
+    k01_block<LANES>(p, sh, nullptr, false);
+}
+
+// k01_kernel<8> with E1 of the views whose matrix changed since the device arrays were made in the KERNEL ARGUMENTS (x.patch_*,
+// at most ECC_SMALL_PATCH_MAX views, computed by the host with e1_kernel's own code): an optimiser step that moves a few
+// views needs no e1_kernel launch in front of a small evaluation.  The list is read in place in the kernel-argument segment,
+// as in small_eval_kernel.hip; workgroup 0 stores the entries into the device arrays for later launches.
+__global__ __launch_bounds__(256) void k01_patched_kernel(EccPairParams p, EccSmallEval x)
+{
+    __shared__ K01Shared<8> sh;
+    typedef const char __attribute__((address_space(4))) * KernargBytes;
+    static_assert(alignof(EccSmallEval) == 8 && alignof(EccPairParams) == 8, "layout of the kernel arguments");
+    const EccSmallEvalArg xs = (EccSmallEvalArg)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(EccPairParams) + 7) & ~(size_t)7));
+    const bool args_ok = xs->magic == ECC_SMALL_MAGIC && x.magic == ECC_SMALL_MAGIC && xs->patch_count == x.patch_count;
+    k01_block<8>(p, sh, xs, !args_ok);
 }
 
 #define PK_OCCUPANCY
@@ -531,6 +553,17 @@ extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream)
     // small launches: 8 lanes per fit (the kernel's time is one thread's chain there); the records are identical
     if (p->count <= ECC_K01_WIDE_MAX_PAIRS) hipLaunchKernelGGL(k01_kernel<8>, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p);
     else hipLaunchKernelGGL(k01_kernel<1>, dim3((unsigned)((p->count + 63) / 64)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+// ecc_launch_k01 for at most ECC_K01_WIDE_MAX_PAIRS pairs with x->patch_* (see k01_patched_kernel); nothing else of x is used.
+extern "C" hipError_t ecc_launch_k01_patched(const EccPairParams* p, const EccSmallEval* x, hipStream_t stream)
+{
+    if (p->count <= 0) return hipSuccess;
+    if (p->count > ECC_K01_WIDE_MAX_PAIRS || p->patch_count || x->patch_count < 0 || x->patch_count > ECC_SMALL_PATCH_MAX) return hipErrorInvalidValue;
+    EccSmallEval xx = *x;
+    xx.magic = ECC_SMALL_MAGIC;
+    hipLaunchKernelGGL(k01_patched_kernel, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p, xx);
     return hipGetLastError();
 }
 

@@ -296,7 +296,9 @@ int ecc_metric_set_record_reuse(ecc_metric* m, int on);
  * waves, every value goes to the device array and -- at system scope -- to pinned host memory, the workgroup that arrives
  * last writes the word the host polls, and the host adds the values in the sum kernel's order.  Larger evaluations keep the
  * stream-ordered launches, up to 4096 pairs with several waves per pair (pairs_split_kernel), index lists without copy
- * commands (the list is read from pinned memory, the sum kernel hands the values back).  Every value and every sum has the
+ * commands (the list is read from pinned memory, the sum kernel hands the values back), and launches of at most 4096 pairs
+ * also take E1 of up to 16 changed views in the arguments of their record kernel (k01_patched_kernel) instead of an e1_kernel
+ * launch.  Every value and every sum has the
  * bits of the multi-launch one-wave-per-pair path (tests/test_gpu_small_eval.py, tests/test_gpu_stress_sequences.py); on = 0
  * keeps the stream-ordered launches for everything. */
 int ecc_metric_set_small_eval(ecc_metric* m, int on);
