@@ -161,10 +161,19 @@ struct EccPairParams {
 #ifndef ECC_REFERENCE_WIDE_MAX_PAIRS
 #define ECC_REFERENCE_WIDE_MAX_PAIRS 512
 #endif
-// launches of at most this many pairs fit their records with 8 lanes per fit (k01_kernel<8>, pairs_kernel.hip), and take E1 of a
-// few changed views in their kernel arguments instead of an e1_kernel launch (k01_patched_kernel)
+// launches of at most this many pairs fit their records with ECC_K01_SMALL_LANES lanes per fit (k01_kernel<16>, pairs_kernel.hip:
+// the kernel's time is the length of one fit's dependent chain there), and take E1 of a few changed views in their kernel
+// arguments instead of an e1_kernel launch (k01_patched_kernel)
 #ifndef ECC_K01_WIDE_MAX_PAIRS
 #define ECC_K01_WIDE_MAX_PAIRS 4096
+#endif
+#ifndef ECC_K01_SMALL_LANES
+#define ECC_K01_SMALL_LANES 16  // 16: one exact curve point per lane; 8: two or three (round 3)
+#endif
+// ... up to this many pairs; beyond, 8 lanes per fit (measured: 1 pair / 528 pairs 20.0 / 25.3 -> 18.9 / 23.3 us per evaluation with
+// 16 lanes, 1035 and 2016 pairs the same either way, 4095 pairs 42.3 -> 45.2: twice the workgroups for the same chain)
+#ifndef ECC_K01_LANES16_MAX_PAIRS
+#define ECC_K01_LANES16_MAX_PAIRS 1024
 #endif
 #define ECC_SMALL_PATCH_MAX 16
 #define ECC_SMALL_MAGIC 0x45434353u

@@ -699,6 +699,54 @@ __device__ bool fit_coordinate_wide(const PolyT& T, const CurveGeom& g, double k
     constexpr int N = ECC_POLY_DEG + 1, H = ECC_POLY_DEG / 2;
     static_assert(LANES >= H + 1 && LANES >= ECC_POLY_CHECKS && (LANES & (LANES - 1)) == 0, "one lane per node and per check");
     const int lane = threadIdx.x & 63, base = lane & ~(LANES - 1);
+    if constexpr (LANES >= 2 * H + 1 + ECC_POLY_CHECKS) {
+        // 16 lanes per fit: ONE exact curve point per lane -- lanes 0 .. H-1 the nodes at +kappa, H .. 2H-1 the same nodes at
+        // -kappa, 2H the centre, the next ECC_POLY_CHECKS the check points, all at once; then the same exchanges and the same
+        // accumulation order as below.  The chain of a fit is one curve point + the accumulation instead of three points.
+        constexpr int C0 = 2 * H + 1;
+        const bool neg = j >= H && j < 2 * H, is_check = j >= C0 && j < C0 + ECC_POLY_CHECKS;
+        bool ok16 = true, f = false, v = true;
+        double val = 0.0, xq = 0.0;
+        if (j < C0 + ECC_POLY_CHECKS) {
+            double sn = 0.0, cs = 1.0;
+            if (j < 2 * H) {
+                sincos_table(T, T.nodes[neg ? j - H : j] * km, sn, cs);
+                if (neg) sn = -sn;  // the mirrored node: cos(-t) = cos t, sin(-t) = -sin t
+            } else if (is_check) {
+                xq = T.checks[j - C0];
+                sincos_table(T, fabs(xq) * km, sn, cs);
+                if (xq < 0) sn = -sn;
+            }
+            val = ANGLE ? exact_angle_coord(T, g, cs, sn, f, v) : exact_distance_coord(g, cs, sn, false);
+            ok16 = v;
+        }
+        fold0 = __shfl((int)f, base) != 0;  // the state at node 0, +kappa (what fit_coordinate takes)
+        if (ANGLE && j < C0 + ECC_POLY_CHECKS) ok16 = ok16 && f == fold0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) c[k] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < H; ++jj) {
+            const double fp = __shfl(val, base + jj), fm = __shfl(val, base + H + jj);
+            const double fej = 0.5 * (fp + fm), foj = (fp - fm) * (0.5 / T.nodes[jj]);
+#pragma unroll
+            for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.g->Ae[k * (H + 1) + jj], fej, c[2 * k]);
+#pragma unroll
+            for (int k = 0; k < H; ++k) c[2 * k + 1] = fma(T.g->Ao[k * H + jj], foj, c[2 * k + 1]);
+        }
+        {
+            const double f0 = __shfl(val, base + 2 * H);
+#pragma unroll
+            for (int k = 0; k <= H; ++k) c[2 * k] = fma(T.g->Ae[k * (H + 1) + H], f0, c[2 * k]);
+        }
+        if (is_check) {
+            double pq = c[N - 1];
+#pragma unroll
+            for (int k = N - 2; k >= 0; --k) pq = fma(pq, xq, c[k]);
+            ok16 = ok16 && fabs(pq - val) <= 1e-5;  // NaN fails
+        }
+        const unsigned long long all16 = __ballot(ok16);
+        return ((all16 >> base) & ((1ull << LANES) - 1)) == ((1ull << LANES) - 1);
+    }
     bool ok = true, f1 = false;
     double fe = 0.0, fo = 0.0;
     if (j < H) {

@@ -80,14 +80,15 @@ __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 // at most ECC_SMALL_PATCH_MAX views, computed by the host with e1_kernel's own code): an optimiser step that moves a few
 // views needs no e1_kernel launch in front of a small evaluation.  The list is read in place in the kernel-argument segment,
 // as in small_eval_kernel.hip; workgroup 0 stores the entries into the device arrays for later launches.
+template <int LANES>
 __global__ __launch_bounds__(256) void k01_patched_kernel(EccPairParams p, EccSmallEval x)
 {
-    __shared__ K01Shared<8> sh;
+    __shared__ K01Shared<LANES> sh;
     typedef const char __attribute__((address_space(4))) * KernargBytes;
     static_assert(alignof(EccSmallEval) == 8 && alignof(EccPairParams) == 8, "layout of the kernel arguments");
     const EccSmallEvalArg xs = (EccSmallEvalArg)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(EccPairParams) + 7) & ~(size_t)7));
     const bool args_ok = xs->magic == ECC_SMALL_MAGIC && x.magic == ECC_SMALL_MAGIC && xs->patch_count == x.patch_count;
-    k01_block<8>(p, sh, xs, !args_ok);
+    k01_block<LANES>(p, sh, xs, !args_ok);
 }
 
 #define PK_OCCUPANCY
@@ -551,7 +552,11 @@ extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream)
 {
     if (p->count <= 0) return hipSuccess;
     // small launches: 8 lanes per fit (the kernel's time is one thread's chain there); the records are identical
-    if (p->count <= ECC_K01_WIDE_MAX_PAIRS) hipLaunchKernelGGL(k01_kernel<8>, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p);
+    if (p->count <= ECC_K01_LANES16_MAX_PAIRS) {
+        constexpr int per_wg = 64 / ECC_K01_SMALL_LANES;
+        hipLaunchKernelGGL(k01_kernel<ECC_K01_SMALL_LANES>, dim3((unsigned)((p->count + per_wg - 1) / per_wg)), dim3(256), 0, stream, *p);
+    } else if (p->count <= ECC_K01_WIDE_MAX_PAIRS)
+        hipLaunchKernelGGL(k01_kernel<8>, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p);
     else hipLaunchKernelGGL(k01_kernel<1>, dim3((unsigned)((p->count + 63) / 64)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
@@ -563,7 +568,11 @@ extern "C" hipError_t ecc_launch_k01_patched(const EccPairParams* p, const EccSm
     if (p->count > ECC_K01_WIDE_MAX_PAIRS || p->patch_count || x->patch_count < 0 || x->patch_count > ECC_SMALL_PATCH_MAX) return hipErrorInvalidValue;
     EccSmallEval xx = *x;
     xx.magic = ECC_SMALL_MAGIC;
-    hipLaunchKernelGGL(k01_patched_kernel, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p, xx);
+    if (p->count <= ECC_K01_LANES16_MAX_PAIRS) {
+        constexpr int per_wg = 64 / ECC_K01_SMALL_LANES;
+        hipLaunchKernelGGL(k01_patched_kernel<ECC_K01_SMALL_LANES>, dim3((unsigned)((p->count + per_wg - 1) / per_wg)), dim3(256), 0, stream, *p, xx);
+    } else
+        hipLaunchKernelGGL(k01_patched_kernel<8>, dim3((unsigned)((p->count + 7) / 8)), dim3(256), 0, stream, *p, xx);
     return hipGetLastError();
 }
 

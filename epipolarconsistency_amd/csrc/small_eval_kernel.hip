@@ -60,9 +60,10 @@ __global__ __launch_bounds__(REF ? 1024 : 256, ECC_SMALL_MIN_WAVES) void small_e
 {
     constexpr int PPW = 4 / WPP;  // pairs per workgroup
     static_assert(!REF || WPP == 4, "reference arithmetic: one pair per workgroup");
+    static_assert(PPW <= 64 / ECC_K01_SMALL_LANES, "phase A makes 64 / ECC_K01_SMALL_LANES records per workgroup");
     extern __shared__ float stage_all[];  // WPP > 1 or REF: PPW * x.stage_stride floats
     const bool member = !REF || threadIdx.x < 256;  // wave-uniform: the threads that make the records
-    __shared__ K01Shared<8> ks;
+    __shared__ K01Shared<ECC_K01_SMALL_LANES> ks;
     __shared__ int32_t idx_lds[4 * PPW];
     __shared__ double part[4];
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(REF ? 1024 : 256, ECC_SMALL_MIN_WAVES) void small_e
     static_assert(alignof(EccSmallEval) == 8 && alignof(EccPairParams) == 8, "layout of the kernel arguments");
     const EccSmallEvalArg xs = (EccSmallEvalArg)((KernargBytes)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(EccPairParams) + 7) & ~(size_t)7));
     const bool args_ok = xs->magic == ECC_SMALL_MAGIC && x.magic == ECC_SMALL_MAGIC && xs->patch_count == x.patch_count;
-    k01_fit_block<8>(p, blk_first, PPW, ks, xs, p.indices ? idx_lds : nullptr, member);  // ends with a barrier
+    k01_fit_block<ECC_K01_SMALL_LANES>(p, blk_first, PPW, ks, xs, p.indices ? idx_lds : nullptr, member);  // ends with a barrier
 
     ECC_SMALL_STAMP(1);
     // ---- phase B ----
