@@ -67,7 +67,8 @@ struct EccRadonParams {
 #define ECC_PAIRS_SPLIT_MAX 4096  // launches up to here: several waves per pair (pairs_split_kernel)
 #endif
 #ifndef ECC_PAIRS_SPLIT4_MAX
-#define ECC_PAIRS_SPLIT4_MAX 1792  // ... four of them up to here, two beyond
+#define ECC_PAIRS_SPLIT4_MAX 2048  // ... four of them up to here, two beyond (bench.py --views 64 --size 512, 2016 pairs: 34.5 -> 32.6 us per
+                                   // step against two; 2775 and 4095 pairs: the same either way)
 #endif
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
