@@ -70,6 +70,9 @@ struct EccRadonParams {
 #define ECC_PAIRS_SPLIT4_MAX 2048  // ... four of them up to here, two beyond (bench.py --views 64 --size 512, 2016 pairs: 34.5 -> 32.6 us per
                                    // step against two; 2775 and 4095 pairs: the same either way)
 #endif
+#ifndef ECC_PAIRS_SPLIT8_MAX
+#define ECC_PAIRS_SPLIT8_MAX 768   // ... eight (one pair per 512-thread workgroup) up to here
+#endif
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
 

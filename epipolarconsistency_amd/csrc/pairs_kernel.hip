@@ -165,10 +165,13 @@ __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(Ecc
 // stores every sample's term in LDS; the pair's first wave then adds the terms per lane in the order ONE wave accumulates
 // them (k = lane, lane + 64, ... while kappa < kappa_max), so the value has pairs_kernel's bits
 // (tests/test_gpu_small_eval.py: the same pairs through both kernels).  Round 4, config 2 (2016 pairs): 16.9 -> ~7 us.
+// WPP = 8 (one pair per 512-thread workgroup, launches of at most ECC_PAIRS_SPLIT8_MAX pairs): a 512-pair index list
+// 30.2 -> 28.7 us end to end, smaller lists and the pose-delta sweep unchanged (their time is the record kernel and the
+// launches around it).
 template <bool DERIV, int WPP>
-__global__ __launch_bounds__(PK_THREADS) void pairs_split_kernel(EccPairParams p, int stage_stride)
+__global__ __launch_bounds__(WPP > 4 ? 64 * WPP : PK_THREADS) void pairs_split_kernel(EccPairParams p, int stage_stride)
 {
-    constexpr int PPW = 4 / WPP;  // pairs per workgroup
+    constexpr int PPW = WPP > 4 ? 1 : 4 / WPP;  // pairs per workgroup (WPP = 8: one pair per 512-thread workgroup)
     extern __shared__ float stage_all[];  // PPW * stage_stride floats
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = wave / WPP, sub = wave % WPP;  // wave-uniform
@@ -600,16 +603,19 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
     }
     if (!p->use_corr && !p->skip_enabled && p->count <= ECC_PAIRS_SPLIT_MAX) {
         // few pairs: several waves per pair (pairs_split_kernel); four while that fits one round of resident waves
-        const int wpp = p->count <= ECC_PAIRS_SPLIT4_MAX ? 4 : 2;
+        const int wpp = p->count <= ECC_PAIRS_SPLIT8_MAX ? 8 : (p->count <= ECC_PAIRS_SPLIT4_MAX ? 4 : 2);
+        const int ppw = wpp > 4 ? 1 : 4 / wpp;
         const int stride = (p->k_limit + 63) & ~63;
-        const size_t lds = sizeof(float) * (size_t)(4 / wpp) * (size_t)stride;
+        const size_t lds = sizeof(float) * (size_t)ppw * (size_t)stride;
         if (lds <= 48 * 1024) {  // (a user-chosen dkappa with tens of thousands of samples per pair: the one-wave kernel)
-            const dim3 grid((unsigned)((p->count + (4 / wpp) - 1) / (4 / wpp))), block(PK_THREADS);
+            const dim3 grid((unsigned)((p->count + ppw - 1) / ppw)), block(wpp > 4 ? 64 * wpp : PK_THREADS);
             if (p->is_derivative) {
-                if (wpp == 4) hipLaunchKernelGGL((pairs_split_kernel<true, 4>), grid, block, lds, stream, *p, stride);
+                if (wpp == 8) hipLaunchKernelGGL((pairs_split_kernel<true, 8>), grid, block, lds, stream, *p, stride);
+                else if (wpp == 4) hipLaunchKernelGGL((pairs_split_kernel<true, 4>), grid, block, lds, stream, *p, stride);
                 else hipLaunchKernelGGL((pairs_split_kernel<true, 2>), grid, block, lds, stream, *p, stride);
             } else {
-                if (wpp == 4) hipLaunchKernelGGL((pairs_split_kernel<false, 4>), grid, block, lds, stream, *p, stride);
+                if (wpp == 8) hipLaunchKernelGGL((pairs_split_kernel<false, 8>), grid, block, lds, stream, *p, stride);
+                else if (wpp == 4) hipLaunchKernelGGL((pairs_split_kernel<false, 4>), grid, block, lds, stream, *p, stride);
                 else hipLaunchKernelGGL((pairs_split_kernel<false, 2>), grid, block, lds, stream, *p, stride);
             }
             return hipGetLastError();
