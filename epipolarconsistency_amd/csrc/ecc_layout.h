@@ -114,6 +114,9 @@ struct EccPairParams {
     float* pair_values;        // optional, `count` floats (local pair order)
     const int32_t* value_slots;  // optional, `count` entries: pair_values[value_slots[k]] instead of pair_values[k]
     int reference_split;       // reference arithmetic: waves per pair, 1 or 4 (4: one pair per workgroup, for few pairs)
+    int beside_another_launch; // host only: this launch runs beside a chip-filling one on another stream -- 256-thread workgroups only
+                               // (a 512-thread workgroup waits until eight wave slots of ONE CU are free at once: the moved view's
+                               // 399 pairs took 304 us instead of 29 beside the all-pairs launch)
     float* cost;               // optional n x n cost image (index i + j*n)
     float* K01_out;            // optional debug output, 16 floats per pair
     EccPairRecord* records;    // `count` records, written by k01_kernel, read by pairs_kernel

@@ -603,7 +603,7 @@ extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t strea
     }
     if (!p->use_corr && !p->skip_enabled && p->count <= ECC_PAIRS_SPLIT_MAX) {
         // few pairs: several waves per pair (pairs_split_kernel); four while that fits one round of resident waves
-        const int wpp = p->count <= ECC_PAIRS_SPLIT8_MAX ? 8 : (p->count <= ECC_PAIRS_SPLIT4_MAX ? 4 : 2);
+        const int wpp = (p->count <= ECC_PAIRS_SPLIT8_MAX && !p->beside_another_launch) ? 8 : (p->count <= ECC_PAIRS_SPLIT4_MAX ? 4 : 2);
         const int ppw = wpp > 4 ? 1 : 4 / wpp;
         const int stride = (p->k_limit + 63) & ~63;
         const size_t lds = sizeof(float) * (size_t)ppw * (size_t)stride;
