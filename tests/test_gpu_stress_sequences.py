@@ -36,7 +36,7 @@ def _sequence(rng, n, m, ref, P0, slabs, torch, E, ctx, n_ops, log):
 
     for op_i in range(n_ops):
         op = rng.choice(["set1", "set1", "set1", "set0", "set2", "setmany", "all", "all", "all", "cost", "range", "range", "async",
-                         "list", "list", "pair", "geo", "refresh", "params", "mode", "incr", "reuse", "small"])
+                         "list", "list", "pair", "geo", "refresh", "params", "mode", "incr", "reuse", "small", "poses"])
         log.append(op)
         if op == "set0":
             set_matrices(0)
@@ -110,6 +110,17 @@ def _sequence(rng, n, m, ref, P0, slabs, torch, E, ctx, n_ops, log):
             m.setRecordReuse(k > 0, always=k == 2)
         elif op == "small":
             m.setSmallEval(bool(rng.random() < 0.7))
+        elif op == "poses":  # ecc_metric_evaluate_poses (two deep): the last pose stays the metric's current one
+            poses = []
+            for _ in range(int(rng.integers(1, 4))):
+                Pq = P.copy()
+                v = int(rng.integers(0, n))
+                Pq[v] = (Pq[v].reshape(4, 3).T @ E.geometry.rigid_transform(tx=float(rng.uniform(-1, 1)), rz=float(rng.uniform(-.01, .01)))).T.reshape(12)
+                poses.append(Pq)
+            got = m.evaluate_poses(poses)
+            want = np.array([ref.setProjectionMatrices(Pq).evaluate() for Pq in poses])
+            assert np.array_equal(np.asarray(got), want, equal_nan=True), log[-12:]
+            P = poses[-1]
     both(lambda q: q.useCorrelation(False).setObjectRadius(0.0).setdKappa(0.0))
     assert m.evaluate() == ref.evaluate(), log[-12:]
 
