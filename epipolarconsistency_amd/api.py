@@ -351,6 +351,12 @@ class MetricRadonIntermediate:
         self._sampling = 0 if d is None else (self._SAMPLING[d] if isinstance(d, str) else int(d))
         self._incremental = False
         self._record_reuse = None  # library default (on unless ECC_RECORD_REUSE=0)
+        # the optimiser loop's two calls, setProjectionMatrices + evaluate(): data pointers of the caller's (n, 12) arrays by
+        # array object (ndarray.ctypes costs 1.2 us per call; the arrays are kept alive here, at most 1024 of them), and the
+        # result cell of evaluate()
+        self._ptr_cache = {}
+        self._mean = C.c_double()
+        self._mean_ref = C.byref(self._mean)
         if dtrs is not None:
             self.setRadonIntermediates(dtrs)
         if Ps is not None:
@@ -385,9 +391,18 @@ class MetricRadonIntermediate:
     def setProjectionMatrices(self, Ps):
         """Ps: list of 3x4 matrices, or (fast path) an (n, 12) float64 C-contiguous array that is
         already column-major per view (what Eigen's Ps[i].data() holds)."""
+        hit = self._ptr_cache.get(id(Ps))
+        if hit is not None and hit[0] is Ps and hit[2] == Ps.shape:  # this very array object has passed the checks below
+            self._Ps = Ps
+            if self._h:
+                check(_lib.lib().ecc_metric_set_projections(self._h, hit[1], hit[2][0]))
+            return self
         if isinstance(Ps, np.ndarray) and Ps.ndim == 2 and Ps.shape[1] == 12 and Ps.dtype == np.float64 \
                 and Ps.flags["C_CONTIGUOUS"]:
             self._Ps = Ps
+            if len(self._ptr_cache) >= 1024:
+                self._ptr_cache.clear()
+            self._ptr_cache[id(Ps)] = (Ps, C.c_void_p(Ps.ctypes.data), Ps.shape)  # (an ndarray's buffer does not move while it is referenced)
         else:
             self._Ps = _Ps_colmajor(Ps)
         if self._h:
@@ -476,6 +491,9 @@ class MetricRadonIntermediate:
         evaluate(indices[, out])        -> mean over explicit (P0,P1,dtr0,dtr1) tuples
         ref: ...RadonIntermediate.cpp:166-225, :228-245, :267-322."""
         L = _lib.lib()
+        if arg is None:
+            check(L.ecc_metric_evaluate_all(self._h, None, self._mean_ref))
+            return self._mean.value
         mean = C.c_double()
         if arg is None or (isinstance(arg, np.ndarray) and arg.dtype == np.float32 and arg.ndim == 2
                            and out is None and arg.shape[0] == arg.shape[1] == self.getNumberOfProjetions()):
@@ -490,12 +508,25 @@ class MetricRadonIntermediate:
             idx = [(a, b, a, b) for k, a in enumerate(views) for b in views[k + 1:]]
         else:
             idx = arg
+        hit_i, hit_o = self._ptr_cache.get(id(idx)), self._ptr_cache.get(id(out))
+        if hit_i is not None and hit_o is not None and hit_i[0] is idx and hit_o[0] is out and hit_i[2] == idx.shape \
+                and hit_o[2] == out.shape:  # these very arrays have passed the checks below
+            check(L.ecc_metric_evaluate_pairs(self._h, hit_i[1], hit_i[2][0], hit_o[1], self._mean_ref))
+            return self._mean.value
+        cacheable = isinstance(idx, np.ndarray) and idx.dtype == np.int32 and idx.ndim == 2 and idx.shape[1] == 4 \
+            and idx.flags["C_CONTIGUOUS"] and isinstance(out, np.ndarray) and out.flags["C_CONTIGUOUS"]
+        idx0 = idx
         idx = np.ascontiguousarray(idx, np.int32).reshape(-1, 4)
         if out is None:
             out = np.empty(len(idx), np.float32)
         assert out.dtype == np.float32 and out.size >= len(idx)
-        check(L.ecc_metric_evaluate_pairs(self._h, C.c_void_p(idx.ctypes.data), len(idx),
-                                          C.c_void_p(out.ctypes.data), C.byref(mean)))
+        pi, po = C.c_void_p(idx.ctypes.data), C.c_void_p(out.ctypes.data)
+        if cacheable:  # (idx is a view of idx0 then: the same buffer)
+            if len(self._ptr_cache) >= 1024:
+                self._ptr_cache.clear()
+            self._ptr_cache[id(idx0)] = (idx0, pi, idx0.shape)
+            self._ptr_cache[id(out)] = (out, po, out.shape)
+        check(L.ecc_metric_evaluate_pairs(self._h, pi, len(idx), po, C.byref(mean)))
         return mean.value
 
     def evaluate_poses(self, poses):
