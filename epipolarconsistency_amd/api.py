@@ -606,11 +606,11 @@ class MetricRadonIntermediate:
 
     def debug_polynomials(self, first, count):
         """The sample-coordinate polynomials the pair-geometry kernel fitted: list of dicts with
-        poly_ok, degree (the pair kernel evaluates the polynomials up to it), x_scale, fold (2,), ca (2, 13), cd (2, 12)."""
+        poly_ok, degree (the pair kernel evaluates the polynomials up to it), clamp_free (no sample can reach a clamp), x_scale, fold (2,), ca (2, 13), cd (2, 12)."""
         n = 4 + 2 * 13 + 2 * 12
         out = np.empty((count, n), np.float32)
         check(_lib.lib().ecc_metric_debug_polynomials(self._h, int(first), int(count), C.c_void_p(out.ctypes.data)))
-        return [dict(poly_ok=bool(r[0]), degree=int(r[0]), x_scale=float(r[1]), fold=r[2:4] > 0, ca=r[4:30].reshape(2, 13).astype(np.float64),
+        return [dict(poly_ok=bool(r[0]), degree=int(r[0]), clamp_free=bool(r[0] != int(r[0])), x_scale=float(r[1]), fold=r[2:4] > 0, ca=r[4:30].reshape(2, 13).astype(np.float64),
                      cd=r[30:54].reshape(2, 12).astype(np.float64)) for r in out]
 
     def close(self):

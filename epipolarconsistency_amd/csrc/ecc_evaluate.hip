@@ -992,7 +992,7 @@ ECC_EXPORT int ecc_metric_debug_polynomials(ecc_metric* m, int64_t first, int64_
     for (int64_t q = 0; q < count; ++q) {
         const EccPairRecord& r = recs[(size_t)q];
         float* o = out + (size_t)q * ECC_POLY_RECORD_FLOATS;
-        *o++ = (float)r.poly_ok;
+        *o++ = (float)(r.poly_ok & ~1) + ((r.poly_ok & 1) ? 0.5f : 0.f);  // the degree; + 0.5: the clamp-free class
         *o++ = r.x_scale;
         *o++ = r.fold[0] ? 1.f : 0.f;
         *o++ = r.fold[1] ? 1.f : 0.f;

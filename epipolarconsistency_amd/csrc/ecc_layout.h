@@ -83,7 +83,8 @@ struct EccPairRecord {
     int iD0, iD1;  // Radon intermediates of the two views
     int ci, cj;    // cost-image position (all-pairs mode)
     int poly_ok;   // 0: exact per-sample path; else the sample coordinates of both views are given by the polynomials
-                   // below, evaluated up to this degree (4, 6, 8 or 10; economised in k01_kernel, higher coefficients are zero)
+                   // below, evaluated up to the degree poly_ok & ~1 (4, 6, 8 or 10; economised in k01_kernel, higher coefficients
+                   // are zero); bit 0: k01's bound on the polynomials says no sample can reach a clamp of the pair kernel
     float x_scale; // x = kappa * x_scale in (0, 1]; the -kappa samples are the same polynomials at -x
     unsigned fold[2];                  // per view: 0x80000000 when the (alpha+pi, -t) fold applies on the +kappa side
                                        // (it is the opposite on the -kappa side: the line is negated there)

@@ -366,7 +366,9 @@ __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_
 // Addressing, the one 16-byte load and the bilinear rule for a sample whose coordinates are already known.
 // (Non-temporal loads for the view whose band no later pair of the XCD re-uses were measured: they bypass the L1 as
 // well and lose the reuse between neighbouring lanes, 0.397 vs 0.338 ms.)
-template <bool DERIV, int PITCH4>
+// NOCLAMP: k01's bound on the pair's polynomials (record.poly_ok bit 0) says that neither coordinate can reach a clamp: the
+// two v_med3 would return their inputs, and are left out.
+template <bool DERIV, int PITCH4, bool NOCLAMP = false>
 __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, const SlabView sv, float n_t_f, float pitch4_f,
                                            float xa_max)
 {
@@ -378,11 +380,11 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
         // point of the same bilinear surface -- and leaves the index in the low mantissa bits.  Needs x >= 0.25: the angle
         // coordinate is >= 0.5 in padded texel units; the distance coordinate is clamped at 0.5 instead of 0 (cell 0 is
         // the replicated border: both its bins hold the same bits, the value does not depend on the fraction there).
-        yd = __builtin_amdgcn_fmed3f(yd, 0.5f, n_t_f);
+        if (!NOCLAMP) yd = __builtin_amdgcn_fmed3f(yd, 0.5f, n_t_f);
         // the angle coordinate is within [0.5, n_alpha + 0.5] wherever the fitted polynomial is the mapping it was checked
         // against; between the check points nothing guarantees it, and the index below is 24 mantissa bits times the row
         // pitch: one v_med3 keeps a misbehaving fit inside the slab (advisor, round 3; values in range are not changed)
-        xa = __builtin_amdgcn_fmed3f(xa, 0.5f, xa_max);
+        if (!NOCLAMP) xa = __builtin_amdgcn_fmed3f(xa, 0.5f, xa_max);
         const float ma = xa + 8388607.5f, md = yd + 8388607.5f;
         fx = xa - (ma - 8388608.f);
         fy = yd - (md - 8388608.f);
@@ -418,7 +420,7 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
 // two prefetches 0.41 ms -- a gather instruction costs the L1 the same whatever it fetches.
 // DEG: the degree the record asks for -- the fit is of degree ECC_POLY_DEG, k01_kernel lowers it where Chebyshev
 // economisation costs less than 2e-8 bins (see economise).
-template <bool DERIV, bool CORR, int PITCH4, int DEG, int WPP = 1>
+template <bool DERIV, bool CORR, int PITCH4, int DEG, int WPP = 1, bool NOCLAMP = false>
 __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
                                                 float kappa_max, float w06, const SlabView sv0, const SlabView sv1,
                                                 float n_alpha_f, float n_t_f, float pitch4_f, double& acc, double& mom2,
@@ -457,10 +459,10 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         poly_pm<DEG>(ca[1], ca[1][ECC_POLY_DEG + 1], ca[1][ECC_POLY_DEG + 2], false, x, z, xa1p, xa1m);
         poly_pm<DEG>(cd[1], cd[1][ECC_POLY_DEG + 1], 0.f, true, x, z, yd1p, yd1m);
         // (CORR keeps the signed samples: the cross moment sees the signs)
-        const float v0p = sample_at<DERIV && CORR, PITCH4>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f, xa_max);
-        const float v1p = sample_at<DERIV && CORR, PITCH4>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f, xa_max);
-        const float v0m = sample_at<DERIV && CORR, PITCH4>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f, xa_max);
-        const float v1m = sample_at<DERIV && CORR, PITCH4>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f, xa_max);
+        const float v0p = sample_at<DERIV && CORR, PITCH4, NOCLAMP>(xa0p, yd0p, fold[0], sv0, n_t_f, pitch4_f, xa_max);
+        const float v1p = sample_at<DERIV && CORR, PITCH4, NOCLAMP>(xa1p, yd1p, fold[1], sv1, n_t_f, pitch4_f, xa_max);
+        const float v0m = sample_at<DERIV && CORR, PITCH4, NOCLAMP>(xa0m, yd0m, fold[0] ^ 0x80000000u, sv0, n_t_f, pitch4_f, xa_max);
+        const float v1m = sample_at<DERIV && CORR, PITCH4, NOCLAMP>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f, xa_max);
         if (!CORR) {
             const float vp = fmaf(v1p, rel_sign, v0p), vm = fmaf(v1m, rel_sign, v0m);
             const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
@@ -856,6 +858,19 @@ struct K01Shared {
 // (small->patch_*); workgroup 0 copies those entries into the device arrays, which no thread reads for a patched view.
 // (`small` points INTO THE KERNEL-ARGUMENT SEGMENT -- constant address space, scalar loads -- not at a by-value copy of the
 // argument: indexing such a copy with a run-time index makes the compiler move all of it to scratch memory.)
+// coefficient of T_k in x^n (n >= k, same parity): 2^(1-n) C(n, (n-k)/2), halved for k = 0 -- a compile-time constant wherever
+// it is used (the loops over n and k are unrolled)
+__device__ __forceinline__ constexpr double cheb_weight(int n, int k)
+{
+    double binom = 1.0;
+    const int r = (n - k) / 2;
+    for (int i = 1; i <= r; ++i) binom = binom * (double)(n - r + i) / (double)i;
+    double w = binom;
+    for (int i = 1; i < n; ++i) w *= 0.5;  // 2^(1-n) for n >= 1
+    if (n == 0) w = 1.0;
+    return k == 0 && n > 0 ? 0.5 * w : w;
+}
+
 typedef const EccSmallEval __attribute__((address_space(4))) * EccSmallEvalArg;
 template <int LANES>
 __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long blk_first, int live_slots, K01Shared<LANES>& sh,
@@ -987,8 +1002,29 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         }
     }
     if (ok) ok = economise(c, (double)p.economise_tol);
+    // Can a sample of this coordinate reach a clamp of the pair kernel (angle: [0.5, n_alpha + 0.5], distance: [0.5, n_t])?
+    // |p(x) - a0| <= sum |a_k| on [-1, 1] for the Chebyshev coefficients a_k of p (both signs of kappa; the distance bound
+    // also holds for the reflected polynomial n_t + 1 - p, which is what is stored when the view is folded); 0.05 bins cover
+    // the float evaluation and the low parts.
+    int in_range = 0;
+    if (ok) {
+        // in the Chebyshev basis (|T_k| <= 1 on [-1, 1]; the monomial sum over-estimates the range of a wide curve several
+        // times): x^n = 2^(1-n) sum_k C(n, (n-k)/2) T_k over k = n, n-2, ..., the k = 0 term halved
+        double a0 = 0.0, spread = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double ak = 0.0;
+#pragma unroll
+            for (int nn = k; nn < N; nn += 2) ak = fma(c[nn], cheb_weight(nn, k), ak);
+            if (k == 0) a0 = ak;
+            else spread += fabs(ak);
+        }
+        const double lo = a0 - spread, hi = a0 + spread, margin = 0.05;
+        in_range = angle_role ? (lo >= 0.5 + margin && hi <= (double)p.n_alpha + 0.5 - margin)
+                              : (lo >= 1.0 + margin && hi <= (double)p.n_t - margin);
+    }
     const bool writer = member && jl == 0;  // LANES > 1: the lanes of a group hold identical results
-    if (writer) sh.ok_flags[role][slot] = ok;
+    if (writer) sh.ok_flags[role][slot] = ok | in_range;  // degree (even) | 1
     if (angle_role && writer) {
         r->fold[v] = fold0 ? 0x80000000u : 0u;
 #pragma unroll
@@ -1024,8 +1060,8 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         r->ci = ci;
         r->cj = cj;
         const int d0 = sh.ok_flags[0][slot], d1 = sh.ok_flags[1][slot], d2 = sh.ok_flags[2][slot], d3 = sh.ok_flags[3][slot];
-        const int degree = (d0 && d1 && d2 && d3) ? max(max(d0, d1), max(d2, d3)) : 0;
-        r->poly_ok = degree;
+        const int degree = (d0 && d1 && d2 && d3) ? max(max(d0 & ~1, d1 & ~1), max(d2 & ~1, d3 & ~1)) : 0;
+        r->poly_ok = degree ? (degree | (d0 & d1 & d2 & d3 & 1)) : 0;  // bit 0: no sample can reach a clamp
         r->x_scale = degree ? (float)(1.0 / (double)kappa_max) : 0.f;
     }
     __syncthreads();
@@ -1056,13 +1092,21 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
     const float kappa_max = K1[7];
 
     const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
-    const int poly_ok = __builtin_amdgcn_readfirstlane(rec->poly_ok);
+    const int poly_raw = __builtin_amdgcn_readfirstlane(rec->poly_ok);
+    const int poly_ok = poly_raw & ~1;       // the degree
+    const bool in_range = (poly_raw & 1) != 0;  // no sample of this pair can reach a clamp (k01_fit_block's bound)
     if (poly_ok) {
-#define ECC_POLY_LOOP(P4, DEG) \
-    kappa_loop_poly<DERIV, CORR, P4, DEG, WPP>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_alpha_f, n_t_f, pitch4_f, acc, mom2, mom3, mom4, sub, stage)
+#define ECC_POLY_LOOP_NC(P4, DEG, NC) \
+    kappa_loop_poly<DERIV, CORR, P4, DEG, WPP, NC>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_alpha_f, n_t_f, pitch4_f, acc, mom2, mom3, mom4, sub, stage)
+#define ECC_POLY_LOOP(P4, DEG) ECC_POLY_LOOP_NC(P4, DEG, false)
         if (p.wide_offsets) {
             if (poly_ok <= 6) ECC_POLY_LOOP(-1, 6);
             else ECC_POLY_LOOP(-1, ECC_POLY_DEG);
+        } else if (pitch4 == 6400u && in_range) {  // (the clamp-free loops exist for the default 768 distance bins only)
+            if (poly_ok <= 4) ECC_POLY_LOOP_NC(6400, 4, true);
+            else if (poly_ok <= 6) ECC_POLY_LOOP_NC(6400, 6, true);
+            else if (poly_ok <= 8) ECC_POLY_LOOP_NC(6400, 8, true);
+            else ECC_POLY_LOOP_NC(6400, ECC_POLY_DEG, true);
         } else if (pitch4 == 6400u) {
             if (poly_ok <= 4) ECC_POLY_LOOP(6400, 4);
             else if (poly_ok <= 6) ECC_POLY_LOOP(6400, 6);
@@ -1073,6 +1117,7 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
             else ECC_POLY_LOOP(0, ECC_POLY_DEG);
         }
 #undef ECC_POLY_LOOP
+#undef ECC_POLY_LOOP_NC
     } else if (reduce && p.quads) {
         // kappa_max > pi/4: in practice the pairs whose baseline passes through the object (kappa_max = pi/2).  Their
         // sampling curve crosses the whole Radon intermediate diagonally -- the 64 samples of a gather sit in ~17

@@ -412,7 +412,8 @@ int ecc_direct_evaluate_for_image_pair_kappas(ecc_direct* d, int i, int j, int n
                                               double* metric);
 
 /* Debug: what the pair-geometry kernel fitted for pairs ij in [first, first+count): per pair
- * ECC_POLY_RECORD_FLOATS floats = { degree evaluated (4, 6, 8, 10; 0 = exact path), x_scale, fold0, fold1 (1 = folded on the +kappa side),
+ * ECC_POLY_RECORD_FLOATS floats = { degree evaluated (4, 6, 8, 10; 0 = exact path; + 0.5 when the fit's bound says that no sample
+ * of the pair can reach a clamp of the pair kernel, which then runs its clamp-free loop), x_scale, fold0, fold1 (1 = folded on the +kappa side),
  * ca[0][0..DEG+2], ca[1][...], cd[0][0..DEG+1], cd[1][...] } with DEG = 10.  Host output. */
 #define ECC_POLY_RECORD_FLOATS (4 + 2 * 13 + 2 * 12)
 int ecc_metric_debug_polynomials(ecc_metric* m, int64_t first, int64_t count, float* out);

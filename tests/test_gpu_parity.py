@@ -248,7 +248,7 @@ def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
     recs = m.debug_polynomials(0, n_pairs)
     K01 = m.debug_K01(0, n_pairs)
     range_t = np.float32(B) * np.float32(np.sqrt(2.0) * S / B)
-    n_ok, worst = 0, 0.0
+    n_ok, worst, n_free = 0, 0.0, 0
     for ij, (r, K) in enumerate(zip(recs, K01)):
         kmax = float(K[15])
         if not r["poly_ok"]:
@@ -277,5 +277,48 @@ def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
                 pa = np.polyval(np.concatenate([ca[10:0:-1], [c0]]), sgn * x)
                 pd = np.polyval(np.concatenate([cd[10:0:-1], [cd[0] + cd[11]]]), sgn * x)
                 worst = max(worst, np.abs(pa - xa).max(), np.abs(pd - yd).max())
+                # the clamp-free class (record bit 0, k01's bound |p - c0| <= sum |c_k|): nothing the pair kernel evaluates for
+                # such a pair can reach one of its clamps -- angle [0.5, n_alpha + 0.5], distance [0.5, n_t] -- on the whole range
+                if r["clamp_free"]:
+                    xx = sgn * np.linspace(0.0, 1.0, 513)
+                    qa = np.polyval(np.concatenate([ca[10:0:-1], [c0]]), xx)
+                    qd = np.polyval(np.concatenate([cd[10:0:-1], [cd[0] + cd[11]]]), xx)
+                    assert qa.min() > 0.5 + 0.04 and qa.max() < B + 0.5 - 0.04, (ij, v, sgn, qa.min(), qa.max())
+                    assert qd.min() > 0.5 + 0.04 and qd.max() < B - 0.04, (ij, v, sgn, qd.min(), qd.max())
+                    n_free += 1
     assert n_ok > 0.8 * n_pairs
     assert worst < 2e-5, worst
+    assert n_free > 0 and any(r["poly_ok"] and not r["clamp_free"] for r in recs) or n_free == 4 * n_ok  # both loops, or all free
+
+
+def test_clamp_free_class_and_clamped_loops_agree_with_the_per_sample_path(gpu_ctx):
+    """With the automatic object radius no sampling curve comes near a border of the Radon intermediate and the pairs take
+    the clamp-free loops; a radius whose shadow leaves the detector pushes the distance coordinate into its clamp and the pairs
+    keep the clamped loops.  Both kinds must occur over the three radii, and every pair value agrees with the per-sample path,
+    which has no such split."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    n, S, B = 40, 1024, 768  # the default 768 distance bins: the layout the clamp-free loops exist for
+    Ps = synthetic.short_scan(n, S, S, 0.308)
+    rng = np.random.default_rng(12)
+    base = [E.RadonIntermediate.from_host(gpu_ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(4)]
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, [base[v % 4] for v in range(n)])
+    n_pairs = n * (n - 1) // 2
+    n_free = n_clamped = 0
+    for radius in (0.0, 104.0, 150.0):
+        m.setSampling("polynomial").setObjectRadius(radius)
+        _, vp = m.evaluate_range(0, n_pairs, want_pairs=True)
+        recs = m.debug_polynomials(0, n_pairs)
+        free = np.array([r["clamp_free"] for r in recs])
+        poly = np.array([r["poly_ok"] for r in recs])
+        assert not (free & ~poly).any()
+        n_free += int(free.sum())
+        n_clamped += int((poly & ~free).sum())
+        m.setSampling("per_sample")
+        _, vs = m.evaluate_range(0, n_pairs, want_pairs=True)
+        rel = np.abs(vp - vs) / np.maximum(np.abs(vs), 1e-30)
+        assert rel[poly].max() < 2e-3 and abs(vp.sum() - vs.sum()) / abs(vs.sum()) < 1e-5, (radius, rel.max(), vp.sum(), vs.sum())
+    assert n_free > 100 and n_clamped > 100, (n_free, n_clamped)
+    m.close()
+    for d in base:
+        d.close()
