@@ -358,9 +358,14 @@ __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_
     }
     const float Ep = fmaf(E, z, lo_plus);
     const float Em = same_lo ? Ep : fmaf(E, z, lo_minus);
+#ifdef ECC_POLY_UNFUSED_ODD  // rounds 1-3 and most of round 4: the odd part as a rounded product of its own (one instruction more)
     const float xo = x * O;
     plus = (Ep + xo) + c[0];
     minus = (Em - xo) + c[0];
+#else
+    plus = fmaf(x, O, Ep) + c[0];
+    minus = fmaf(-x, O, Em) + c[0];
+#endif
 }
 
 // Addressing, the one 16-byte load and the bilinear rule for a sample whose coordinates are already known.
@@ -448,6 +453,7 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
     // (s0 a0 - s1 a1)^2 = (a0 - s0 s1 a1)^2, and rounding is sign-symmetric -- so the four sign flips per trip become the sign
     // of one wave-uniform factor in the two differences (fma(a1, -+1, a0) is the rounded a0 -+ a1).
     const float rel_sign = (DERIV && ((fold[0] ^ fold[1]) & 0x80000000u)) ? 1.0f : -1.0f;
+    const float w06_dkappa = w06 * dkappa;
     float kf = (float)(lane + 64 * sub);
     for (int k = lane + 64 * sub; k < k_limit; k += 64 * WPP, kf += (float)(64 * WPP)) {
         const float kappa = dkappa * 0.5f + dkappa * kf;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
@@ -465,9 +471,16 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         const float v1m = sample_at<DERIV && CORR, PITCH4, NOCLAMP>(xa1m, yd1m, fold[1] ^ 0x80000000u, sv1, n_t_f, pitch4_f, xa_max);
         if (!CORR) {
             const float vp = fmaf(v1p, rel_sign, v0p), vm = fmaf(v1m, rel_sign, v0m);
+#ifdef ECC_POLY_UNFUSED_ODD
             const float consistency = (vp * vp + vm * vm) * w06;  // ref: ...RadonIntermediate.cu:112
-            if (WPP == 1) acc += (double)(consistency * dkappa);  // ref: ...RadonIntermediate.cu:269
-            else stage[k] = consistency * dkappa;
+            const float term = consistency * dkappa;              // ref: ...RadonIntermediate.cu:269
+#else
+            // the contracted form of the same two source lines (what nvcc emits for them): one fma, and the two wave-uniform
+            // factors as one -- the throughput path only; the per-sample and the reference loops keep every rounding
+            const float term = fmaf(vp, vp, vm * vm) * w06_dkappa;
+#endif
+            if (WPP == 1) acc += (double)term;
+            else stage[k] = term;
         } else {
             const float one_over_n = kappa_max / kappa;
             mom2 += (double)(one_over_n * (v0p * v0p + v0m * v0m));
