@@ -603,10 +603,10 @@ def main():
         blocks, last = [], None
         el, last = timed_block(step, 0)
         blocks.append(el)
-        # automatic: about 0.3 s of timed steps, at most 25 blocks -- the driver's 20-step blocks last 8 ms each and the clocks
+        # automatic: about 0.6 s of timed steps, 5 to 25 blocks -- the driver's 20-step blocks last 8 ms each and the clocks
         # of a box that idled through the host-side set-up take 5+ such blocks to settle (round 4: blocks 1-5 0.40-0.45 ms
         # per step, 6-9 0.364-0.370); the median of 9 sat on the ramp
-        n_blocks = args.blocks if args.blocks > 0 else int(min(25, max(3, 0.3 / max(el, 1e-6))))
+        n_blocks = args.blocks if args.blocks > 0 else int(min(25, max(5, 0.6 / max(el, 1e-6))))
         if world > 1:  # every rank must run the same number of blocks
             nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
             dist.broadcast(nb, 0)
