@@ -71,7 +71,7 @@ def parse():
                          "measures the pair kernel's HBM bytes and vector instructions for the roofline objects; the "
                          "committed profiles/pmc_current.json is used instead")
     ap.add_argument("--blocks", type=int, default=0,
-                    help="number of timed K-step blocks (0 = automatic: up to 25, about 0.3 s in total)")
+                    help="number of timed K-step blocks (0 = automatic: 5 to 25, about 0.6 s in total)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
