@@ -52,6 +52,26 @@ LDS_READ_B64_BYTES_PER_CLK_CU = 256.0   # ds_read_b64 / b128: 256 B/clk/CU
 VALU_CYCLES_PER_WAVE_INSTR = 2.0        # wave64 fp32 instruction on a SIMD-32: 2 cycles (4 for cvt/fract/f64, not modelled)
 
 
+_RESULT_STREAM = None
+
+
+def claim_stdout():
+    """The one JSON line is the only thing that may reach this process's stdout: libraries write there too (RCCL prints a
+    five-line version banner to stdout when rank 0 creates its communicator).  Keep a private handle on the original
+    stdout for emit() and point file descriptor 1 at stderr for everything else."""
+    global _RESULT_STREAM
+    if _RESULT_STREAM is None:
+        sys.stdout.flush()
+        _RESULT_STREAM = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    out = _RESULT_STREAM or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +100,14 @@ def parse():
                     help="rehearse only the launch: every rank joins the process group (gloo, no GPU touched), one all-reduce "
                          "checks the rank count, rank 0 prints one JSON line; ECC_BENCH_FAIL_RANK=r makes rank r die first "
                          "(tests/test_bench_launch.py)")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="internal: this run is the short child of live_pmc() under rocprofv3 -- no contracted-arithmetic stack, no "
+                         "metric tie (their two extra all-pairs launches would be averaged into the pair kernel's counters)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: run the N > 1 code path over a ONE-rank process group (RCCL with --backend nccl) -- the "
+                         "all-gather of the Radon-intermediate stack, ecc_metric_evaluate_range_async -> all-reduce of the "
+                         "device scalar -> publish_scalar_kernel -> poll per step, MAX-reduced block times: first contact of "
+                         "that path with RCCL on a one-GPU box (profiles/r05_bench_1rank_rccl.json)")
     ap.add_argument("--sweep-poses", action="store_true",
                     help="BASELINE config 5 instead of the per-step bench: the 600-point 6-DoF sweep of one view "
                          "(ref: Gui/Visualization.h:78-98), the POSES sharded round-robin over the ranks, every rank "
@@ -150,7 +178,7 @@ def live_pmc(args, counters=("FETCH_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD"))
     try:
         cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv",
                "-d", out_dir, "--", sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--blocks", "3",
-               "--no-cpu-baseline", "--no-live-pmc", "--views", str(args.views), "--size", str(args.size), "--bins", str(args.bins)]
+               "--no-cpu-baseline", "--no-live-pmc", "--pmc-child", "--views", str(args.views), "--size", str(args.size), "--bins", str(args.bins)]
         env = dict(os.environ, TMPDIR="/tmp")
         subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
         per, grids = {}, {}
@@ -297,16 +325,18 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
         oracle.build(native=True)
         host = [d.readback() for d in dtrs]
         errs = []
-        for p, k in ((0, 10), (4, 70), (5, 99)):
+        # one oracle point per swept parameter (">= 6 sampled sweep points")
+        for p, k in ((0, 10), (1, 35), (2, 88), (3, 5), (4, 70), (5, 99)):
             x = -ranges[p] + 2 * ranges[p] * k / 99.0
             Pk = [q.copy() for q in Ps]
             Pk[moving] = P0 @ geometry.rigid_transform(**{names[p]: x})
             ref = oracle.evaluate_all(Pk, host, S, S, native=True)["mean"]
             errs.append(abs(values[p, k] - ref) / abs(ref))
-        out["parity_rel_err_vs_oracle_at_3_points"] = errs
+        out["parity_rel_err_vs_oracle_at_6_points"] = errs
+        out["parity_points"] = "(parameter, step) = (tx,10) (ty,35) (tz,88) (rx,5) (ry,70) (rz,99): all pairs of the pose by oracle/"
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        emit(out)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -370,8 +400,8 @@ def launch_check(args, rank, world):
             raise SystemExit("all-reduce over %d ranks returned %r" % (world, probe.item()))
         seen = dist.get_world_size()
     if rank == 0:
-        print(json.dumps({"metric": "launch check (nothing measured)", "value": None, "n_gpus": world,
-                          "config": {"ranks_seen_by_collective_backend": seen, "launch_check": True}}))
+        emit({"metric": "launch check (nothing measured)", "value": None, "n_gpus": world,
+              "config": {"ranks_seen_by_collective_backend": seen, "launch_check": True}})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -383,6 +413,7 @@ def main():
         raise SystemExit("--gpus must be at least 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         self_launch(args)  # does not return
+    claim_stdout()
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%s: the job must have exactly --gpus ranks"
                          % (args.gpus, os.environ.get("WORLD_SIZE", "<unset>")))
@@ -405,14 +436,23 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if args.force_collective and world != 1:
+        raise SystemExit("--force-collective is the one-rank rehearsal of the N > 1 path: use it with --gpus 1")
+    grouped = world > 1 or args.force_collective  # a process group exists and every per-step sum goes through it
+    if grouped:
+        kw = {}
+        if world == 1 and "MASTER_ADDR" not in os.environ:  # one rank outside torchrun: a rendezvous of our own
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                kw = dict(init_method="tcp://127.0.0.1:%d" % sk.getsockname()[1], rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **kw)
 
     ranks_seen, devices_seen = 1, [torch.cuda.get_device_properties(dev).name + " #%d" % local_rank]
-    if world > 1:
+    if grouped:
         # the collective backend must see exactly the ranks the driver asked for, one device each
         if dist.get_world_size() != args.gpus or dist.get_rank() != rank:
             raise SystemExit("process group has %d ranks (this one %d), --gpus %d RANK %d" % (dist.get_world_size(), dist.get_rank(), args.gpus, rank))
@@ -465,15 +505,17 @@ def main():
     # the same stack in the contracted arithmetic (ecc_radon_set_arithmetic(ECC_RADON_FMA): positions fmaf(t, d, o), lerps
     # as one fma each; bit-identical to the oracle's contracted variant, tests/test_gpu_radon_fma.py).  The metric below is
     # evaluated on the EXACT stack; at N = 1 it is evaluated on this one too and the two means are compared.
-    slabs_fma = torch.zeros((hi - lo, slab), dtype=torch.float32, device=dev)
-    ctx.setRadonArithmetic("fma")
-    keep = E.RadonIntermediate.compute_into(ctx, imgs_all, slabs_fma, B, B)
-    ctx.synchronize()
-    ms_per_radon_fma = ctx.last_kernel_ms("radon") / max(hi - lo, 1)
-    ctx.setRadonArithmetic("exact")
+    slabs_fma, ms_per_radon_fma = None, 0.0
+    if not args.pmc_child:
+        slabs_fma = torch.zeros((hi - lo, slab), dtype=torch.float32, device=dev)
+        ctx.setRadonArithmetic("fma")
+        keep = E.RadonIntermediate.compute_into(ctx, imgs_all, slabs_fma, B, B)
+        ctx.synchronize()
+        ms_per_radon_fma = ctx.last_kernel_ms("radon") / max(hi - lo, 1)
+        ctx.setRadonArithmetic("exact")
     del keep, imgs_all
     if world > 1:
-        del slabs_fma
+        slabs_fma = None
     # pre-processing (the step in front of the Radon intermediate) on one sub-batch, device
     # resident in and out, reference defaults + cosine weighting: HBM-bound, 8 B per pixel algorithmic
     imgs = synthetic.projections_torch(Ps[lo:min(lo + sub, hi)], S, S, phantom, dev)
@@ -483,7 +525,7 @@ def main():
         pp.process(ctx, imgs, Ps[lo:min(lo + sub, hi)], out=pre_out)
     ms_per_preprocess = ctx.last_kernel_ms("preprocess") / imgs.shape[0]
     del imgs, pre_out
-    if world > 1:
+    if grouped:
         if args.backend == "nccl":
             gathered = torch.empty_like(slabs_all)
             dist.all_gather_into_tensor(gathered, local.contiguous())
@@ -503,7 +545,7 @@ def main():
         del keep, pimg, pslab
     dtrs = [E.RadonIntermediate.wrap_device(ctx, slabs_all[k], B, B, S, S) for k in range(n)]
     radon_tie = None
-    if world == 1:  # metric-level tie of the two Radon arithmetic modes on this very data set
+    if world == 1 and slabs_fma is not None:  # metric-level tie of the two Radon arithmetic modes on this very data set
         dtrs_fma = [E.RadonIntermediate.wrap_device(ctx, slabs_fma[k], B, B, S, S) for k in range(n)]
         m_fma = E.MetricRadonIntermediate(ctx, Ps, dtrs_fma)
         mean_fma = m_fma.evaluate()
@@ -546,7 +588,7 @@ def main():
 
     # N > 1: the per-evaluation exchange of the 8-byte partial sums
     exchange = None
-    if world > 1 and args.exchange in ("both", "shm"):
+    if grouped and args.exchange in ("both", "shm"):
         ok = True
         try:
             exchange = sharding.open_exchange(rank, world, dist.barrier)
@@ -565,7 +607,7 @@ def main():
     def make_step(mode):
         def step(k):
             metric.setProjectionMatrices(poses[k % len(poses)])
-            if world == 1:
+            if not grouped:
                 return metric.evaluate()
             if mode == "shm":
                 return sharding.exchanged_evaluate(metric, n, exchange, shard=(first, count))
@@ -576,7 +618,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -589,7 +631,7 @@ def main():
             last = step(k)
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if grouped:
             e = torch.tensor([el], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(e, op=dist.ReduceOp.MAX)
             el = e.item()
@@ -607,7 +649,7 @@ def main():
         # of a box that idled through the host-side set-up take 5+ such blocks to settle (round 4: blocks 1-5 0.40-0.45 ms
         # per step, 6-9 0.364-0.370); the median of 9 sat on the ramp
         n_blocks = args.blocks if args.blocks > 0 else int(min(25, max(5, 0.6 / max(el, 1e-6))))
-        if world > 1:  # every rank must run the same number of blocks
+        if grouped:  # every rank must run the same number of blocks
             nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
             dist.broadcast(nb, 0)
             n_blocks = int(nb.item())
@@ -618,7 +660,7 @@ def main():
         return dict(cold=blocks[0], steady=steady, blocks=blocks, last=last, step=step)
 
     ctx.enable_timing(False)  # no event records inside the timed region (they break back-to-back dispatch)
-    modes = ["single"] if world == 1 else (
+    modes = ["single"] if not grouped else (
         [m for m in ("shm", "collective") if (m != "shm" or exchange is not None)] if args.exchange == "both"
         else (["shm"] if args.exchange == "shm" and exchange is not None else ["collective"]))
     results = {m: measure(m) for m in modes}
@@ -704,7 +746,8 @@ def main():
                 "algorithmic_bytes_per_launch": launch_bytes, "roofs": roofs,
                 "hbm_compulsory_bytes": hbm_compulsory,
                 "traffic_over_compulsory": (traffic / hbm_compulsory) if traffic else None,
-                "l2_hit_rate": (live_tcc["TCC_HIT_sum"] / (live_tcc["TCC_HIT_sum"] + live_tcc["TCC_MISS_sum"])) if live_tcc else None,
+                "l2_hit_rate": (live_tcc["TCC_HIT_sum"] / (live_tcc["TCC_HIT_sum"] + live_tcc["TCC_MISS_sum"]))
+                if (live_tcc and live_tcc["TCC_HIT_sum"] + live_tcc["TCC_MISS_sum"] > 0) else None,
                 "l2_hit_rate_source": ("measured in this run: a second rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum pass over a child run "
                                        "of this bench, %d launches averaged" % live_tcc["dispatches"]) if live_tcc else None,
                 # SURVEY.md 8(d)'s figure against HBM peak: > 1 means the gather's reuse is captured on chip
@@ -785,7 +828,8 @@ def main():
                    # last step are kept (one view moves per step: 399 of 79 800 pairs are refitted, E1 of the moved view
                    # on the host, no e1_kernel launch); every pair is sampled; bit-identical results
                    "k01_record_reuse": "on (library default); the same run with it off under timing.record_reuse_off",
-                   "ranks_seen_by_collective_backend": ranks_seen, "devices": devices_seen},
+                   "ranks_seen_by_collective_backend": ranks_seen, "devices": devices_seen,
+                   "force_collective": bool(args.force_collective)},
         "timing": {"value_is": "median of %d blocks of %d steps" % (len(res["blocks"]), args.steps),
                    # round 1's definition of the headline: all timed steps of the run over all their time
                    "whole_run": {"ms_per_step": 1e3 * sum(res["blocks"]) / (args.steps * len(res["blocks"])),
@@ -855,6 +899,16 @@ def main():
                       % (reps, sub_pairs, args.cpu_sample_stride, sub_pairs, n_pairs, cpu_s),
         }
         out["parity_rel_err_vs_oracle_on_sample"] = abs(gpu_mean - ref["mean"]) / abs(ref["mean"])
+        if args.cpu_sample_stride == 1:
+            # the n x n cost image is what the reference hands its callers (ref: ...RadonIntermediate.cpp:214-221, plotted by
+            # Gui/Visualization.h:18-56): every single pair value of the timed path against the oracle's
+            _, gpu_pairs = metric.evaluate_range(0, n_pairs, want_pairs=True)
+            ref_pairs = np.asarray(ref["pairs"], np.float64)
+            rel = np.abs(gpu_pairs.astype(np.float64) - ref_pairs) / np.maximum(np.abs(ref_pairs), 1e-300)
+            out["pair_rel_err_max"], out["pair_rel_err_p99"], out["pair_rel_err_p50"] = (
+                float(rel.max()), float(np.percentile(rel, 99)), float(np.percentile(rel, 50)))
+            out["pair_rel_err_note"] = ("all %d pair values of the timed (polynomial) path vs oracle/; single values carry the fp32 "
+                                        "rounding of the sample positions (DESIGN.md 2), the mean averages it out" % n_pairs)
         # Radon baseline: 1/4 of the bins of one image
         img = synthetic.projections_numpy([Ps[n // 3]], S, S, phantom)[0]
         bins = np.arange(0, B * B, 4, dtype=np.int32)
@@ -863,8 +917,8 @@ def main():
         out["cpu_baseline"]["ms_per_radon_intermediate"] = 1e3 * (time.perf_counter() - t1) * 4
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        emit(out)
+    if grouped:
         dist.barrier()
         if exchange is not None:
             exchange.close()

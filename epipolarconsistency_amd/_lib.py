@@ -125,6 +125,11 @@ SIGNATURES = {
     "ecc_exchange_open": (_i, [C.c_char_p, _i, _i, C.POINTER(C.c_void_p)]),
     "ecc_exchange_sum": (_i, [_vp, _d, _pd]),
     "ecc_exchange_close": (_i, [_vp]),
+    "ecc_debug_set_poly_tolerance": (_i, [_vp, C.c_float]),
+    "ecc_debug_set_small_eval_bound": (_i, [_vp, _i64]),
+    "ecc_debug_set_result_polling": (_i, [_i]),
+    "ecc_debug_set_quad_copies": (_i, [_vp, _i]),
+    "ecc_debug_small_stamps": (_i, [_vp, _i]),
     "ecc_ctx_enable_timing": (_i, [_vp, _i]),
     "ecc_ctx_last_kernel_ms": (_i, [_vp, _i, _pf]),
 }

@@ -53,6 +53,11 @@ class Context:
         check(_lib.lib().ecc_ctx_last_kernel_ms(self._h, {"pairs": 0, "radon": 1, "preprocess": 2}[which], C.byref(ms)))
         return ms.value
 
+    def debugSetQuadCopies(self, on=True):
+        """ecc_debug_set_quad_copies (experiments): metrics created from this context afterwards build row-quad copies."""
+        check(_lib.lib().ecc_debug_set_quad_copies(self._h, 1 if on else 0))
+        return self
+
     def setRadonArithmetic(self, mode="exact"):
         """ecc_radon_set_arithmetic: "exact" (default; unfused fp32, bit-identical to the oracle's normative variant) or
         "fma" (contracted sampling loop, bit-identical to the oracle's contracted variant, ~25 % faster)."""
@@ -351,6 +356,8 @@ class MetricRadonIntermediate:
         self._sampling = 0 if d is None else (self._SAMPLING[d] if isinstance(d, str) else int(d))
         self._incremental = False
         self._record_reuse = None  # library default (on unless ECC_RECORD_REUSE=0)
+        self._small_eval = None    # library default (on)
+        self._debug = {}           # ecc_debug_* settings of this object (experiments), re-applied to a new handle
         # the optimiser loop's two calls, setProjectionMatrices + evaluate(): data pointers of the caller's (n, 12) arrays by
         # array object (ndarray.ctypes costs 1.2 us per call; the arrays are kept alive here, at most 1024 of them), and the
         # result cell of evaluate()
@@ -374,8 +381,31 @@ class MetricRadonIntermediate:
         check(_lib.lib().ecc_metric_set_incremental(self._h, int(self._incremental)))
         if self._record_reuse is not None:
             check(_lib.lib().ecc_metric_set_record_reuse(self._h, int(self._record_reuse)))
+        if self._small_eval is not None:
+            check(_lib.lib().ecc_metric_set_small_eval(self._h, int(self._small_eval)))
+        self._apply_debug()
         if self._Ps is not None:
             self.setProjectionMatrices(self._Ps)
+        return self
+
+    def _apply_debug(self):
+        if "poly_tolerance" in self._debug:
+            check(_lib.lib().ecc_debug_set_poly_tolerance(self._h, float(self._debug["poly_tolerance"])))
+        if "small_eval_bound" in self._debug:
+            check(_lib.lib().ecc_debug_set_small_eval_bound(self._h, int(self._debug["small_eval_bound"])))
+
+    def debugSetPolyTolerance(self, tol_bins):
+        """ecc_debug_set_poly_tolerance (experiments): economisation bound of the polynomial path in Radon bins."""
+        self._debug["poly_tolerance"] = float(tol_bins)
+        if self._h:
+            self._apply_debug()
+        return self
+
+    def debugSetSmallEvalBound(self, max_pairs):
+        """ecc_debug_set_small_eval_bound (experiments): size bound of the one-launch path, -1 = default."""
+        self._debug["small_eval_bound"] = int(max_pairs)
+        if self._h:
+            self._apply_debug()
         return self
 
     def getRadonIntermediates(self):
@@ -473,8 +503,12 @@ class MetricRadonIntermediate:
         return self
 
     def setSmallEval(self, on=True):
-        """ecc_metric_set_small_eval: evaluations of at most 4096 pairs as ONE launch (default on; bit-identical results)."""
-        check(_lib.lib().ecc_metric_set_small_eval(self._h, 1 if on else 0))
+        """ecc_metric_set_small_eval: evaluations of at most 192 pairs (ECC_SMALL_EVAL_MAX_PAIRS) as ONE launch, and E1 in
+        the record kernel's arguments for launches of at most 4096 pairs (default on; bit-identical results).  Kept
+        across setRadonIntermediates like the other settings."""
+        self._small_eval = 1 if on else 0
+        if self._h:
+            check(_lib.lib().ecc_metric_set_small_eval(self._h, self._small_eval))
         return self
 
     def last_evaluated_pairs(self):

@@ -60,17 +60,17 @@ hipError_t wait_stream_spin(hipStream_t stream)
 // consulted when the value does not show up, so a failed launch surfaces as an error instead of a hang.
 constexpr uint64_t ECC_RESULT_PENDING = 0x7ff8ecc0dead0001ull;
 
-bool result_polling_enabled()
-{
-    static const bool on = [] {
-        const char* e = std::getenv("ECC_RESULT_WAIT");  // "stream": wait for the stream instead (A/B measurements)
-        return !(e && std::strcmp(e, "stream") == 0);
-    }();
-    return on;
-}
+std::atomic<bool> g_result_polling{true};  // ecc_debug_set_result_polling(0): wait for the stream instead (A/B measurements)
+bool result_polling_enabled() { return g_result_polling.load(std::memory_order_relaxed); }
 
 void arm_result(ecc_metric* m)
 {
+    if (m->small_pending_count > 0) {
+        // a synchronous call enqueued a one-launch evaluation and failed before it collected the result: that kernel still
+        // stores its "done" word into this slot -- let it, before the slot is armed for the next evaluation
+        (void)hipStreamSynchronize(m->ctx->stream);
+        m->small_pending_count = 0;
+    }
     reinterpret_cast<volatile uint64_t*>(m->sum_h)[0] = ECC_RESULT_PENDING;
     std::atomic_thread_fence(std::memory_order_seq_cst);
 }
@@ -419,6 +419,19 @@ ECC_EXPORT int ecc_ctx_synchronize(ecc_ctx* ctx)
     return ECC_OK;
 }
 
+ECC_EXPORT int ecc_debug_set_result_polling(int on)
+{
+    g_result_polling.store(on != 0, std::memory_order_relaxed);
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on)
+{
+    if (!ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "context is null");
+    ctx->quad_copies = on != 0;
+    return ECC_OK;
+}
+
 ECC_EXPORT int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable)
 {
     if (!ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "ctx is null");
@@ -699,7 +712,7 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     if (!m) return fail(ECC_ERR_OUT_OF_MEMORY, "host allocation failed");
     m->ctx = ctx;
     {
-        const char* e = std::getenv("ECC_RECORD_REUSE");  // 0: off, 1: default, 2: for every size
+        const char* e = std::getenv("ECC_RECORD_REUSE");  // 0: off, 1: default, 2: for every size (include/ecc_hip.h, next to ecc_metric_set_record_reuse)
         if (e && e[0] >= '0' && e[0] <= '2') m->record_reuse = e[0] - '0';
     }
     m->dtrs.assign(dtrs, dtrs + n_dtrs);
@@ -736,11 +749,11 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) ptable[k] = m->paired_d + (size_t)paired_floats * k;
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->paired_table_d, ptable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
-    // row-quad copies: opt-in (ECC_QUAD_COPIES=1; 4x the slab memory, see pairs_kernel.hip); offsets must fit 32 bits
+    // row-quad copies: opt-in (ecc_debug_set_quad_copies on the context; 4x the slab memory, see pairs_kernel.hip); offsets
+    // must fit 32 bits
     std::vector<const float*> qtable(n_dtrs);
     m->quad_floats = (int64_t)((m->n_alpha + 1 + 3) / 4) * m->pitch * 16;
-    const char* quads_env = std::getenv("ECC_QUAD_COPIES");
-    const bool want_quads = m->quad_floats * 4 < ((int64_t)1 << 32) && quads_env && quads_env[0] == '1';
+    const bool want_quads = m->quad_floats * 4 < ((int64_t)1 << 32) && ctx->quad_copies;
     if (e == hipSuccess && want_quads) {
         e = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
         if (e == hipSuccess) e = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);

@@ -39,7 +39,7 @@ extern "C" hipError_t ecc_launch_build_quad(const float* const* slabs_tbl_d, flo
 extern "C" hipError_t ecc_launch_k01(const EccPairParams* p, hipStream_t stream);
 extern "C" hipError_t ecc_launch_k01_patched(const EccPairParams* p, const EccSmallEval* x, hipStream_t stream);
 extern "C" hipError_t ecc_launch_pairs(const EccPairParams* p, hipStream_t stream);
-extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds_bytes);
+extern "C" int ecc_small_eval_plan(const EccPairParams* p, long long forced_bound, int* wpp, size_t* lds_bytes);
 extern "C" hipError_t ecc_launch_small_eval(const EccPairParams* p, const EccSmallEval* x, hipStream_t stream);
 extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStream_t stream);
 extern "C" size_t ecc_preprocess_lds_bytes(int k);
@@ -91,6 +91,7 @@ struct ecc_ctx {
     hipStream_t stream = nullptr;
     bool timing = false;
     int radon_arithmetic = ECC_RADON_EXACT;  // ecc_radon_set_arithmetic
+    bool quad_copies = false;                // ecc_debug_set_quad_copies: metrics created from this context build row-quad copies
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pair, radon, preprocess start/stop
     bool ev_valid[3] = {false, false, false};
     // trig table cache for the Radon kernel
@@ -224,6 +225,8 @@ struct ecc_metric {
     // E1 of the views whose matrix changed since the device arrays were made is done on the host and handed over in the
     // kernel arguments (dev_Ps above says which views those are).
     int small_eval = 1;
+    int64_t small_max_pairs = -1;  // ecc_debug_set_small_eval_bound: >= 0 replaces the one-launch path's own size bound
+    float economise_tol = ECC_POLY_ECONOMISE_TOL_BINS;  // ecc_debug_set_poly_tolerance
     int32_t* sidx_h = nullptr;    // index list of a fused index-list evaluation (pinned, device-mapped)
     int32_t* sidx_h_dev = nullptr;
     int64_t sidx_capacity = 0;    // pairs

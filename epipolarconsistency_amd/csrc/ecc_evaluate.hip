@@ -72,13 +72,7 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool n
     p->wide_offsets = ((int64_t)(m->n_alpha + 1) * m->pitch * 8 >= (int64_t)1 << 24) ? 1 : 0;
     p->quads = m->quads_table_d;
     p->quad_group_bytes = (unsigned)m->pitch * 64u;
-    {
-        static const float tol = [] {
-            const char* e = std::getenv("ECC_POLY_TOL");  // experiments only
-            return e ? (float)std::atof(e) : 2e-8f;
-        }();
-        p->economise_tol = tol;
-    }
+    p->economise_tol = m->economise_tol;  // ECC_POLY_ECONOMISE_TOL_BINS unless ecc_debug_set_poly_tolerance changed it
     return ECC_OK;
 }
 
@@ -133,6 +127,41 @@ int ensure_small_host_buffers(ecc_metric* m, int64_t idx_pairs, int64_t value_pa
 }
 constexpr unsigned long long ECC_SMALL_DONE_TOKEN = 0x7ff8ecc0d04e0001ull;  // a NaN payload: not a sum, not ECC_RESULT_PENDING
 
+// The pair values a kernel hands to the host through pinned memory (small_eval_kernel: one system-scope store per
+// workgroup; sum_pairs_kernel with values_host) are ordered in front of the word the host polls by the device's own
+// drains and barriers, not by anything the HIP memory model promises across workgroups.  So the hand-over checks itself:
+// the host arms every slot it expects with a NaN payload no kernel stores, and after the polled word has arrived it
+// accepts the values only once no slot is armed any more (bounded wait, then an error -- never a stale value).
+constexpr uint32_t ECC_VALUE_ARMED = 0x7fc0ecc1u;
+void arm_values(ecc_metric* m, int64_t count)
+{
+    volatile uint32_t* v = reinterpret_cast<volatile uint32_t*>(m->svals_h);
+    for (int64_t k = 0; k < count; ++k) v[k] = ECC_VALUE_ARMED;
+}
+hipError_t wait_values(ecc_metric* m, int64_t count)
+{
+    const volatile uint32_t* v = reinterpret_cast<const volatile uint32_t*>(m->svals_h);
+    double t0 = 0.0;
+    int64_t k = 0;
+    for (unsigned spins = 0;; ++spins) {
+        while (k < count && v[k] != ECC_VALUE_ARMED) ++k;
+        if (k == count) break;
+        if ((spins & 0xff) == 0xff) {
+            const double t = pose_now();
+            if (t0 == 0.0) t0 = t;
+            else if (t - t0 > 2.0) {
+                const hipError_t e = hipStreamSynchronize(m->ctx->stream);
+                if (e != hipSuccess) return e;
+                for (k = 0; k < count; ++k)
+                    if (v[k] == ECC_VALUE_ARMED) return hipErrorUnknown;  // the kernel has ended and a value never arrived
+                break;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return hipSuccess;
+}
+
 // The float64 sum of `count` <= 4096 pair values exactly as sum_pairs_kernel forms it (pairs_kernel.hip; ref:
 // ...RadonIntermediate.cpp:216-224): thread t of its 1024 holds ((0 + v[4t]) + (0 + v[4t+1])) + ((0 + v[4t+2]) + (0 + v[4t+3]))
 // (one float4 at most for such a count), thread 0 then adds the up to three values past the last float4, the 64 threads
@@ -172,7 +201,8 @@ hipError_t wait_small_eval(ecc_metric* m, int64_t count, double* sum)
     unsigned long long bits;
     std::memcpy(&bits, &token, sizeof(bits));
     if (bits != ECC_SMALL_DONE_TOKEN) return hipErrorUnknown;  // the kernel found its argument views inconsistent
-    std::atomic_thread_fence(std::memory_order_acquire);
+    const hipError_t ev = wait_values(m, count);
+    if (ev != hipSuccess) return ev;
     *sum = small_sum_on_host(m->svals_h, count);
     return hipSuccess;
 }
@@ -191,8 +221,11 @@ hipError_t wait_sum(ecc_metric* m, double* sum)
 // the device is behind the current matrices go into x->patch_*, computed here with the code e1_kernel compiles
 // (ecc_host_geometry.h, bit-identical; ref: ...RadonIntermediate.cpp:134-163); more than ECC_SMALL_PATCH_MAX of them (the
 // first call, a new trajectory): e1_kernel, ordered before the launch, and x->patch_count stays 0.
-int small_eval_patches(ecc_metric* m, EccSmallEval* x)
+// The host's view of the device arrays (dev_Ps, e1_pending) is NOT updated here: the caller calls commit_patches once the
+// launch that stores the patches has been enqueued -- a failure in between must leave the views marked stale.
+int small_eval_patches(ecc_metric* m, EccSmallEval* x, bool* from_host)
 {
+    *from_host = false;
     const int n = m->n_views;
     const double* Pcur = m->Ps_h[m->set_generation & 1];
     std::vector<int>& stale = m->scratch_stale;
@@ -207,11 +240,22 @@ int small_eval_patches(ecc_metric* m, EccSmallEval* x)
         ecc_host::pinv_transpose(Pcur + 12 * v, x->patch_geo[e]);
         ecc_host::source_position(Pcur + 12 * v, x->patch_geo[e] + 12);
         x->patch_views[e] = v;
-        std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);  // workgroup 0 stores the entry
     }
     x->patch_count = (int)stale.size();
-    m->e1_pending = false;
+    *from_host = true;
     return ECC_OK;
+}
+
+// After the launch that carries x's patches is in the stream: workgroup 0 of it stores the entries into PinvTs_d / Cs_d.
+void commit_patches(ecc_metric* m, const EccSmallEval& x, bool from_host)
+{
+    if (!from_host) return;  // (E1 went through ensure_e1, which keeps its own books)
+    const double* Pcur = m->Ps_h[m->set_generation & 1];
+    for (int e = 0; e < x.patch_count; ++e) {
+        const int v = x.patch_views[e];
+        std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
+    }
+    m->e1_pending = false;
 }
 
 // k01 over p on the context's stream, E1 included: small launches (8 lanes per fit) of a metric with the one-launch path on
@@ -222,7 +266,8 @@ int launch_k01_with_e1(ecc_metric* m, const EccPairParams& p)
     if (m->small_eval && p.count > 0 && p.count <= ECC_K01_WIDE_MAX_PAIRS && !p.patch_count) {
         EccSmallEval x;
         std::memset(&x, 0, sizeof(x));
-        const int rc = small_eval_patches(m, &x);
+        bool from_host = false;
+        const int rc = small_eval_patches(m, &x, &from_host);
         if (rc) return rc;
         m->eager_e1 = false;  // the views that change next are patched by the next launch
         EccPairParams q = p;
@@ -230,6 +275,7 @@ int launch_k01_with_e1(ecc_metric* m, const EccPairParams& p)
         q.Cs = m->Cs_d;
         if (x.patch_count > 0) HIP_TRY(ecc_launch_k01_patched(&q, &x, m->ctx->stream));
         else HIP_TRY(ecc_launch_k01(&q, m->ctx->stream));
+        commit_patches(m, x, from_host);
         return ECC_OK;
     }
     const int rc = ensure_e1(m);
@@ -243,7 +289,7 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, boo
     *taken = false;
     int wpp = 0;
     size_t lds = 0;
-    if (!m->small_eval || !ecc_small_eval_plan(&p, &wpp, &lds)) return ECC_OK;
+    if (!m->small_eval || !ecc_small_eval_plan(&p, m->small_max_pairs, &wpp, &lds)) return ECC_OK;
 
     ecc_ctx* ctx = m->ctx;
     if (!m->small_ticket_d) {
@@ -252,8 +298,9 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, boo
     }
     EccSmallEval x;
     std::memset(&x, 0, sizeof(x));
+    bool patches_from_host = false;
     {
-        const int rcp = small_eval_patches(m, &x);
+        const int rcp = small_eval_patches(m, &x, &patches_from_host);
         if (rcp) return rcp;
     }
     p.PinvTs = m->PinvTs_d;
@@ -272,17 +319,21 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, boo
     // the "done" word: the metric's pinned result slot, armed by the caller; the token is never a value a sum kernel stores
     x.done_out = reinterpret_cast<unsigned long long*>(m->sum_h_dev);
     x.done_token = ECC_SMALL_DONE_TOKEN;
-    static unsigned long long* dbg_d = [] {  // experiments only: ECC_SMALL_DEBUG=1, read back by ecc_debug_small_stamps
+#ifdef ECC_SMALL_STAMPS  // experiment builds only (scripts/exp_small_phases.py): stamps read back by ecc_debug_small_stamps
+    static unsigned long long* dbg_d = [] {
         unsigned long long* d = nullptr;
-        if (std::getenv("ECC_SMALL_DEBUG")) (void)hipMalloc((void**)&d, sizeof(unsigned long long) * 4 * 4096);
+        (void)hipMalloc((void**)&d, sizeof(unsigned long long) * 4 * 4096);
         return d;
     }();
     x.dbg = dbg_d;
     g_small_dbg = dbg_d;
+#endif
 
+    arm_values(m, p.count);
     std::atomic_thread_fence(std::memory_order_seq_cst);  // the host's writes to pinned memory before the doorbell
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     HIP_TRY(ecc_launch_small_eval(&p, &x, ctx->stream));
+    commit_patches(m, x, patches_from_host);
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         ctx->ev_valid[0] = true;
@@ -881,6 +932,10 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     }
     arm_result(m);
     if (pinned) {
+        if (out) {
+            arm_values(m, n_pairs);
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+        }
         HIP_TRY(ecc_launch_sum_pairs_to_host(m->pair_values_d, n_pairs, m->sum_h_dev, out ? m->svals_h_dev : nullptr, ctx->stream));
     } else {
         HIP_TRY(ecc_launch_sum_pairs(m->pair_values_d, n_pairs, m->sum_h_dev, m->sum_scratch_d, ctx->stream));
@@ -892,7 +947,7 @@ ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int
     double sum = 0.0;
     HIP_TRY(wait_result(m, ctx->stream, &sum));
     if (pinned && out) {
-        std::atomic_thread_fence(std::memory_order_acquire);
+        HIP_TRY(wait_values(m, n_pairs));
         std::memcpy(out, m->svals_h, sizeof(float) * (size_t)n_pairs);
     }
     m->done_generation = m->set_generation;
@@ -1004,7 +1059,25 @@ ECC_EXPORT int ecc_metric_debug_polynomials(ecc_metric* m, int64_t first, int64_
     return ECC_OK;
 }
 
-/* Experiments (ECC_SMALL_DEBUG=1): the wall-clock stamps (100 MHz) of the last small_eval_kernel launch, 4 per workgroup. */
+// ---- experiment hooks (include/ecc_hip.h, last section): nothing of this kind is read from the environment ----------
+ECC_EXPORT int ecc_debug_set_poly_tolerance(ecc_metric* m, float tol_bins)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    if (!(tol_bins >= 0.f) || tol_bins > 1.f) return fail(ECC_ERR_INVALID_ARGUMENT, "tolerance outside [0, 1] bins");
+    m->economise_tol = tol_bins;
+    m->rec_valid = false;    // the kept records and values were made with the old tolerance
+    m->cache_valid = false;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_debug_set_small_eval_bound(ecc_metric* m, int64_t max_pairs)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    m->small_max_pairs = max_pairs < 0 ? -1 : max_pairs;
+    return ECC_OK;
+}
+
+/* Builds with -DECC_SMALL_STAMPS only: the wall-clock stamps (100 MHz) of the last small_eval_kernel launch, 4 per workgroup. */
 ECC_EXPORT int ecc_debug_small_stamps(unsigned long long* out, int n_blocks)
 {
     if (!g_small_dbg || !out || n_blocks < 1 || n_blocks > 4096) return ECC_ERR_INVALID_ARGUMENT;

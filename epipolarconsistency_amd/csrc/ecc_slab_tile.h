@@ -331,8 +331,12 @@ __device__ __forceinline__ void walk(Shared& sh, const float* __restrict__ img, 
             if (with_band && t <= t_end) {
                 // Both end points of the run inside the slab's admissible region => every sample's footprint is in the
                 // tile (the region is convex and positions are linear in t; .03 / .01 px cover the fp32 rounding of
-                // o + t * d).  f, s >= .5 keeps the tile index non-negative.
+                // o + t * d).  f, s >= .5 keeps the tile index non-negative; the guard carries a margin (GUARD = .5 + 1e-3)
+                // because the end points are evaluated unfused here while the contracted mode samples at fmaf(t, d, o): a
+                // fused position may round just below an unfused end point (a failing run only takes the global-memory
+                // path -- same arithmetic, same bits).
                 bool ok = true;
+                constexpr float GUARD = .5f + 1e-3f;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float te = e ? t_end : t;
@@ -340,12 +344,12 @@ __device__ __forceinline__ void walk(Shared& sh, const float* __restrict__ img, 
                     {
                         const float fa = A_OFFSET ? f + af : f, sa = A_OFFSET ? s + as : s;
                         const float g = fa - bf.beta * sa;
-                        ok = ok && g >= cur.Glo && g <= cur.Ghi && sa >= cur.slo && sa <= cur.shi && fa >= .5f && sa >= .5f;
+                        ok = ok && g >= cur.Glo && g <= cur.Ghi && sa >= cur.slo && sa <= cur.shi && fa >= GUARD && sa >= GUARD;
                     }
                     if (TWO) {
                         const float fb = f + ef, sb = s + es;
                         const float g = fb - bf.beta * sb;
-                        ok = ok && g >= cur.Glo && g <= cur.Ghi && sb >= cur.slo && sb <= cur.shi && fb >= .5f && sb >= .5f;
+                        ok = ok && g >= cur.Glo && g <= cur.Ghi && sb >= cur.slo && sb <= cur.shi && fb >= GUARD && sb >= GUARD;
                     }
                 }
                 if (ok) {

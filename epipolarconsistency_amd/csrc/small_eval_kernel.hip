@@ -174,9 +174,9 @@ __global__ __launch_bounds__(REF ? 1024 : 256, ECC_SMALL_MIN_WAVES) void small_e
 
 // Host-side plan of the launch: waves per pair by evaluation size, LDS for the staged terms.  Returns 0 when the
 // evaluation cannot take this path (the caller falls back to the stream-ordered launches).
-extern "C" int ecc_small_eval_plan(const EccPairParams* p, int* wpp, size_t* lds_bytes)
+extern "C" int ecc_small_eval_plan(const EccPairParams* p, long long forced_bound, int* wpp, size_t* lds_bytes)
 {
-    static const long long forced_bound = [] { const char* e = std::getenv("ECC_SMALL_MAX_PAIRS"); return e ? std::atoll(e) : -1ll; }();  // experiments
+    // forced_bound >= 0: ecc_debug_set_small_eval_bound (experiments)
     const long long bound = forced_bound >= 0 ? forced_bound : ECC_SMALL_EVAL_PAIR_BOUND(p->k_limit);
     if (p->count < 1 || p->count > bound || p->count > ECC_SMALL_EVAL_MAX_PAIRS || p->use_corr || p->K01_out || p->record_slots || p->value_slots ||
         p->patch_count || p->skip_enabled)
@@ -201,7 +201,7 @@ extern "C" hipError_t ecc_launch_small_eval(const EccPairParams* p, const EccSma
 {
     int wpp = 0;
     size_t lds = 0;
-    if (!ecc_small_eval_plan(p, &wpp, &lds)) return hipErrorInvalidValue;
+    if (!ecc_small_eval_plan(p, p->count, &wpp, &lds)) return hipErrorInvalidValue;  // (the caller has applied its size bound)
     EccSmallEval xx = *x;
     xx.stage_stride = (p->k_limit + 63) & ~63;
     xx.magic = ECC_SMALL_MAGIC;

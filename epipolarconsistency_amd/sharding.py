@@ -41,7 +41,10 @@ def allreduce_mean(partial_sum_tensor, n_pairs, group=None, metric=None):
     context's stream), the reduced value comes back through the metric's pinned result slot (a one-thread kernel queued
     behind the collective + a poll) instead of tensor.item() (a device-to-host copy command and its synchronisation)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # whenever a process group exists the sum goes through its collective, a one-rank group included: that is the form in
+    # which the RCCL path (all-reduce kernel -> publish_scalar_kernel, stream-ordered behind the pair kernel) can be run
+    # and checked on a single GPU (tests/test_gpu_rccl_one_rank.py, bench.py --force-collective)
+    if dist.is_available() and dist.is_initialized():
         if partial_sum_tensor.is_cuda and dist.get_backend(group) == "gloo":
             host = partial_sum_tensor.cpu()  # gloo rehearsal of the GPU path: reduce through host memory
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -142,7 +145,7 @@ def gather_cost_image(pair_values, n_views, rank, world, group=None, cost=None):
     counts = [pair_range(r, world, n_pairs)[1] for r in range(world)]
     mine = torch.zeros(max(counts), dtype=torch.float32)
     mine[:counts[rank]] = torch.from_numpy(np.ascontiguousarray(pair_values, np.float32))
-    if world > 1 and dist.is_initialized():
+    if dist.is_initialized():  # (a one-rank group too: the RCCL all-gather then runs on the one GPU there is)
         on_gpu = dist.get_backend(group) == "nccl"
         if on_gpu:
             mine = mine.cuda()

@@ -56,13 +56,14 @@ int ecc_version(void);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int ecc_device_count(void);
 
-/* Environment variables the library reads (all optional; none changes a result):
- *   ECC_RECORD_REUSE = 0 | 1 | 2   default of ecc_metric_set_record_reuse for new metrics
- *   ECC_RESULT_WAIT = stream       wait for the stream instead of polling the pinned result slot (A/B measurements)
- *   ECC_QUAD_COPIES = 1            metrics also build row-quad copies of their Radon intermediates (4x the memory)
- *   ECC_EXCHANGE_TIMEOUT_S         time-out of ecc_exchange_sum
- *   ECC_HIP_DEVICES                (C++ adapter) devices of the process-wide default group
- *   ECC_POLY_TOL, ECC_SMALL_DEBUG  experiments only */
+/* Environment variables the library reads -- two, both optional, neither changes a result; each is described next to
+ * the entry point it affects:
+ *   ECC_RECORD_REUSE = 0 | 1 | 2   default of ecc_metric_set_record_reuse for new metrics   (see ecc_metric_set_record_reuse)
+ *   ECC_EXCHANGE_TIMEOUT_S         time-out of ecc_exchange_sum in seconds, default 60      (see ecc_exchange_open)
+ * (the header-only C++ adapter additionally reads ECC_HIP_DEVICES: the devices of its process-wide default group).
+ * Experiment hooks are explicit calls (ecc_debug_*, last section of this header), never environment variables: the
+ * variables of earlier versions -- ECC_POLY_TOL, ECC_SMALL_MAX_PAIRS, ECC_SMALL_DEBUG, ECC_RESULT_WAIT, ECC_QUAD_COPIES --
+ * are ignored (tests/test_gpu_env_hooks.py). */
 
 /* ---- context ------------------------------------------------------------------------------ */
 /* `stream` is a hipStream_t (may be NULL = the device's default stream).  All launches and
@@ -532,6 +533,26 @@ int ecc_exchange_close(ecc_exchange* ex);
  * Timing is off by default (no events recorded); enable with ecc_ctx_enable_timing. */
 int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable);
 int ecc_ctx_last_kernel_ms(ecc_ctx* ctx, int which, float* ms);
+
+/* ---- experiment hooks (not part of the drop-in surface) ------------------------------------------ */
+/* What scripts/ uses for A/B measurements.  Explicit calls on a handle, so that nothing outside the caller's code can
+ * change the arithmetic of an evaluation.
+ * ecc_debug_set_poly_tolerance: the bound (in Radon bins) on what lowering a pair's polynomial degree may cost in
+ *   ECC_SAMPLING_POLYNOMIAL (DESIGN.md 4.2 "economise"); default ECC_POLY_ECONOMISE_TOL_BINS.  Changes pair values at the
+ *   1e-7 level; drops the kept records / values.
+ * ecc_debug_set_small_eval_bound: max_pairs >= 0 lowers the size bound of the one-launch path (192 pairs; 0 = never taken,
+ *   the path's other conditions still apply); -1 restores the default.  Same bits either way.
+ * ecc_debug_set_result_polling: process-wide; 0 = synchronous calls wait for the stream instead of polling the pinned
+ *   result slot.  Same bits.
+ * ecc_debug_set_quad_copies: metrics created from ctx AFTERWARDS also build row-quad copies of their Radon intermediates
+ *   (4x the slab memory) for the pairs with kappa_max > pi/4.  Same bits.
+ * ecc_debug_small_stamps: only in builds with -DECC_SMALL_STAMPS (returns ECC_ERR_INVALID_ARGUMENT otherwise). */
+#define ECC_POLY_ECONOMISE_TOL_BINS 2e-8f
+int ecc_debug_set_poly_tolerance(ecc_metric* m, float tol_bins);
+int ecc_debug_set_small_eval_bound(ecc_metric* m, int64_t max_pairs);
+int ecc_debug_set_result_polling(int on);
+int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on);
+int ecc_debug_small_stamps(unsigned long long* out, int n_blocks);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 """Time of ONE launch over exactly the pairs on the per-sample path of the BASELINE workload (the kappa_max = pi/2 pairs, in
-their natural order), with the row-paired copies and with the row-quad copies (ECC_QUAD_COPIES=1): what a second,
+their natural order), with the row-paired copies and with the row-quad copies (Context.debugSetQuadCopies): what a second,
 heavy-only launch after a main launch that skips them would cost.  python scripts/exp_heavy_alone.py"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,7 @@ for a in range(0, n, 50):
 out = {}
 for quads in (0, 1):
     if quads:
-        os.environ["ECC_QUAD_COPIES"] = "1"
+        ctx.debugSetQuadCopies(True)
     m = E.MetricRadonIntermediate(ctx, Ps, dtrs).setSampling("polynomial")
     deg = np.concatenate([[p["degree"] for p in m.debug_polynomials(a, min(10000, 79800 - a))] for a in range(0, 79800, 10000)])
     iu = np.triu_indices(n, 1)

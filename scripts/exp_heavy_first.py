@@ -1,6 +1,6 @@
 """Experiment: does the ORDER in which the kappa_max = pi/2 pairs are dispatched matter?  All 79 800 pairs of the BASELINE
 workload as an index list in (a) natural get_ij order, (b) heavy pairs first, (c) heavy pairs last, (d) heavy pairs spread
-evenly.  Kernel time by HIP events.  ECC_QUAD_COPIES=1 to combine with the row-quad copies."""
+evenly.  Kernel time by HIP events.  QUADS=1 in the environment of this script to combine with the row-quad copies (Context.debugSetQuadCopies)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,6 +11,8 @@ dev = torch.device("cuda", 0)
 Ps = synthetic.short_scan(n, S, S, 0.308)
 ph = synthetic.sphere_phantom()
 ctx = E.Context(0)
+if os.environ.get("QUADS") == "1":
+    ctx.debugSetQuadCopies(True)
 slabs = torch.zeros((n, E.slab_floats(B, B)), dtype=torch.float32, device=dev)
 dtrs = []
 for a in range(0, n, 50):
@@ -39,7 +41,7 @@ posw = np.concatenate([w * nblk + np.arange(hb) for w in range(4)])[:H]
 mask = np.zeros(N, bool); mask[posw] = True
 wg = np.empty(N, np.int64); wg[mask] = nat[heavy]; wg[~mask] = nat[~heavy]
 orders["heavy_first_whole_workgroups"] = wg
-out = {"heavy_pairs": H, "quad_copies": os.environ.get("ECC_QUAD_COPIES", "0")}
+out = {"heavy_pairs": H, "quad_copies": os.environ.get("QUADS", "0")}
 vals = np.empty(N, np.float32)
 ref = None
 for name, o in orders.items():

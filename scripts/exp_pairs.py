@@ -1,5 +1,5 @@
 """Pair-kernel experiments on the BASELINE workload: kernel time (HIP events), step time and parity of the mean against
-the oracle, for the library as currently built / configured (environment: ECC_POLY_TOL).  python scripts/exp_pairs.py [tag]"""
+the oracle, for the library as currently built / configured (POLY_TOL in this script's environment -> MetricRadonIntermediate.debugSetPolyTolerance).  python scripts/exp_pairs.py [tag]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,6 +18,8 @@ for a in range(0, n, 50):
     dtrs += E.RadonIntermediate.compute_into(ctx, imgs, slabs[a:a + 50], B, B)
     ctx.synchronize()
 m = E.MetricRadonIntermediate(ctx, Ps, dtrs)
+if os.environ.get("POLY_TOL"):
+    m.debugSetPolyTolerance(float(os.environ["POLY_TOL"]))
 P = E.pack_projection_matrices(Ps)
 for _ in range(100):
     m.setProjectionMatrices(P).evaluate()

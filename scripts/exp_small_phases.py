@@ -1,9 +1,8 @@
 """Phase time-line of small_eval_kernel (experiments; needs a library built with -DECC_SMALL_STAMPS -- python -c "from
-epipolarconsistency_amd import build; build.build_library(force=True, extra_flags=['-DECC_SMALL_STAMPS'])" -- and ECC_SMALL_DEBUG=1;
+epipolarconsistency_amd import build; build.build_library(force=True, extra_flags=['-DECC_SMALL_STAMPS'])";
 the stamps cost registers (occupancy 3 instead of 5), so launches of more than 768 workgroups run in two rounds here): wall-clock stamps (100 MHz) per workgroup --
 start, records done (phase A), value stored (phase B), and for the last arriver the sum stored."""
 import ctypes as C, os, sys
-os.environ["ECC_SMALL_DEBUG"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import epipolarconsistency_amd as E

@@ -82,16 +82,18 @@ def test_reference_mode_variants(gpu_ctx, oracle_mod, small_scan):
     m.close()
 
 
-def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan, monkeypatch):
-    """Opt-in row-quad copies (ECC_QUAD_COPIES=1 at metric creation): the pairs with kappa_max > pi/4 on the per-sample
+def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan):
+    """Opt-in row-quad copies (ecc_debug_set_quad_copies on the context before the metric is created): the pairs with kappa_max > pi/4 on the per-sample
     path sample them instead of the row-paired copies -- the same taps, the same arithmetic, identical values; also
     after refreshRadonIntermediates()."""
     import epipolarconsistency_amd as E
     s = small_scan
     m0, _ = _metric(gpu_ctx, s)
-    monkeypatch.setenv("ECC_QUAD_COPIES", "1")
-    m1, dtrs1 = _metric(gpu_ctx, s)
-    monkeypatch.delenv("ECC_QUAD_COPIES")
+    gpu_ctx.debugSetQuadCopies(True)
+    try:
+        m1, dtrs1 = _metric(gpu_ctx, s)
+    finally:
+        gpu_ctx.debugSetQuadCopies(False)
     K = m0.debug_K01(0, 28)
     assert (K[:, 15] > np.pi / 4).sum() >= 3, "the scan needs pairs with kappa_max > pi/4 for this test"
     for mode in ("per_sample", "polynomial"):
