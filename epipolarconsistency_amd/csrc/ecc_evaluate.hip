@@ -256,6 +256,7 @@ void commit_patches(ecc_metric* m, const EccSmallEval& x, bool from_host)
         std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
     }
     m->e1_pending = false;
+    m->dev_gen = m->set_generation;  // the patch list was every view whose geometry on the device was behind
 }
 
 // k01 over p on the context's stream, E1 included: small launches (8 lanes per fit) of a metric with the one-launch path on
@@ -399,17 +400,26 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                            m->rec_dkappa == p.dkappa_user && m->rec_tol == p.economise_tol && (int64_t)m->rec_Ps.size() == 12 * n;
     m->rec_valid = false;  // until everything below is enqueued
     bool pairs_launched = false;
+    ecc_stamp(m, 3);
+    m->stamps[4] = m->stamps[5] = 0.0;
     if (rec_match) {
         std::vector<int>& changed = m->scratch_changed;
-        changed.clear();
-        for (int64_t v = 0; v < n; ++v)
-            if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
+        std::vector<int>& patched = m->scratch_patched;
+        const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * n;
+        // the optimiser's pattern -- records and device geometry both belong to the matrices of the set call before this
+        // one: what changed is what ecc_metric_set_projections saw while staging (no pass over the matrices here)
+        const bool from_set = dev_known && m->set_changed_valid && m->rec_gen != 0 && m->rec_gen + 1 == m->set_generation &&
+                              m->dev_gen + 1 == m->set_generation;
+        if (from_set) changed = m->set_changed;
+        else {
+            changed.clear();
+            for (int64_t v = 0; v < n; ++v)
+                if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
+        }
         // views whose geometry on the device is not that of the current matrices although their records are (an E1 launch
         // or a patch list of another call in between): they need a patch entry too, but no refit
-        std::vector<int>& patched = m->scratch_patched;
         patched = changed;
-        const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * n;
-        if (dev_known) {
+        if (dev_known && !from_set) {
             for (int64_t v = 0; v < n; ++v)
                 if (std::memcmp(Pcur + 12 * v, m->dev_Ps.data() + 12 * v, sizeof(double) * 12) != 0 &&
                     std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) == 0)
@@ -437,9 +447,16 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                     split = false;
                 }
             }
+            bool forked = false;
             if (split) {
-                // whatever the caller queued on the context's stream before this call comes first for the side stream too
-                HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
+                // whatever the caller queued on the context's stream before this call comes first for the side stream too --
+                // unless that stream is idle (a synchronous caller's usual state: its last evaluation has returned): then
+                // there is nothing to order against and the event record + wait are saved
+                forked = hipStreamQuery(ctx->stream) != hipSuccess;
+                if (forked) {
+                    (void)hipGetLastError();  // hipErrorNotReady is not an error
+                    HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
+                }
                 EccPairParams pa = p;
                 pa.skip_enabled = 1;
                 for (int v : changed) pa.skip_mask[v >> 5] |= 1u << (v & 31);
@@ -450,6 +467,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                     ctx->ev_valid[0] = true;
                 }
                 pairs_launched = true;
+                ecc_stamp(m, 4);
             }
             std::vector<char>& is_changed = m->scratch_is_changed;
             std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots, &refs = m->scratch_refs, &patch_of = m->scratch_patch_of;
@@ -515,7 +533,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             HIP_TRY(_s);                                                      \
         }                                                                     \
     } while (0)
-                if (split) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
+                if (split && forked) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
                 SIDE_TRY(ecc_launch_k01(&q, ks));
                 if (split) {  // the changed pairs' own launch: records and values in their slots
                     q.pair_values = pair_values_d;
@@ -534,6 +552,10 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 for (int v : changed) std::memcpy(m->rec_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
                 for (int v : patched) std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
                 m->e1_pending = false;  // workgroup 0 of the list launch stores the patches: PinvTs / Cs are current again
+                m->rec_gen = m->dev_gen = m->set_generation;  // every view of both now belongs to the current matrices
+            } else if (changed.empty()) {
+                m->rec_gen = m->set_generation;  // nothing differs from the kept records
+                if (patched.empty()) m->dev_gen = m->set_generation;
             }
             // (L = 0: nothing was launched; dev_Ps says which views of the device arrays are behind, ensure_e1 will look)
             reused = true;
@@ -549,6 +571,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         if (rc) return rc;
         if (m->record_reuse && !K01_d && count > 0) {
             m->rec_Ps.assign(Pcur, Pcur + 12 * n);
+            m->rec_gen = m->set_generation;
             m->rec_first = first;
             m->rec_count = count;
             m->rec_n_views = (int)n;
@@ -558,6 +581,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             m->rec_tol = p.economise_tol;
         }
     }
+    ecc_stamp(m, 5);
     if (!pairs_launched) {
         if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         HIP_TRY(ecc_launch_pairs(&p, ctx->stream));
@@ -566,12 +590,14 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             ctx->ev_valid[0] = true;
         }
     }
+    if (m->stamps[4] == 0.0) ecc_stamp(m, 4);
     if (sum_d) {
         if (count > 0) HIP_TRY(ecc_launch_sum_pairs(pair_values_d, count, sum_d, m->sum_scratch_d, ctx->stream));
         else if (sum_d == m->sum_h_dev) std::memset(m->sum_h, 0, sizeof(double));  // empty shard: nothing is launched
         else HIP_TRY(hipMemsetAsync(sum_d, 0, sizeof(double), ctx->stream));
     }
     m->rec_valid = m->record_reuse && !K01_d && count > 0;
+    ecc_stamp(m, 6);
     return ECC_OK;
 }
 
@@ -717,6 +743,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
                                          double* partial_sum)
 {
     if (!m || !partial_sum) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    ecc_stamp(m, 2);
     ecc_ctx* ctx = m->ctx;
     int rc = set_device(ctx);
     if (rc) return rc;
@@ -735,6 +762,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
         HIP_TRY(wait_stream_spin(ctx->stream));  // the copy has to land too
     }
     HIP_TRY(wait_sum(m, partial_sum));
+    ecc_stamp(m, 7);
     // an empty shard launches no kernel behind e1_kernel: its result slot says nothing about the stream
     if (count == 0) HIP_TRY(wait_stream_spin(ctx->stream));
     m->done_generation = m->set_generation;
@@ -744,6 +772,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
 ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean)
 {
     if (!m || !mean) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    ecc_stamp(m, 2);
     ecc_ctx* ctx = m->ctx;
     int rc = set_device(ctx);
     if (rc) return rc;
@@ -782,6 +811,7 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
     }
     double sum = 0.0;
     HIP_TRY(wait_sum(m, &sum));
+    ecc_stamp(m, 7);
     m->done_generation = m->set_generation;
     *mean = sum / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
     return ECC_OK;
@@ -1067,6 +1097,13 @@ ECC_EXPORT int ecc_debug_set_poly_tolerance(ecc_metric* m, float tol_bins)
     m->economise_tol = tol_bins;
     m->rec_valid = false;    // the kept records and values were made with the old tolerance
     m->cache_valid = false;
+    return ECC_OK;
+}
+
+ECC_EXPORT int ecc_debug_step_stamps(const ecc_metric* m, double* out8)
+{
+    if (!m || !out8) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    std::memcpy(out8, m->stamps, sizeof(double) * ECC_STEP_STAMPS);
     return ECC_OK;
 }
 

@@ -84,6 +84,24 @@ __device__ __forceinline__ float pointwise(const EccPreprocessParams& p, float v
     return borders(p, intensity(p, v, scale, bias), sx, sy);
 }
 
+// Workgroup -> tile.  The launch is one-dimensional; workgroups b, b + 8, ... share an XCD (round-robin dispatch), and an
+// XCD walks a CONTIGUOUS run of tiles (x fastest, then y, then the image), so the halo texels two neighbouring tiles both
+// read come out of that XCD's L2.  With the three-dimensional grid of rounds 1-4 neighbouring tiles sat on different XCDs
+// and every halo line was fetched again: 1.94x the image per launch through the fabric (profiles/r05_pmc_preprocess.txt).
+// Returns false for the padding workgroups of the last round.
+__device__ __forceinline__ bool pp_tile(const EccPreprocessParams& p, int& bx, int& by, int& bz)
+{
+    const unsigned tiles_x = (unsigned)(p.n_u + PP_TW - 1) / PP_TW, tiles_y = (unsigned)(p.n_v + PP_TH - 1) / PP_TH;
+    const unsigned total = tiles_x * tiles_y * (unsigned)p.n_img, per_xcd = (total + 7) / 8;
+    const unsigned t = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (t >= total) return false;
+    const unsigned row = t / tiles_x;
+    bx = (int)(t - row * tiles_x);
+    bz = (int)(row / tiles_y);
+    by = (int)(row - (unsigned)bz * tiles_y);
+    return true;
+}
+
 // KT: half kernel width known at compile time (taps live in registers, loops unroll), or -1 = runtime k with
 // (k = 0, no low-pass, is preprocess_pointwise_kernel's; the KT == 0 branches below are not instantiated any more)
 // the taps read from an LDS copy (a scalar load per tap inside the loop serialises on its latency: 10.8 -> x us).
@@ -110,10 +128,11 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
     } else if (KT < 0) {
         if ((int)threadIdx.x < 2 * k) taps_lds[threadIdx.x] = p.kernel[threadIdx.x];
     }
-    const int img_i = blockIdx.z;
+    int bx, by, img_i;
+    if (!pp_tile(p, bx, by, img_i)) return;  // (uniform over the workgroup, in front of every barrier)
     const float* __restrict__ src = p.in + (int64_t)img_i * p.stride;
     float* __restrict__ dst = p.out + (int64_t)img_i * p.stride;
-    const int x0 = blockIdx.x * PP_TW, y0 = blockIdx.y * PP_TH;
+    const int x0 = bx * PP_TW, y0 = by * PP_TH;
     const int W = p.n_u, H = p.n_v;
 
     float scale = p.scale, bias = p.bias;
@@ -317,12 +336,13 @@ __global__ __launch_bounds__(NT) void preprocess_kernel(EccPreprocessParams p)
 __global__ __launch_bounds__(256) void preprocess_pointwise_kernel(EccPreprocessParams p)
 {
     constexpr int NP = PP_TH / 4;
-    const int img_i = blockIdx.z;
+    int bx, by, img_i;
+    if (!pp_tile(p, bx, by, img_i)) return;
     const float* __restrict__ src = p.in + (int64_t)img_i * p.stride;
     float* __restrict__ dst = p.out + (int64_t)img_i * p.stride;
     const int W = p.n_u, H = p.n_v;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int gx = blockIdx.x * PP_TW + tx, y0 = blockIdx.y * PP_TH;
+    const int gx = bx * PP_TW + tx, y0 = by * PP_TH;
     float scale = p.scale, bias = p.bias;
     if (p.normalize) {  // ref: :68-76, as in preprocess_kernel
         bias = 0;
@@ -337,7 +357,7 @@ __global__ __launch_bounds__(256) void preprocess_pointwise_kernel(EccPreprocess
     const int sx = p.flip_u ? W - 1 - gx : gx;
     bool interior = p.n_blanks == 0;
     {
-        const int gx_lo = blockIdx.x * PP_TW, gx_hi = min(gx_lo + PP_TW, W) - 1, gy_lo = y0, gy_hi = min(y0 + PP_TH, H) - 1;
+        const int gx_lo = bx * PP_TW, gx_hi = min(gx_lo + PP_TW, W) - 1, gy_lo = y0, gy_hi = min(y0 + PP_TH, H) - 1;
         const int sx_lo = p.flip_u ? W - 1 - gx_hi : gx_lo, sx_hi = p.flip_u ? W - 1 - gx_lo : gx_hi;
         const int sy_lo = p.flip_v ? H - 1 - gy_hi : gy_lo, sy_hi = p.flip_v ? H - 1 - gy_lo : gy_hi;
         interior = interior && sx_lo >= p.zero[0] + p.feather[0] && p.n_u - sx_hi > p.zero[1] + p.feather[1] &&
@@ -426,7 +446,9 @@ extern "C" hipError_t ecc_launch_preprocess(const EccPreprocessParams* p, hipStr
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    dim3 grid((p->n_u + PP_TW - 1) / PP_TW, (p->n_v + PP_TH - 1) / PP_TH, p->n_img);
+    // one-dimensional grid, padded to a multiple of 8: pp_tile gives every XCD a contiguous run of tiles
+    const unsigned tiles = (unsigned)((p->n_u + PP_TW - 1) / PP_TW) * (unsigned)((p->n_v + PP_TH - 1) / PP_TH) * (unsigned)p->n_img;
+    dim3 grid(((tiles + 7) / 8) * 8);
     const size_t lds = ecc_preprocess_lds_bytes(p->k);
     if (p->k == 0)
         hipLaunchKernelGGL(preprocess_pointwise_kernel, grid, dim3(256), 0, stream, *p);

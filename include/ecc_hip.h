@@ -280,7 +280,9 @@ int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
  * all-pairs launch (which skips them) on the context's stream; events order that stream after whatever the caller had
  * queued on the context's stream and the final sum after both (up to 512 views, no cost image; otherwise one stream). */
 #define ECC_RECORD_REUSE_MIN_PAIRS 4096
+#ifndef ECC_RECORD_REUSE_SPLIT_PAIRS
 #define ECC_RECORD_REUSE_SPLIT_PAIRS 8192
+#endif
 /* on: 0 = off; 1 (default) = by size: ranges of more than ECC_RECORD_REUSE_MIN_PAIRS pairs (up to there refitting
  * everything is one short launch), the two-stream form from ECC_RECORD_REUSE_SPLIT_PAIRS pairs on (a shorter pair kernel
  * cannot hide the refit's launches: measured 2016 pairs, 61 us per step with two streams, 40 us refitting everything; a
@@ -553,6 +555,12 @@ int ecc_debug_set_small_eval_bound(ecc_metric* m, int64_t max_pairs);
 int ecc_debug_set_result_polling(int on);
 int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on);
 int ecc_debug_small_stamps(unsigned long long* out, int n_blocks);
+/* Host clock (seconds, std::chrono::steady_clock) at fixed points of the metric's last ecc_metric_set_projections and last
+ * synchronous all-pairs / range evaluation -- where the host's share of a step goes (scripts/step_fixed_cost.py):
+ * [0] set_projections entered, [1] returned; [2] evaluate entered, [3] change detection done (first launch next),
+ * [4] first pair-kernel launch returned, [5] refit / list launches queued, [6] sum launch returned, [7] result seen. */
+#define ECC_STEP_STAMPS 8
+int ecc_debug_step_stamps(const ecc_metric* m, double* out8);
 
 #ifdef __cplusplus
 }

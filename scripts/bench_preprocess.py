@@ -22,3 +22,8 @@ for name, setup in (("defaults+cos", lambda p: None), ("no lowpass", lambda p: s
         pp.process(ctx, imgs, Ps, out=out)
     us = 1e3 * ctx.last_kernel_ms("preprocess") / n
     print("%-14s %.2f us per image, %.0f GB/s of 8 B/pixel" % (name, us, 8.0 * S * S / (us * 1e-6) / 1e9))
+# calibration of the byte counters on this shape (MI355X_MICROARCH.md, HBM: "other access widths are uncalibrated"): a plain
+# copy of the same stack -- 4 B read and 4 B written per pixel, nothing else
+for r in range(3):
+    out.copy_(imgs)
+torch.cuda.synchronize()
