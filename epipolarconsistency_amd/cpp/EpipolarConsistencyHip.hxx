@@ -576,6 +576,16 @@ class MetricRadonIntermediate : public Metric {
             detail::check(ecc_group_metric_set_params(m_gh, object_radius_mm, dkappa, use_corr ? 1 : 0));
             detail::check(ecc_group_metric_set_sampling(m_gh, sampling));
             detail::check(ecc_group_metric_set_incremental(m_gh, incremental ? 1 : 0));
+            if (record_reuse >= 0 || small_eval >= 0) {  // per-metric switches: forwarded to every rank's metric
+                ecc_group* g = m_group ? m_group : detail::default_group();
+                const int ranks = g ? ecc_group_size(g) : 0;
+                for (int r = 0; r < ranks; ++r) {
+                    ecc_metric* rm = nullptr;
+                    detail::check(ecc_group_metric_rank_metric(m_gh, r, &rm));
+                    if (record_reuse >= 0) detail::check(ecc_metric_set_record_reuse(rm, record_reuse));
+                    if (small_eval >= 0) detail::check(ecc_metric_set_small_eval(rm, small_eval));
+                }
+            }
         } else if (m_h) {
             detail::check(ecc_metric_set_params(m_h, object_radius_mm, dkappa, use_corr ? 1 : 0));
             detail::check(ecc_metric_set_sampling(m_h, sampling));
