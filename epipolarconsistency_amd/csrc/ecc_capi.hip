@@ -814,13 +814,11 @@ int ensure_e1(ecc_metric* m)
     const size_t n12 = (size_t)12 * m->n_views;
     if (m->dev_valid && m->dev_Ps.size() == n12 && std::memcmp(m->dev_Ps.data(), m->Ps_h[slot], sizeof(double) * n12) == 0) {
         m->e1_pending = false;  // the device arrays already belong to these matrices (patched view by view, or set back)
-        m->dev_gen = m->set_generation;
         return ECC_OK;
     }
     HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], m->n_views, m->PinvTs_d, m->Cs_d, m->ctx->stream));
     m->dev_Ps.assign(m->Ps_h[slot], m->Ps_h[slot] + n12);
     m->dev_valid = true;
-    m->dev_gen = m->set_generation;
     m->e1_pending = false;
     // The reuse path of launch_range assumes PinvTs / Cs on the device are E1(rec_Ps) for every view it finds unchanged.
     // This launch has just made them E1 of the CURRENT matrices for all views (an image-pair or debug call between two
@@ -929,15 +927,6 @@ ECC_EXPORT int ecc_metric_set_projections(ecc_metric* m, const double* Ps, int n
         m->done_generation = m->set_generation;
     }
     const int slot = (int)(g & 1);
-    // the views that differ from the call before (its matrices are in the other staging buffer), found while staging
-    m->set_changed_valid = false;
-    if (m->set_generation >= 1 && n_views == m->n_views) {
-        const double* prev = m->Ps_h[slot ^ 1];
-        m->set_changed.clear();
-        for (int v = 0; v < n_views; ++v)
-            if (std::memcmp(Ps + 12 * (size_t)v, prev + 12 * (size_t)v, sizeof(double) * 12) != 0) m->set_changed.push_back(v);
-        m->set_changed_valid = true;
-    }
     std::memcpy(m->Ps_h[slot], Ps, sizeof(double) * 12 * (size_t)n_views);
     m->set_generation = g;
     m->n_views = n_views;

@@ -199,15 +199,6 @@ struct ecc_metric {
     // reuse path and of the one-launch path: the listed views)
     std::vector<double> dev_Ps;
     bool dev_valid = false;
-    // Change detection in ONE pass: ecc_metric_set_projections compares each view with the matrices of the call before while
-    // it stages them (set_changed).  rec_gen / dev_gen name the set_generation whose matrices rec_Ps / dev_Ps equal in EVERY
-    // view (0: unknown): when both are the generation before the current one -- the optimiser's pattern, one evaluation per
-    // set -- "changed against the kept records" and "stale on the device" are exactly set_changed and launch_range needs no
-    // pass over the matrices of its own; anything else (two sets in a row, an image-pair call in between, ranges the moved
-    // view does not touch) falls back to comparing view by view.
-    std::vector<int> set_changed;
-    bool set_changed_valid = false;
-    uint64_t rec_gen = 0, dev_gen = 0;
     // automatic object radius (a function of the first matrix and the image size), kept until the first matrix changes
     mutable double radius_cache = 0.0;
     mutable double radius_cache_P[12] = {0};

@@ -256,7 +256,6 @@ void commit_patches(ecc_metric* m, const EccSmallEval& x, bool from_host)
         std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
     }
     m->e1_pending = false;
-    m->dev_gen = m->set_generation;  // the patch list was every view whose geometry on the device was behind
 }
 
 // k01 over p on the context's stream, E1 included: small launches (8 lanes per fit) of a metric with the one-launch path on
@@ -403,23 +402,22 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     ecc_stamp(m, 3);
     m->stamps[4] = m->stamps[5] = 0.0;
     if (rec_match) {
+        // (Round 5, measured and dropped: the changed views found in ONE pass by ecc_metric_set_projections while it stages the
+        // matrices, with generation counters saying when that list is what the kept records and the device geometry differ
+        // by, and the fork event skipped when hipStreamQuery finds the stream idle -- A/B/A/B on one box the step was 2-4 us
+        // SLOWER: the three passes over 38 KB below cost less than a microsecond, and the stream is usually NOT yet reported
+        // idle when the next step begins -- the polled result arrives before the runtime sees the completion signal --
+        // which makes the query the expensive call.  profiles/r05_ab_host_shortcuts.txt)
         std::vector<int>& changed = m->scratch_changed;
-        std::vector<int>& patched = m->scratch_patched;
-        const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * n;
-        // the optimiser's pattern -- records and device geometry both belong to the matrices of the set call before this
-        // one: what changed is what ecc_metric_set_projections saw while staging (no pass over the matrices here)
-        const bool from_set = dev_known && m->set_changed_valid && m->rec_gen != 0 && m->rec_gen + 1 == m->set_generation &&
-                              m->dev_gen + 1 == m->set_generation;
-        if (from_set) changed = m->set_changed;
-        else {
-            changed.clear();
-            for (int64_t v = 0; v < n; ++v)
-                if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
-        }
+        changed.clear();
+        for (int64_t v = 0; v < n; ++v)
+            if (std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) != 0) changed.push_back((int)v);
         // views whose geometry on the device is not that of the current matrices although their records are (an E1 launch
         // or a patch list of another call in between): they need a patch entry too, but no refit
+        std::vector<int>& patched = m->scratch_patched;
         patched = changed;
-        if (dev_known && !from_set) {
+        const bool dev_known = m->dev_valid && (int64_t)m->dev_Ps.size() == 12 * n;
+        if (dev_known) {
             for (int64_t v = 0; v < n; ++v)
                 if (std::memcmp(Pcur + 12 * v, m->dev_Ps.data() + 12 * v, sizeof(double) * 12) != 0 &&
                     std::memcmp(Pcur + 12 * v, m->rec_Ps.data() + 12 * v, sizeof(double) * 12) == 0)
@@ -447,16 +445,9 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                     split = false;
                 }
             }
-            bool forked = false;
             if (split) {
-                // whatever the caller queued on the context's stream before this call comes first for the side stream too --
-                // unless that stream is idle (a synchronous caller's usual state: its last evaluation has returned): then
-                // there is nothing to order against and the event record + wait are saved
-                forked = hipStreamQuery(ctx->stream) != hipSuccess;
-                if (forked) {
-                    (void)hipGetLastError();  // hipErrorNotReady is not an error
-                    HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
-                }
+                // whatever the caller queued on the context's stream before this call comes first for the side stream too
+                HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
                 EccPairParams pa = p;
                 pa.skip_enabled = 1;
                 for (int v : changed) pa.skip_mask[v >> 5] |= 1u << (v & 31);
@@ -533,7 +524,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             HIP_TRY(_s);                                                      \
         }                                                                     \
     } while (0)
-                if (split && forked) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
+                if (split) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
                 SIDE_TRY(ecc_launch_k01(&q, ks));
                 if (split) {  // the changed pairs' own launch: records and values in their slots
                     q.pair_values = pair_values_d;
@@ -552,10 +543,6 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 for (int v : changed) std::memcpy(m->rec_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
                 for (int v : patched) std::memcpy(m->dev_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
                 m->e1_pending = false;  // workgroup 0 of the list launch stores the patches: PinvTs / Cs are current again
-                m->rec_gen = m->dev_gen = m->set_generation;  // every view of both now belongs to the current matrices
-            } else if (changed.empty()) {
-                m->rec_gen = m->set_generation;  // nothing differs from the kept records
-                if (patched.empty()) m->dev_gen = m->set_generation;
             }
             // (L = 0: nothing was launched; dev_Ps says which views of the device arrays are behind, ensure_e1 will look)
             reused = true;
@@ -571,7 +558,6 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         if (rc) return rc;
         if (m->record_reuse && !K01_d && count > 0) {
             m->rec_Ps.assign(Pcur, Pcur + 12 * n);
-            m->rec_gen = m->set_generation;
             m->rec_first = first;
             m->rec_count = count;
             m->rec_n_views = (int)n;
