@@ -44,3 +44,22 @@ print({k: v for k, v in names.items() if "ccl" in k.lower() or "publish" in k or
 PY
 tail -30 $R/gpurun_out/${tag}_rccl_kernel_order.txt
 rm -rf $out
+# RCCL device code in the stream: the same sequence with the reduction op AVG (see scripts/rccl_one_rank_avg_trace.py)
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/scripts/rccl_one_rank_avg_trace.py > $R/gpurun_out/${tag}_rccl_avg_trace.log 2>&1
+python3 - <<PY
+import csv, glob
+rows = []
+for f in glob.glob("$out/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+t0 = int(rows[0]["Start_Timestamp"])
+with open("$R/gpurun_out/${tag}_rccl_avg_kernel_order.txt", "w") as f:
+    f.write("# rocprofv3 --kernel-trace of scripts/rccl_one_rank_avg_trace.py (one-rank RCCL group, all_reduce(AVG)); last 40 dispatches\n")
+    f.write("# start_us  dur_us  queue  kernel\n")
+    for r in rows[-40:]:
+        f.write("%12.1f %9.1f  q%s  %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                             r.get("Queue_Id", "?"), r["Kernel_Name"][:120]))
+PY
+grep -a "one-rank RCCL" $R/gpurun_out/${tag}_rccl_avg_trace.log
+tail -16 $R/gpurun_out/${tag}_rccl_avg_kernel_order.txt
+rm -rf $out
