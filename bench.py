@@ -72,6 +72,86 @@ def emit(obj):
     out.flush()
 
 
+class PowerSampler:
+    """Socket power and engine clock of one GPU while a region runs, from the amdgpu hwmon files (power1_input in microwatts,
+    freq1_input in Hz; readable without privileges).  The pair and Radon kernels run into the socket's POWER CAP (1400 W):
+    the clock they hold -- not the 2.4 GHz the roofs are priced at -- is what the chip allows this instruction mix, so the
+    bench reports both.  A thread that reads two small files every 2 ms; never active inside a timed block."""
+
+    def __init__(self, pci_bus=None):
+        """pci_bus: "dddd:bb" of the device whose files are wanted (a node with several cards); None = the first card found"""
+        import glob
+        self.dir = None
+        found = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(d, "power1_input")) and os.path.exists(os.path.join(d, "freq1_input")):
+                found.append(d)  # (a one-GPU box shows the hwmon files of its own card only)
+        for d in found:
+            if pci_bus and pci_bus in os.path.realpath(os.path.dirname(os.path.dirname(d))):
+                self.dir = d
+        if not self.dir and found and (pci_bus is None or len(found) == 1):
+            self.dir = found[0]
+        self.samples = []
+        self._stop = False
+        self._thread = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def once(self):
+        if not self.dir:
+            return None
+        p, f = self._read("power1_input"), self._read("freq1_input")
+        return None if p is None or f is None else (p * 1e-6, f * 1e-6)
+
+    def cap_w(self):
+        v = self._read("power1_cap") if self.dir else None
+        return None if v is None else v * 1e-6
+
+    def rated_mhz(self):
+        try:
+            with open(os.path.join(os.path.dirname(os.path.dirname(self.dir)), "pp_dpm_sclk")) as f:
+                return max(float(tok[:-3]) for line in f for tok in line.split() if tok.lower().endswith("mhz") and tok[:-3].replace(".", "").isdigit())
+        except Exception:
+            return None
+
+    def start(self):
+        import threading
+        if not self.dir:
+            return self
+        self.samples, self._stop = [], False
+
+        def run():
+            while not self._stop:
+                v = self.once()
+                if v:
+                    self.samples.append(v)
+                time.sleep(0.002)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self, skip_s=0.0):
+        """-> summary of the samples (the first skip_s seconds dropped: the power reading is a moving average)"""
+        if not self._thread:
+            return None
+        self._stop = True
+        self._thread.join()
+        self._thread = None
+        k = int(skip_s / 0.002)
+        sm = self.samples[k:] if len(self.samples) > k + 4 else self.samples
+        if not sm:
+            return None
+        w = sorted(v[0] for v in sm)
+        f = [v[1] for v in sm]
+        return {"avg_w": sum(w) / len(w), "p95_w": w[int(0.95 * (len(w) - 1))], "sclk_mhz_avg": sum(f) / len(f),
+                "sclk_mhz_min": min(f), "samples": len(sm)}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -480,6 +560,13 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = E.Context(local_rank, stream=stream.cuda_stream)
     ctx.enable_timing(True)  # Radon / pre-processing kernel times below
+    try:
+        pr = torch.cuda.get_device_properties(dev)
+        pci = "%04x:%02x" % (pr.pci_domain_id, pr.pci_bus_id)
+    except Exception:
+        pci = None
+    power = PowerSampler(pci)
+    power_first = power.once()  # (watts, MHz) before this process has launched anything of its own
 
     # ---- Radon intermediates: data-parallel over views, then one all-gather ---------------------
     slab = E.slab_floats(B, B)
@@ -498,8 +585,10 @@ def main():
     # untimed first call: the context allocates its scratch (transposed image copy, trig table), clocks ramp
     keep = E.RadonIntermediate.compute_into(ctx, imgs_all[:min(sub, hi - lo)], local[:min(sub, hi - lo)], B, B)
     ctx.synchronize()
+    power.start()
     keep = E.RadonIntermediate.compute_into(ctx, imgs_all, local[:hi - lo], B, B)
     ctx.synchronize()
+    power_radon = power.stop(skip_s=0.05)
     radon_ms = ctx.last_kernel_ms("radon")
     ms_per_radon = radon_ms / max(hi - lo, 1)
     # the same stack in the contracted arithmetic (ecc_radon_set_arithmetic(ECC_RADON_FMA): positions fmaf(t, d, o), lerps
@@ -679,6 +768,22 @@ def main():
     fence()
     pair_ms /= n_timed
     pair_s = pair_ms * 1e-3
+    # socket power and engine clock while the same steps run back to back (untimed, ~1.5 s; the first 0.5 s dropped: the
+    # reading is a moving average and the controller takes about a second to settle at the cap)
+    ctx.enable_timing(False)
+    n_power = int(min(20000, max(200, 1.5 / max(elapsed / args.steps, 1e-6))))  # (elapsed is the MAX over ranks: the same count everywhere)
+    fence()
+    power.start()
+    t_p = time.perf_counter()
+    for k in range(n_power):
+        step(k)
+    fence()
+    t_p = time.perf_counter() - t_p
+    power_steps = power.stop(skip_s=0.5)
+    if power_steps:
+        power_steps["ms_per_step_while_sampling"] = 1e3 * t_p / n_power
+        power_steps["steps"] = n_power
+    ctx.enable_timing(True)
 
     # the same steps with the record reuse switched off (every step refits all pairs and launches e1_kernel): the
     # results are bit-identical, only the fixed cost per step differs
@@ -696,6 +801,24 @@ def main():
     reuse_off_s = sorted(off_blocks)[1]
     if v_on != v_off:
         raise SystemExit("record reuse changed the results: %r vs %r" % (v_on, v_off))
+
+    # ---- socket power and engine clock (hwmon) --------------------------------------------------------------------------
+    # Both kernels run INTO THE POWER CAP: the socket reads 1395-1399 W of its 1400 W while the steps run back to back and
+    # the engine clock settles near 2.2 GHz, below the 2.4 GHz every roof here is priced at.  At the cap a kernel's time
+    # follows the ENERGY of its instruction and data stream, not the issue slots of one pipe: cutting instructions returns
+    # well under its share (CHANGELOG.md 4.2 has five rounds of such cuts), and idle XCDs at the end of a launch cost
+    # nothing (the remaining ones clock up: CHANGELOG.md round 5, XCD schedule).  `frac_at_measured_clock` restates the two
+    # clock-bound roofs against the clock the chip actually ran at.
+    power_report = None
+    if power.dir and rank == 0:
+        cap, rated = power.cap_w(), power.rated_mhz()
+        power_report = {"source": "amdgpu hwmon power1_input / freq1_input, 2-ms samples, outside the timed blocks",
+                        "cap_w": cap, "sclk_rated_mhz": rated,
+                        "before_first_launch": {"w": power_first[0], "sclk_mhz": power_first[1]} if power_first else None,
+                        "pair_steps": power_steps, "radon_stack": power_radon,
+                        "radon_stack_note": "one call of about 0.2 s: the power reading (a moving average) is still rising when it ends"}
+        if power_steps and cap:
+            power_report["pair_steps"]["frac_of_cap"] = power_steps["avg_w"] / cap
 
     n_kappa = n_kappa_auto(S, S, B)
     bytes_per_pair = 64 * n_kappa + 68            # 2 views x 2 signs x 4 taps x 4 B + K01 + result
@@ -739,6 +862,12 @@ def main():
                                  "frac": traffic / pair_s / 1e9 / HBM_PEAK_GBS}
     # SURVEY.md 8(d)'s compulsory figure: every Radon intermediate read once + the per-view geometry + one float per pair
     hbm_compulsory = 4 * n * B * B + 64 * n + 4 * count
+    if power_report and power_report.get("pair_steps"):
+        scale = ENGINE_CLOCK_GHZ * 1e3 / power_report["pair_steps"]["sclk_mhz_avg"]
+        for r in ("l1", "valu"):
+            if r in roofs:
+                roofs[r]["frac_at_measured_clock"] = roofs[r]["frac"] * scale
+                roofs[r]["measured_clock_mhz"] = power_report["pair_steps"]["sclk_mhz_avg"]
     bound = max(roofs, key=lambda r: roofs[r]["frac"])
     roofline = {"bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"],
                 "unit": roofs[bound]["unit"], "frac": roofs[bound]["frac"], "traffic": traffic,
@@ -843,6 +972,7 @@ def main():
                                                 "over all pairs every step; same result bits"}},
         "roofline": roofline,
         "roofline_radon": roofline_radon,
+        "power": power_report,
         "ms_per_radon_intermediate": ms_per_radon,
         "ms_per_radon_intermediate_by_arithmetic": {
             "exact": ms_per_radon, "fma": ms_per_radon_fma,
