@@ -1,5 +1,6 @@
-// ecc_capi_internal.h -- what the translation units of the C ABI share (ecc_capi.hip: contexts, Radon intermediates, metric
-// state and set-up, pre-processing, MetricDirect; ecc_evaluate.hip: the evaluation paths of the metric): the object
+// ecc_capi_internal.h -- what the translation units of the C ABI share (ecc_capi.hip: errors, contexts; ecc_radon_api.hip: Radon
+// intermediates; ecc_metric_api.hip: the metric's objects; ecc_evaluate.hip: its evaluation paths; ecc_preprocess_api.hip;
+// ecc_direct_api.hip: MetricDirect): the object
 // layouts behind the opaque handles, the kernel launchers, error handling and the helpers of namespace ecc_internal.
 #ifndef ECC_CAPI_INTERNAL_H
 #define ECC_CAPI_INTERNAL_H

@@ -1,5 +1,5 @@
 // ecc_evaluate.hip -- the evaluation paths of MetricRadonIntermediate behind the C ABI (host code only; the object layouts
-// and shared helpers are in ecc_capi_internal.h, everything else of the ABI in ecc_capi.hip).
+// and shared helpers are in ecc_capi_internal.h, the metric's objects in ecc_metric_api.hip).
 //
 // ref: MetricRadonIntermediate::evaluate(float*), evaluate(indices, out) (EpipolarConsistencyRadonIntermediate.cpp:166-225,
 // 267-322) and their launcher epipolarConsistency(...) (.cpp:16-37, .cu:300-409).  Here: the parameters of a launch

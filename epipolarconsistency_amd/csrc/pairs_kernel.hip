@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict
     if (threadIdx.x == 0) {
         double tot = 0.0;
         for (int w = 0; w < 1024 / 64; w++) tot += s[w];
-        // `out` is usually pinned host memory that the host polls (ecc_capi.hip, wait_result): one 8-byte store at
+        // `out` is usually pinned host memory that the host polls (ecc_capi.hip: wait_result): one 8-byte store at
         // system scope, written through, visible to the host before the kernel's end-of-dispatch write-back
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(tot),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

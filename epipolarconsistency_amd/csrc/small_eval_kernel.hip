@@ -26,7 +26,7 @@
 //   * phase C: each value goes to the device array (plain store) and, at system scope, into pinned host memory; the
 //     workgroup drains its stores and takes a ticket, and the workgroup that arrives last writes a "done" word the host
 //     polls.  The HOST then adds the values in sum_pairs_kernel's order (the float4 layout of its 1024 threads, its shuffle
-//     tree, its 16 wave sums in order: ecc_capi.hip, small_sum_on_host) -- at most 4096 values, under 2 us.  (First form,
+//     tree, its 16 wave sums in order: ecc_evaluate.hip, small_sum_on_host) -- at most 4096 values, under 2 us.  (First form,
 //     measured: the last arriver added the values itself with agent-scope loads -- 55 us for 399 values; loads that must
 //     bypass the XCD's L2 cost microseconds each.  Asynchronous callers, who want the sum in device memory, keep the
 //     stream-ordered launches.)

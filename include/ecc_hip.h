@@ -471,7 +471,7 @@ void ecc_pair_shard(int64_t n_pairs, int world, int rank, int64_t* first, int64_
 /* Cost-balanced alternative: contiguous chunks of equal MODEL COST instead of equal count -- the pair kernel's time per
  * pair grows with the pair's kappa_max, and for a circular scan the expensive pairs sit in the first rows of the pair
  * triangle (equal-count shards of an 8-rank job measured 93 ... 68 us; model for balanced shards 77.5 us each; the fit is in
- * ecc_capi.hip).  bounds receives world + 1 pair indices, rank r evaluates [bounds[r], bounds[r+1]).  Host, float64, a
+ * ecc_metric_api.hip).  bounds receives world + 1 pair indices, rank r evaluates [bounds[r], bounds[r+1]).  Host, float64, a
  * function of the matrices and the object radius only (every rank of a job computes the same bounds); ~0.3 ms for 400
  * views -- once per data set.  ecc_metric_balanced_shards uses the metric's current matrices and object radius. */
 int ecc_pair_shards_balanced(const double* Ps, int n_views, double object_radius_mm, int world, int64_t* bounds);
