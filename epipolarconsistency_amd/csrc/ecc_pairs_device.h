@@ -345,6 +345,10 @@ __device__ __forceinline__ bool kappa_step(int k, const float (&K0)[8], const fl
 // (The coefficients are scalar registers and a gfx9 vector instruction reads only one, so each Horner chain starts with a
 // v_mov; keeping the second coefficients in vector registers instead removes 8 instructions per kappa step and was
 // SLOWER: 0.342 vs 0.330 ms, measured twice on the same device.)
+// (Round 5, the other way round: the two LEADING coefficients of every chain in vector registers for the whole loop, so that a
+// chain's first step is fma(vector, vector, scalar) like the others -- 8 instructions and 8 scalar registers less per kappa step,
+// no v_mov left in the loop, bit-identical: 0.3141 / 0.3144 -> 0.3278 / 0.3282 ms A/B/A/B on one box, at LOWER socket power and a
+// higher clock (1354 W, 2348 MHz against 1373 W, 2298 MHz): the loop waits on its vector-register reads, not on issue slots.)
 template <int DEG>
 __device__ __forceinline__ void poly_pm(const float* c, float lo_plus, float lo_minus, bool same_lo, float x, float z,
                                         float& plus, float& minus)
