@@ -188,6 +188,9 @@ def parse():
                          "all-gather of the Radon-intermediate stack, ecc_metric_evaluate_range_async -> all-reduce of the "
                          "device scalar -> publish_scalar_kernel -> poll per step, MAX-reduced block times: first contact of "
                          "that path with RCCL on a one-GPU box (profiles/r05_bench_1rank_rccl.json)")
+    ap.add_argument("--no-power", action="store_true",
+                    help="skip the ~1.5 s of extra steps behind the timed blocks during which socket power and engine clock are sampled "
+                         "(profiler runs: every step is a traced dispatch)")
     ap.add_argument("--sweep-poses", action="store_true",
                     help="BASELINE config 5 instead of the per-step bench: the 600-point 6-DoF sweep of one view "
                          "(ref: Gui/Visualization.h:78-98), the POSES sharded round-robin over the ranks, every rank "
@@ -771,7 +774,7 @@ def main():
     # socket power and engine clock while the same steps run back to back (untimed, ~1.5 s; the first 0.5 s dropped: the
     # reading is a moving average and the controller takes about a second to settle at the cap)
     ctx.enable_timing(False)
-    n_power = int(min(20000, max(200, 1.5 / max(elapsed / args.steps, 1e-6))))  # (elapsed is the MAX over ranks: the same count everywhere)
+    n_power = 0 if (args.no_power or args.pmc_child) else int(min(20000, max(200, 1.5 / max(elapsed / args.steps, 1e-6))))  # (elapsed is the MAX over ranks: the same count everywhere)
     fence()
     power.start()
     t_p = time.perf_counter()
@@ -779,7 +782,7 @@ def main():
         step(k)
     fence()
     t_p = time.perf_counter() - t_p
-    power_steps = power.stop(skip_s=0.5)
+    power_steps = power.stop(skip_s=0.5) if n_power else (power.stop() and None)
     if power_steps:
         power_steps["ms_per_step_while_sampling"] = 1e3 * t_p / n_power
         power_steps["steps"] = n_power

@@ -5,7 +5,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 rm -rf $out
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-live-pmc --no-power > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
 python3 - <<PY
 import csv, glob, collections, re
 rows=[]

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/stats_$tag
 rm -rf $out
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-live-pmc > $R/gpurun_out/stats_$tag.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-live-pmc --no-power > $R/gpurun_out/stats_$tag.log 2>&1
 # per-kernel statistics from the kernel trace, kernels of this library only; a name launched with clearly different grids
 # (pairs_kernel: all pairs / the list of the moved view's pairs; radon_kernel: sub-batches) gets one line per grid
 python3 - <<PY
