@@ -17,6 +17,7 @@ namespace {
 constexpr int PK_THREADS = 256;
 constexpr int PK_MAIN_WAVES = 4;  // waves (= pairs) per workgroup of pairs_kernel, wave w taking the pair w * nblk + block.  Measured
                                   // on the benchmark's launch: 1 wave 0.399 ms, 2 0.333, 4 0.326, 8 0.377, 16 0.408
+                                  // (round 5, at seven waves per SIMD: 1 wave 0.389, 2 0.320 but a slower step, 4 0.318-0.323, 8 0.344)
 constexpr int PK_MAIN_THREADS = 64 * PK_MAIN_WAVES;
 
 // ref: EpipolarConsistencyCommon.hxx:82-90 (shiftOriginAndNormlaize)
