@@ -22,7 +22,7 @@ PY
 cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/trace_${tag}_rccl
 rm -rf $out
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/bench.py --force-collective --exchange collective --steps 4 --warmup 2 --blocks 2 --no-cpu-baseline --no-live-pmc > $R/gpurun_out/${tag}_rccl_trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $out -- python3 $R/bench.py --force-collective --exchange collective --steps 4 --warmup 2 --blocks 2 --no-cpu-baseline --no-live-pmc --no-power > $R/gpurun_out/${tag}_rccl_trace.log 2>&1
 python3 - <<PY
 import csv, glob
 rows = []
