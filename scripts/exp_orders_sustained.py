@@ -91,7 +91,19 @@ def tiles(T):
     return out
 
 
+def interleave(R):
+    """R consecutive rows of the pair triangle walked together: (i, j), (i + 1, j), ..., (i + R - 1, j), then j + 1: a view j's band
+    is used by R pairs in a row (its next use is otherwise a whole row of pairs later, long after the L2 has dropped it)"""
+    out = []
+    for a in range(0, n - 1, R):
+        block = pid[a:a + R, :]
+        cols = block.T.reshape(-1)  # j-major: for every j the R rows
+        out.append(cols[cols >= 0])
+    return np.concatenate(out)
+
+
 orders = {"natural": contiguous(np.arange(N)), "snake": emulate(deal(rows)),
+          "rows2": contiguous(interleave(2)), "rows4": contiguous(interleave(4)), "rows8": contiguous(interleave(8)),
           "tile16": contiguous(np.concatenate(tiles(16))), "tile32": contiguous(np.concatenate(tiles(32))),
           "tile16_snake": emulate(deal(tiles(16))), "tile32_snake": emulate(deal(tiles(32)))}
 
