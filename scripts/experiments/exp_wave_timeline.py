@@ -21,7 +21,8 @@ for a in range(0, n, 50):
     ctx.synchronize()
 N = n * (n - 1) // 2
 m = E.MetricRadonIntermediate(ctx, Ps, dtrs).setSampling("polynomial")
-m.debugSetXcdSchedule(int(os.environ.get("XCD_SCHEDULE", "1")))
+if hasattr(m, "debugSetXcdSchedule"):  # only with xcd_schedule_table.patch applied
+    m.debugSetXcdSchedule(int(os.environ.get("XCD_SCHEDULE", "1")))
 for _ in range(10):
     m.evaluate()
 ctx.enable_timing(True)
@@ -50,7 +51,7 @@ base = t0.min()
 s = (t0 - base).astype(np.float64) * 0.01  # us (100 MHz)
 e = (t1 - base).astype(np.float64) * 0.01
 dur = e - s
-out = {"xcd_schedule": int(os.environ.get("XCD_SCHEDULE", "1")), "kernel_us_by_events": 1e3 * float(np.median(ks[3:])), "kernel_span_us": float(e.max()),
+out = {"xcd_schedule": int(os.environ.get("XCD_SCHEDULE", "1")) if hasattr(m, "debugSetXcdSchedule") else None, "kernel_us_by_events": 1e3 * float(np.median(ks[3:])), "kernel_span_us": float(e.max()),
        "last_start_us": float(s.max()), "distinct_cus": int(len(np.unique(cuid)))}
 for name, sel in (("exact_heavy", cls == 0), ("deg6", cls == 6), ("deg8", cls == 8), ("deg10", cls == 10)):
     if sel.sum():
