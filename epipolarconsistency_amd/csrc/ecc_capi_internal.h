@@ -226,6 +226,12 @@ struct ecc_metric {
     // (which skips them) already runs on the context's stream
     hipStream_t side_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // Everything this metric has queued on the context's stream or its side stream is KNOWN to have completed: set by the
+    // synchronous evaluations once they have seen their result (the last thing they queued), cleared by whatever queues work for
+    // the metric.  The two-stream refit then needs no fork event: what the side stream reads -- records, device geometry, the
+    // row-paired copies, the pinned lists -- is written by this metric's own launches only, so nothing it must wait for is pending.
+    // (hipEventRecord + hipStreamWaitEvent in front of the first launch cost the shard step of an 8-rank job 3.5-4.7 us of 72.)
+    bool quiet = false;
     // ecc_metric_set_small_eval: evaluations of at most ECC_SMALL_EVAL_MAX_PAIRS pairs as ONE launch (small_eval_kernel.hip).
     // E1 of the views whose matrix changed since the device arrays were made is done on the host and handed over in the
     // kernel arguments (dev_Ps above says which views those are).

@@ -358,6 +358,8 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                  double* sum_d, bool synchronous = false)
 {
     ecc_ctx* ctx = m->ctx;
+    const bool was_quiet = m->quiet;  // nothing of this metric's is pending on either stream (ecc_capi_internal.h)
+    m->quiet = false;
     const int64_t n = m->n_views;
     const int64_t n_pairs = n * (n - 1) / 2;
     if ((int)m->dtrs.size() < m->n_views)
@@ -446,8 +448,9 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 }
             }
             if (split) {
-                // whatever the caller queued on the context's stream before this call comes first for the side stream too
-                HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
+                // whatever this metric queued on the context's stream before this call comes first for the side stream too
+                // (the side stream reads nothing anybody else writes); nothing to wait for after a synchronous evaluation
+                if (!was_quiet) HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
                 EccPairParams pa = p;
                 pa.skip_enabled = 1;
                 for (int v : changed) pa.skip_mask[v >> 5] |= 1u << (v & 31);
@@ -524,7 +527,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             HIP_TRY(_s);                                                      \
         }                                                                     \
     } while (0)
-                if (split) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
+                if (split && !was_quiet) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
                 SIDE_TRY(ecc_launch_k01(&q, ks));
                 if (split) {  // the changed pairs' own launch: records and values in their slots
                     q.pair_values = pair_values_d;
@@ -595,6 +598,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
 // is the one the full range resolves to, and the sum's order is fixed.
 int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, float** vals_out)
 {
+    m->quiet = false;  // (queues work; the synchronous callers set it again once they have seen the result)
     ecc_ctx* ctx = m->ctx;
     const int64_t n = m->n_views;
     if (n < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
@@ -708,6 +712,7 @@ ECC_EXPORT int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int
 ECC_EXPORT int ecc_metric_publish_scalar(ecc_metric* m, const double* value_d)
 {
     if (!m || !value_d) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    m->quiet = false;
     int rc = set_device(m->ctx);
     if (rc) return rc;
     arm_result(m);
@@ -722,6 +727,7 @@ ECC_EXPORT int ecc_metric_wait_scalar(ecc_metric* m, double* value)
     if (rc) return rc;
     HIP_TRY(wait_result(m, m->ctx->stream, value));
     m->done_generation = m->set_generation;  // the publishing kernel is ordered behind everything the metric launched
+    m->quiet = true;  // (and it has run)
     return ECC_OK;
 }
 
@@ -752,6 +758,7 @@ ECC_EXPORT int ecc_metric_evaluate_range(ecc_metric* m, int64_t first, int64_t c
     // an empty shard launches no kernel behind e1_kernel: its result slot says nothing about the stream
     if (count == 0) HIP_TRY(wait_stream_spin(ctx->stream));
     m->done_generation = m->set_generation;
+    m->quiet = true;  // the result is the last thing this call queued, and it has been seen
     return ECC_OK;
 }
 
@@ -799,6 +806,7 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
     HIP_TRY(wait_sum(m, &sum));
     ecc_stamp(m, 7);
     m->done_generation = m->set_generation;
+    m->quiet = true;  // the result is the last thing this call queued, and it has been seen
     *mean = sum / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
     return ECC_OK;
 }
@@ -811,6 +819,7 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
 // (ref for the pattern: Gui/Visualization.h:78-98 plotCostFunction, BASELINE config 5; a finite-difference gradient).
 ECC_EXPORT int ecc_metric_evaluate_poses(ecc_metric* m, int n_poses, const double* Ps_batch, int n_views, double* means)
 {
+    if (m) m->quiet = false;
     if (!m || !Ps_batch || !means) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (n_poses < 1) return ECC_OK;
     if (n_views < 2) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least two views (the reference divides 0/0 here)");
@@ -880,6 +889,7 @@ ECC_EXPORT int ecc_metric_evaluate_poses(ecc_metric* m, int n_poses, const doubl
 
 ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int n_pairs, float* out, double* mean)
 {
+    if (m) m->quiet = false;
     if (!m || !idx4 || !mean) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (n_pairs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "empty index list (the reference divides 0/0 here)");
     ecc_ctx* ctx = m->ctx;
@@ -982,6 +992,7 @@ ECC_EXPORT int ecc_metric_evaluate_external(ecc_metric* m, int num_Ps, const flo
                                             const int32_t* indices_d, float* K01s_d, float* out_d, float object_radius_mm,
                                             float dkappa, int use_corr)
 {
+    if (m) m->quiet = false;
     if (!m || !Cs_d || !PinvTs_d || !out_d) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (num_Ps < 2 || num_pairs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least two views and one pair");
     if ((int)m->dtrs.size() < num_Ps && !indices_d)

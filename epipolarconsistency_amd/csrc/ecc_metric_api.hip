@@ -95,6 +95,7 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
 
 ECC_EXPORT int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count)
 {
+    if (m) m->quiet = false;
     if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
     const int n = (int)m->dtrs.size();
     if (first < 0 || count < 0 || first > n || count > n - first) return fail(ECC_ERR_INVALID_ARGUMENT, "dtr range outside the metric's list");
@@ -125,6 +126,7 @@ int ensure_e1(ecc_metric* m)
         m->e1_pending = false;  // the device arrays already belong to these matrices (patched view by view, or set back)
         return ECC_OK;
     }
+    m->quiet = false;
     HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], m->n_views, m->PinvTs_d, m->Cs_d, m->ctx->stream));
     m->dev_Ps.assign(m->Ps_h[slot], m->Ps_h[slot] + n12);
     m->dev_valid = true;
@@ -332,6 +334,7 @@ ECC_EXPORT int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, i
                                                   float* rs0, float* rs1, float* kappas, float* radon0, float* radon1,
                                                   float* K01, double* ecc)
 {
+    if (m) m->quiet = false;
     if (!m || !n_samples) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     const int nD = (int)m->dtrs.size();
