@@ -277,8 +277,11 @@ int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs);
  * optimisation problems overwrite one view's matrix per cost-function call (ref: Gui/SingleImageMotion.h:84-90).
  * With the switch on, ecc_metric_set_projections only stages the matrices; E1 runs with the next call that needs it.
  * The refit of the changed pairs and their own pair-kernel launch run on a stream of the metric's own beside the
- * all-pairs launch (which skips them) on the context's stream; events order that stream after whatever the caller had
- * queued on the context's stream and the final sum after both (up to 512 views, no cost image; otherwise one stream). */
+ * all-pairs launch (which skips them) on the context's stream; an event orders that stream after whatever this metric had
+ * queued on the context's stream -- it reads nothing anybody else writes: records, device geometry, the row-paired copies
+ * (ecc_metric_refresh_dtrs), pinned lists -- and is left out when the previous call was a synchronous evaluation, which
+ * returns only after it has seen its result; the final sum is ordered after both streams (up to 512 views, no cost image;
+ * otherwise one stream). */
 #define ECC_RECORD_REUSE_MIN_PAIRS 4096
 #ifndef ECC_RECORD_REUSE_SPLIT_PAIRS
 #define ECC_RECORD_REUSE_SPLIT_PAIRS 8192
