@@ -163,7 +163,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the multi-rank path)")
-    ap.add_argument("--exchange", default="both", choices=["both", "shm", "collective"],
+    ap.add_argument("--exchange", default="both", choices=["both", "shm", "collective", "rccl"],
                     help="N > 1: per-evaluation sum of the partial results through the library's shared-memory "
                          "exchange, an all-reduce of a device scalar, or (default) both, one after the other")
     ap.add_argument("--no-live-pmc", action="store_true",
@@ -696,6 +696,22 @@ def main():
         elif abs(exchange.sum(float(rank + 1)) - world * (world + 1) / 2.0) > 1e-12:
             raise SystemExit("shared-memory exchange returned a wrong sum")
 
+    # the library's own RCCL communicator (ecc_comm_*): the all-reduce queued by the library between its sum kernel and the
+    # kernel that publishes the scalar -- no torch.distributed call on the step's path
+    comm = None
+    if grouped and args.backend == "nccl" and args.exchange in ("both", "rccl"):
+        try:
+            comm = sharding.RcclComm(ctx, rank, world, sharding.torch_broadcast_bytes(dev))
+        except Exception as e:
+            sys.stderr.write("rank %d: the library's RCCL communicator is unavailable (%s)\n" % (rank, e))
+            comm = None
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() == 0:
+            comm = None
+        elif abs(metric.evaluate_range_allreduce(comm, 0, 0) - 0.0) > 0:
+            raise SystemExit("the library's all-reduce of empty shards returned a non-zero sum")
+
     def make_step(mode):
         def step(k):
             metric.setProjectionMatrices(poses[k % len(poses)])
@@ -703,6 +719,8 @@ def main():
                 return metric.evaluate()
             if mode == "shm":
                 return sharding.exchanged_evaluate(metric, n, exchange, shard=(first, count))
+            if mode == "rccl":
+                return sharding.rccl_evaluate(metric, n, comm, shard=(first, count))
             # (the context's stream is torch's current stream here, so the reduced scalar can come back through the
             # metric's pinned result slot; with gloo the reduction runs on the host anyway)
             return sharding.distributed_evaluate(metric, n, sum_t, rank, world, shard=(first, count), publish=args.backend == "nccl")
@@ -752,13 +770,22 @@ def main():
         return dict(cold=blocks[0], steady=steady, blocks=blocks, last=last, step=step)
 
     ctx.enable_timing(False)  # no event records inside the timed region (they break back-to-back dispatch)
-    modes = ["single"] if not grouped else (
-        [m for m in ("shm", "collective") if (m != "shm" or exchange is not None)] if args.exchange == "both"
-        else (["shm"] if args.exchange == "shm" and exchange is not None else ["collective"]))
+    if not grouped:
+        modes = ["single"]
+    elif args.exchange == "both":
+        modes = [m for m in ("shm", "collective", "rccl") if (m != "shm" or exchange is not None) and (m != "rccl" or comm is not None)]
+    elif args.exchange == "shm" and exchange is not None:
+        modes = ["shm"]
+    elif args.exchange == "rccl" and comm is not None:
+        modes = ["rccl"]
+    else:
+        modes = ["collective"]
     results = {m: measure(m) for m in modes}
     # N > 1: the headline is the step with the all-reduce of the partial sums (RCCL with --backend nccl), the exchange
     # north_star names; the shared-memory exchange is reported next to it under timing.other_exchange
-    best = "collective" if "collective" in modes else modes[0]
+    # the headline is the RCCL all-reduce: issued by the library where its communicator exists (one call per step, everything
+    # stream-ordered), else through torch.distributed
+    best = "rccl" if "rccl" in modes else ("collective" if "collective" in modes else modes[0])
     res = results[best]
     elapsed, last, step = res["steady"], res["last"], res["step"]
     # pair-kernel duration: HIP events on the context's stream around the pair kernel alone, averaged over a
@@ -827,7 +854,8 @@ def main():
     bytes_per_pair = 64 * n_kappa + 68            # 2 views x 2 signs x 4 taps x 4 B + K01 + result
     launch_bytes = bytes_per_pair * count         # one launch = this rank's shard of pairs
     achieved = launch_bytes / pair_s / 1e9 if pair_ms > 0 else 0.0
-    exch_name = {"single": "none", "shm": "host shared memory", "collective": "all-reduce (%s)" % args.backend}
+    exch_name = {"single": "none", "shm": "host shared memory", "collective": "all-reduce (%s)" % args.backend,
+                 "rccl": "all-reduce (RCCL, issued by the library: ecc_metric_evaluate_range_allreduce)"}
 
     # ---- which roof bounds the pair kernel -------------------------------------------------------------------
     # The gather is served on chip (measured HBM traffic << algorithmic bytes), so the algorithmic bytes are priced
@@ -990,12 +1018,11 @@ def main():
         "pairs_evaluated_last_step": metric.last_evaluated_pairs(),  # the library's own count: this rank's whole shard
         "last_value": last,
     }
-    for m in modes:
-        if m != best:
-            out["timing"]["other_exchange"] = {"sum_exchange": exch_name[m],
-                                               "ms_per_step": 1e3 * results[m]["steady"] / args.steps,
-                                               "value": args.steps / results[m]["steady"],
-                                               "cold_ms_per_step": 1e3 * results[m]["cold"] / args.steps}
+    others = [{"sum_exchange": exch_name[m], "ms_per_step": 1e3 * results[m]["steady"] / args.steps,
+               "value": args.steps / results[m]["steady"], "cold_ms_per_step": 1e3 * results[m]["cold"] / args.steps}
+              for m in modes if m != best]
+    if others:
+        out["timing"]["other_exchange"] = others[0] if len(others) == 1 else others
 
     # ---- CPU baseline: the oracle timed on this box's host cores (rank 0, N = 1 only) -----------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

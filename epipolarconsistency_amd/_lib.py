@@ -110,6 +110,10 @@ SIGNATURES = {
     "ecc_pair_shard": (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "ecc_pair_shards_balanced": (_i, [_vp, _i, _d, _i, _vp]),
     "ecc_metric_balanced_shards": (_i, [_vp, _i, _vp]),
+    "ecc_comm_unique_id": (_i, [_vp]),
+    "ecc_comm_create": (_i, [_vp, _vp, _i, _i, _vp]),
+    "ecc_comm_destroy": (_i, [_vp]),
+    "ecc_metric_evaluate_range_allreduce": (_i, [_vp, _vp, _i64, _i64, _vp]),
     "ecc_group_metric_rebalance": (_i, [_vp]),
     "ecc_group_metric_evaluate_poses": (_i, [_vp, _i, _vp, _i, _vp]),
     "ecc_group_metric_create": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)]),

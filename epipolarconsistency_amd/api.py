@@ -611,6 +611,12 @@ class MetricRadonIntermediate:
                                                    C.c_void_p(vals.ctypes.data if want_pairs else 0), C.byref(s)))
         return (s.value, vals) if want_pairs else s.value
 
+    def evaluate_range_allreduce(self, comm, first, count):
+        """ecc_metric_evaluate_range_allreduce: this rank's pairs, then the RCCL all-reduce of the partial sums over the ranks of
+        `comm` (sharding.RcclComm), all stream-ordered inside one call; returns the sum over ALL ranks' pairs."""
+        check(_lib.lib().ecc_metric_evaluate_range_allreduce(self._h, comm._h, int(first), int(count), self._mean_ref))
+        return self._mean.value
+
     def evaluate_range_async(self, first, count, sum_tensor, pair_tensor=None):
         """Device-resident, non-synchronising form: sum_tensor is a 1-element float64 torch tensor."""
         check(_lib.lib().ecc_metric_evaluate_range_async(

@@ -435,7 +435,14 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
             bool split = C > 0 && !cost_d && !p.reference_arithmetic && n <= 32 * ECC_SKIP_WORDS &&
                          (m->record_reuse >= 2 || count >= ECC_RECORD_REUSE_SPLIT_PAIRS);
             if (split && (!m->side_stream || !m->fork_ev || !m->join_ev)) {  // all three or none (advisor, round 3)
-                if (hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                // A stream of its OWN priority class: the runtime deals the streams of one priority to a few hardware queues in turn,
+                // and a process that has created other streams before this one -- an RCCL communicator brings several -- can end up
+                // with this stream on the context stream's queue: the list launches then run AFTER the all-pairs launch instead of
+                // beside it (step 328 -> 345 us, scripts/experiments/comm_probe.py).  Highest priority: the few hundred pairs of the
+                // moved view also get their slots ahead of the big launch's waiting workgroups (lowest: shard step 69 -> 76 us).
+                int prio_lo = 0, prio_hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+                if (hipStreamCreateWithPriority(&m->side_stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
                     hipEventCreateWithFlags(&m->fork_ev, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&m->join_ev, hipEventDisableTiming) != hipSuccess) {
                     (void)hipGetLastError();
@@ -707,6 +714,41 @@ ECC_EXPORT int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int
         vals = m->pair_values_d;
     }
     return launch_range(m, first, count, vals, nullptr, nullptr, sum_d);
+}
+
+// ecc_rccl.cpp
+struct ecc_comm;
+extern "C" int ecc_comm_allreduce_sum_f64(ecc_comm* c, double* value_d);
+extern "C" ecc_ctx* ecc_comm_context(ecc_comm* c);
+
+// One rank's share of a sharded evaluation with the exchange inside the call: this rank's pairs -> float64 sum on the device
+// -> RCCL all-reduce over the communicator's ranks -> the scalar published to the pinned result slot -> poll.  Four
+// stream-ordered steps on the context's stream, one host call, nothing between them that waits for the host.
+// ref: MetricRadonIntermediate::evaluate's sum (...RadonIntermediate.cpp:216-224), sharded.
+ECC_EXPORT int ecc_metric_evaluate_range_allreduce(ecc_metric* m, ecc_comm* comm, int64_t first, int64_t count, double* sum_all)
+{
+    if (!m || !comm || !sum_all) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
+    if (ecc_comm_context(comm) != m->ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "the communicator belongs to another context");
+    ecc_stamp(m, 2);
+    ecc_ctx* ctx = m->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, count > 0 ? count : 1, ctx->stream);
+    if (rc) return rc;
+    arm_result(m);
+    // (the partial sum goes to the metric's device scalar, not to the result slot: the one-launch path for few pairs -- which
+    // adds on the host -- does not apply, and a shard of an evaluation runs in the whole evaluation's sampling mode anyway)
+    rc = launch_range(m, first, count, m->pair_values_d, nullptr, nullptr, m->sum_d, /*synchronous=*/true);
+    if (rc) return rc;
+    m->last_evaluated_pairs = count;
+    rc = ecc_comm_allreduce_sum_f64(comm, m->sum_d);
+    if (rc) return rc;
+    HIP_TRY(ecc_launch_publish_scalar(m->sum_d, m->sum_h_dev, ctx->stream));
+    HIP_TRY(wait_result(m, ctx->stream, sum_all));
+    ecc_stamp(m, 7);
+    m->done_generation = m->set_generation;
+    m->quiet = true;  // the published scalar is the last thing this call queued, and it has been seen
+    return ECC_OK;
 }
 
 ECC_EXPORT int ecc_metric_publish_scalar(ecc_metric* m, const double* value_d)

@@ -130,6 +130,57 @@ def exchanged_evaluate(metric, n_views, exchange, shard=None):
     return exchange.sum(metric.evaluate_range(first, count)) / n_pairs
 
 
+class RcclComm:
+    """The library's own RCCL communicator of one rank (ecc_comm_* of the C ABI): rank 0 makes the 128-byte id, `broadcast`
+    hands it to the others (a callable bytes -> bytes that every rank calls, e.g. over torch.distributed), then every rank joins
+    (ncclCommInitRank on the context's device: a collective)."""
+
+    def __init__(self, ctx, rank, world, broadcast):
+        from . import _lib
+        from .api import check
+        self._h = C.c_void_p()
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            check(_lib.lib().ecc_comm_unique_id(C.cast(buf, C.c_void_p)))
+        ident = broadcast(bytes(buf))
+        assert len(ident) == 128
+        check(_lib.lib().ecc_comm_create(ctx._h, C.c_char_p(ident), int(rank), int(world), C.byref(self._h)))
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.lib().ecc_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_broadcast_bytes(device=None, group=None):
+    """-> broadcast(bytes) over the torch.distributed process group, from rank 0 (for RcclComm); the identity without a group"""
+    def bc(b):
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return b
+        t = torch.tensor(list(b), dtype=torch.uint8, device=device if (device is not None and dist.get_backend(group) == "nccl") else "cpu")
+        dist.broadcast(t, 0, group=group)
+        return bytes(t.cpu().tolist())
+    return bc
+
+
+def rccl_evaluate(metric, n_views, comm, shard=None):
+    """One all-pairs evaluation sharded over the ranks of `comm` with the exchange inside the library call (pair kernel -> sum ->
+    ncclAllReduce -> publish, one stream); returns the mean.  shard: (first, count) of this rank (default: the equal-count chunk)."""
+    n_pairs = n_views * (n_views - 1) // 2
+    first, count = shard if shard is not None else pair_range(comm.rank, comm.world, n_pairs)
+    return metric.evaluate_range_allreduce(comm, first, count) / n_pairs
+
+
 def gather_cost_image(pair_values, n_views, rank, world, group=None, cost=None):
     """The n x n cost image of a sharded evaluation ("when the caller wants the cost image, a gather of
     each rank's pair values"): every rank passes the float32 values of its pair_range shard (evaluate_range(...,

@@ -526,6 +526,21 @@ int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m)
  * SINGLE NODE ONLY: the segment lives in this node's /dev/shm, so rank / world are the node-local rank and the number
  * of ranks on this node (LOCAL_RANK / LOCAL_WORLD_SIZE under torchrun); a job that spans nodes adds the node sums
  * with a collective of its own (sharding.open_exchange refuses WORLD_SIZE != LOCAL_WORLD_SIZE). */
+/* The same exchange as an RCCL all-reduce issued by the library (one process per GPU; the exchange north_star names).  Every rank
+ * owns a communicator on its context's device: rank 0 makes the 128-byte id (ecc_comm_unique_id) and the job hands it to the
+ * other ranks (bench.py: torch.distributed's broadcast); ecc_comm_create is RCCL's ncclCommInitRank -- a collective, it returns
+ * when all `world` ranks have called it.  ecc_metric_evaluate_range_allreduce then does one rank's share of an evaluation in
+ * ONE call: pair kernel over [first, first + count) -> float64 sum on the device -> ncclAllReduce over the ranks -> the scalar
+ * published to pinned host memory -> poll; all on the context's stream, no host round trip in between.  *sum_all is the sum over
+ * ALL ranks' pairs (the same bits on every rank); the mean is sum_all / (n (n - 1) / 2).  All ranks call it the same number of
+ * times.  RCCL is loaded at run time (dlopen of librccl.so.1: the copy the process already has -- PyTorch's -- or ROCm's);
+ * without it these calls fail with ECC_ERR_UNSUPPORTED and nothing else of the library is affected. */
+typedef struct ecc_comm ecc_comm;
+#define ECC_COMM_ID_BYTES 128
+int ecc_comm_unique_id(void* id128);
+int ecc_comm_create(ecc_ctx* ctx, const void* id128, int rank, int world, ecc_comm** out);
+int ecc_comm_destroy(ecc_comm* c);
+int ecc_metric_evaluate_range_allreduce(ecc_metric* m, ecc_comm* comm, int64_t first, int64_t count, double* sum_all);
 #define ECC_EXCHANGE_MAX_RANKS 64
 typedef struct ecc_exchange ecc_exchange;
 int ecc_exchange_open(const char* name, int rank, int world, ecc_exchange** out);

@@ -8,5 +8,5 @@ tag=$1; src=$2; shift; shift
 mkdir -p $B
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden -fno-slp-vectorize "$@" -c $C/$src -o $B/${tag}.o
 objs=$(ls $C/*.o | grep -v "/${src%.hip}.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $B/${tag}.o -lrt -lpthread -o $B/libecc_${tag}.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $B/${tag}.o -lrt -lpthread -ldl -o $B/libecc_${tag}.so
 echo built $B/libecc_${tag}.so

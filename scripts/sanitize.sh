@@ -41,7 +41,7 @@ for s in build.SOURCES:
            "-Xarch_host", "-fno-sanitize-recover=undefined", "-c", os.path.join(build.CSRC, s), "-o", o]
     subprocess.run(cmd, check=True)
     objs.append(o)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=undefined"] + objs + ["-lrt", "-lpthread", "-o", "$TMP/libecc_hip_ubsan.so"], check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=undefined"] + objs + ["-lrt", "-lpthread", "-ldl", "-o", "$TMP/libecc_hip_ubsan.so"], check=True)
 print("built $TMP/libecc_hip_ubsan.so")
 PY
 # a shared library is linked without the sanitizer runtime (the executable is expected to bring it): preload clang's

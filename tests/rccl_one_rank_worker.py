@@ -40,6 +40,8 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream(dev))
     stream = torch.cuda.current_stream()
     ctx = E.Context(0, stream=stream.cuda_stream)
+    # the library's own communicator (ecc_comm_*: ncclCommInitRank by the library, the id handed round by torch.distributed)
+    comm = sharding.RcclComm(ctx, 0, 1, sharding.torch_broadcast_bytes(dev))
     # (views, image size, bins): 66 pairs (one-launch path of the plain call), 780 pairs, 4950 pairs (two-wave split kernel off)
     for n, S, B, mode in ((12, 96, 64, "auto"), (40, 128, 96, "auto"), (100, 128, 96, "polynomial")):
         Ps = synthetic.short_scan(n, S, S, 0.308 * 1024.0 / S)
@@ -70,6 +72,13 @@ def main():
         metric.evaluate()
         metric.setProjectionMatrices(P2)
         got2 = sharding.distributed_evaluate(metric, n, sum_t, 0, 1, publish=True)
+        # the same two evaluations with the all-reduce issued by the library (ecc_metric_evaluate_range_allreduce)
+        got2_native = sharding.rccl_evaluate(metric, n, comm)
+        metric.setProjectionMatrices(Ps)
+        got_native = sharding.rccl_evaluate(metric, n, comm)
+        half = n_pairs // 2  # and as two shards of one rank's range: the parts add up to the whole sum
+        parts = metric.evaluate_range_allreduce(comm, 0, half) + metric.evaluate_range_allreduce(comm, half, n_pairs - half)
+        metric.setProjectionMatrices(P2)
         # allreduce_mean on a tensor the caller filled, through the metric's result slot
         t = torch.tensor([want2 * n_pairs], dtype=torch.float64, device=dev)
         got3 = sharding.allreduce_mean(t, n_pairs, metric=metric)
@@ -80,12 +89,14 @@ def main():
         out["cases"].append({"n": n, "pairs": n_pairs, "mode": mode, "same_stack": same_stack,
                              "want": want, "publish": got_publish, "item": got_item, "want_moved": want2, "publish_moved": got2,
                              "allreduce_mean": got3, "range_sum_over_pairs": s / n_pairs,
+                             "native": got_native, "native_moved": got2_native, "native_parts_mean": parts / n_pairs,
                              "cost_image_equal": bool(np.array_equal(cost, cost_plain)),
                              "cost_image_nonzero": int(np.count_nonzero(cost))})
         metric.close()
         for d in dtrs:
             d.close()
         del keep
+    comm.close()
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps(out))

@@ -2,8 +2,8 @@
 test box has (ref: the sum at EpipolarConsistencyRadonIntermediate.cpp:216-224 is the path's only exchange).
 
 The worker (tests/rccl_one_rank_worker.py) runs in a child process: RCCL communicator set-up, all_gather_into_tensor of the
-Radon-intermediate stack, ecc_metric_evaluate_range_async -> all_reduce -> publish_scalar_kernel -> poll, and the gathered
-cost image; every result must have the bits of the plain single-device call."""
+Radon-intermediate stack, ecc_metric_evaluate_range_async -> all_reduce -> publish_scalar_kernel -> poll, the same with the
+all-reduce issued by the library on a communicator of its own (ecc_comm_*), and the gathered cost image; every result must have the bits of the plain single-device call."""
 import json
 import os
 import subprocess
@@ -36,3 +36,6 @@ def test_sharded_evaluation_over_a_one_rank_rccl_group():
         assert abs(c["allreduce_mean"] - c["want_moved"]) <= 4e-16 * abs(c["want_moved"]), c
         assert c["range_sum_over_pairs"] == c["want"], c
         assert c["cost_image_equal"] and c["cost_image_nonzero"] > 0, c
+        # the all-reduce issued by the library itself (ecc_comm_*, ecc_metric_evaluate_range_allreduce): the same bits
+        assert c["native"] == c["want"] and c["native_moved"] == c["want_moved"], c
+        assert abs(c["native_parts_mean"] - c["want"]) <= 4e-16 * abs(c["want"]), c
