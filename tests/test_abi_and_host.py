@@ -108,3 +108,22 @@ def test_host_line_to_sample_dtr_matches_oracle(oracle_mod):
         got = line.copy()
         f = L.ecc_host_line_to_sample_dtr(C.c_void_p(got.ctypes.data), C.c_float(range_t))
         assert np.array_equal(got[:2], want[:2]) and bool(f) == folded
+
+
+def test_rccl_is_bound_at_run_time_and_makes_an_id():
+    """ecc_comm_unique_id: the library dlopens RCCL on first use (no link-time dependency: `ldd` shows none) and rank 0's
+    128-byte communicator id comes back non-trivial; creating the communicator itself needs a device (GPU suite)."""
+    import ctypes as C
+    import subprocess
+    from epipolarconsistency_amd import _lib
+    L = _lib.lib()
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    buf = (C.c_char * 128)()
+    rc = L.ecc_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != 0:  # a box without any librccl.so.1: the call says so and nothing else is affected
+        assert rc == 5 and b"librccl" in L.ecc_last_error()
+        return
+    assert any(b != b"\x00" for b in buf)
+    assert L.ecc_comm_unique_id(None) == 1  # ECC_ERR_INVALID_ARGUMENT
+    assert L.ecc_comm_destroy(None) == 0
