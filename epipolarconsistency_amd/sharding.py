@@ -141,10 +141,14 @@ class RcclComm:
         self._h = C.c_void_p()
         self.ctx, self.rank, self.world = ctx, rank, world
         buf = (C.c_char * 128)()
-        if rank == 0:
-            check(_lib.lib().ecc_comm_unique_id(C.cast(buf, C.c_void_p)))
+        why = ""
+        if rank == 0 and _lib.lib().ecc_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+            why = _lib.lib().ecc_last_error().decode(errors="replace")
+            buf = (C.c_char * 128)()  # all zero: every rank learns that there is no id and raises, nobody waits for a collective
         ident = broadcast(bytes(buf))
         assert len(ident) == 128
+        if not any(ident):
+            raise RuntimeError("no RCCL communicator id from rank 0" + (": " + why if why else ""))
         check(_lib.lib().ecc_comm_create(ctx._h, C.c_char_p(ident), int(rank), int(world), C.byref(self._h)))
 
     def close(self):
