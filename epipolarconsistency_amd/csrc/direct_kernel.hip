@@ -23,6 +23,10 @@
 #include "ecc_host_geometry.h"
 #include "ecc_layout.h"
 #include "ecc_sampling.h"
+#ifdef ECC_DIRECT_STATS  // scripts/direct_stats.py: slabs, steps through the tile / through global memory (radon_kernel.hip's scheme)
+__device__ unsigned long long g_direct_stats[8];
+#define ECC_SLAB_STAT(i, v) atomicAdd(&g_direct_stats[i], (unsigned long long)(v))
+#endif
 #include "ecc_slab_tile.h"
 
 namespace {
@@ -460,3 +464,15 @@ extern "C" hipError_t ecc_launch_direct_batch(const EccDirectParams* p, double* 
     }
     return e;
 }
+
+#ifdef ECC_DIRECT_STATS
+extern "C" __attribute__((visibility("default"))) void ecc_debug_direct_stats(unsigned long long* out, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_direct_stats), sizeof(unsigned long long) * 8);
+    if (reset) {
+        const unsigned long long z[8] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_direct_stats), z, sizeof(z));
+    }
+}
+#endif
