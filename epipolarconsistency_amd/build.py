@@ -18,8 +18,10 @@ HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", "ecc_sampling.h", "ecc_worker_
 # radon_kernel.hip: the SLP vectoriser packs the two samples of the derivative pair into v_pk_*_f32 pairs, which
 # cost two issue slots each on gfx950 (no gain, scripts/micro/valu_rate.hip) plus ~12 v_mov per iteration to
 # arrange operands -- scalar code is ~15 % faster there; the pair kernel gains 7 % the same way (0.548 -> 0.512 ms).
+# direct_kernel.hip (round 5): the same walker as the Radon kernel was still built WITH the vectoriser -- 9.2-9.4 -> 7.45-7.55 ms per
+# 496-pair evaluation of 1024^2 images without it (A/B/A/B on one box, bit-identical sums; unrolling its tile loop on top: nothing).
 PER_SOURCE_FLAGS = {"radon_kernel.hip": ["-fno-slp-vectorize"], "pairs_kernel.hip": ["-fno-slp-vectorize"],
-                    "small_eval_kernel.hip": ["-fno-slp-vectorize"]}
+                    "small_eval_kernel.hip": ["-fno-slp-vectorize"], "direct_kernel.hip": ["-fno-slp-vectorize"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function"]
 
