@@ -31,8 +31,15 @@ for _ in range(8):
     m.evaluate()
     ks.append(ctx.last_kernel_ms("pairs"))
 ctx.enable_timing(False)
+import time
+t_s = float(os.environ.get("SUSTAIN_S", "0"))  # evaluations back to back for this long first: the socket at its power cap
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < t_s:
+    m.evaluate()
 order = ""
 K = m.debug_K01(0, N)  # its own all-pairs launch, stamped (the first one warms the debug buffers)
+for _ in range(int(200 * min(t_s, 1.0))):
+    m.evaluate()
 K = m.debug_K01(0, N)
 raw = K.view(np.uint32)
 if os.environ.get("STAMPS_OUT"):
