@@ -75,6 +75,19 @@ struct EccRadonParams {
 #endif
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
+// The polynomials cover |kappa| <= ecc_kappa_fit(kappa_max); a pair whose range goes on beyond that (kappa_max = pi/2: the baseline
+// passes through the object, 3.5 % of the benchmark's pairs) takes its inner samples from the polynomials and the rest from the
+// exact per-sample loop.  Over the whole pi/2 a curve of every such pair switches its fold state and the fit is refused; on the
+// inner 0.98 rad (62 % of the samples) none does and the fit is good to 3e-7 bins in the median, 1.3e-6 at worst over 300 such
+// pairs of the benchmark's scan
+// (scripts/analysis/heavy_pairs_inner_range.py).  k01_kernel and the pair kernels both derive the bound from the record's kappa_max.
+#ifndef ECC_POLY_KAPPA_FIT_MAX
+#define ECC_POLY_KAPPA_FIT_MAX 0.98f
+#endif
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline float ecc_kappa_fit(float kappa_max) { return kappa_max < ECC_POLY_KAPPA_FIT_MAX ? kappa_max : ECC_POLY_KAPPA_FIT_MAX; }
 
 // What k01_kernel hands to pairs_kernel for one pair (296 bytes, read with scalar loads).
 struct EccPairRecord {
@@ -85,7 +98,7 @@ struct EccPairRecord {
     int poly_ok;   // 0: exact per-sample path; else the sample coordinates of both views are given by the polynomials
                    // below, evaluated up to the degree poly_ok & ~1 (4, 6, 8 or 10; economised in k01_kernel, higher coefficients
                    // are zero); bit 0: k01's bound on the polynomials says no sample can reach a clamp of the pair kernel
-    float x_scale; // x = kappa * x_scale in (0, 1]; the -kappa samples are the same polynomials at -x
+    float x_scale; // x = kappa * x_scale in (0, 1], x_scale = 1 / ecc_kappa_fit(kappa_max); the -kappa samples are the same polynomials at -x
     unsigned fold[2];                  // per view: 0x80000000 when the (alpha+pi, -t) fold applies on the +kappa side
                                        // (it is the opposite on the -kappa side: the line is negated there)
     float ca[2][ECC_POLY_DEG + 3];     // angle coordinate (padded texel units): monomial coefficients in x, c0 first;

@@ -430,9 +430,11 @@ __device__ __forceinline__ float sample_at(float xa, float yd, unsigned fold, co
 // two prefetches 0.41 ms -- a gather instruction costs the L1 the same whatever it fetches.
 // DEG: the degree the record asks for -- the fit is of degree ECC_POLY_DEG, k01_kernel lowers it where Chebyshev
 // economisation costs less than 2e-8 bins (see economise).
+// kappa_fit: the end of the polynomials' range (ecc_kappa_fit(kappa_max)); returns the lane's first sample index past it --
+// where the exact loop of a pair with kappa_fit < kappa_max carries on.
 template <bool DERIV, bool CORR, int PITCH4, int DEG, int WPP = 1, bool NOCLAMP = false>
-__device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
-                                                float kappa_max, float w06, const SlabView sv0, const SlabView sv1,
+__device__ __forceinline__ int kappa_loop_poly(int lane, int k_limit, const EccPairRecord* __restrict__ rec, float dkappa,
+                                                float kappa_max, float kappa_fit, float w06, const SlabView sv0, const SlabView sv1,
                                                 float n_alpha_f, float n_t_f, float pitch4_f, double& acc, double& mom2,
                                                 double& mom3, double& mom4, int sub = 0, float* stage = nullptr)
 {
@@ -470,7 +472,7 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
         for (; k + 64 < k_limit; k += 128, kf += 128.f) {
             const float kappa_a = dkappa * 0.5f + dkappa * kf;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
             const float kappa_b = dkappa * 0.5f + dkappa * (kf + 64.f);
-            if (kappa_b >= kappa_max) break;  // kappa_a < kappa_b: the single-step loop below takes what is left
+            if (kappa_b >= kappa_fit) break;  // kappa_a < kappa_b: the single-step loop below takes what is left
             const float xA = kappa_a * xs, zA = xA * xA, xB = kappa_b * xs, zB = xB * xB;
             float a0p, a0m, d0p, d0m, a1p, a1m, d1p, d1m, b0p, b0m, e0p, e0m, b1p, b1m, e1p, e1m;
             poly_pm<DEG>(ca[0], ca[0][ECC_POLY_DEG + 1], ca[0][ECC_POLY_DEG + 2], false, xA, zA, a0p, a0m);
@@ -502,7 +504,7 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
     }
     for (; k < k_limit; k += 64 * WPP, kf += (float)(64 * WPP)) {
         const float kappa = dkappa * 0.5f + dkappa * kf;  // ref: ...RadonIntermediate.cu:259 (same fp32 ops)
-        if (kappa >= kappa_max) break;
+        if (kappa >= kappa_fit) break;
         const float x = kappa * xs, z = x * x;
         float xa0p, xa0m, yd0p, yd0m, xa1p, xa1m, yd1p, yd1m;
         poly_pm<DEG>(ca[0], ca[0][ECC_POLY_DEG + 1], ca[0][ECC_POLY_DEG + 2], false, x, z, xa0p, xa0m);
@@ -533,20 +535,22 @@ __device__ __forceinline__ void kappa_loop_poly(int lane, int k_limit, const Ecc
             mom4 += (double)(one_over_n * (v0p * v1p + v0m * v1m));
         }
     }
+    return k;
 }
 
 
-// The kappa loop of one pair, exact per-sample path.
+// The kappa loop of one pair, exact per-sample path; k_first: the lane's first sample (lane + 64 sub, or where the polynomial
+// loop stopped).
 template <bool DERIV, bool CORR, bool REDUCE, int PITCH4, int WPP = 1>
-__device__ __forceinline__ void kappa_loop(int lane, int k_limit, const float (&K0)[8], const float (&K1)[8],
+__device__ __forceinline__ void kappa_loop(int k_first, int k_limit, const float (&K0)[8], const float (&K1)[8],
                                            const SlabView sv0, const SlabView sv1, float n_alpha_f, float n_t_f,
                                            float dist_scale, float dist_bias, float pitch4_f, double& acc, double& mom2,
-                                           double& mom3, double& mom4, int sub = 0, float* stage = nullptr)
+                                           double& mom3, double& mom4, float* stage = nullptr)
 {
     const float dkappa = K1[6], kappa_max = K1[7];
     // (Two kappa steps per trip with all eight gathers issued before the first is consumed were measured for the pairs
     // with kappa_max > pi/4, which wait on memory: no change, 0.3349 vs 0.3340 ms for the benchmark's launch.)
-    for (int k = lane + 64 * sub; k < k_limit; k += 64 * WPP)
+    for (int k = k_first; k < k_limit; k += 64 * WPP)
         if (!kappa_step<DERIV, CORR, REDUCE, PITCH4, WPP>(k, K0, K1, dkappa, kappa_max, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
                                                           dist_bias, pitch4_f, acc, mom2, mom3, mom4, stage))
             return;  // kappa only grows: this lane is done
@@ -1031,8 +1035,8 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         g.n_t = (double)p.n_t;
         curve_geometry(Kv, g);
         if (LANES == 1) {
-            if (angle_role) ok = fit_coordinate<true>(T, g, (double)kappa_max, fold0, c) ? 1 : 0;  // wave-uniform branch
-            else ok = fit_coordinate<false>(T, g, (double)kappa_max, fold0, c) ? 1 : 0;
+            if (angle_role) ok = fit_coordinate<true>(T, g, (double)ecc_kappa_fit(kappa_max), fold0, c) ? 1 : 0;  // wave-uniform branch
+            else ok = fit_coordinate<false>(T, g, (double)ecc_kappa_fit(kappa_max), fold0, c) ? 1 : 0;
         }
     } else {
 #pragma unroll
@@ -1050,8 +1054,8 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         curve_geometry(Kv, g);
         double cw[N];
         bool fw = false;
-        const bool okw = angle_role ? fit_coordinate_wide<true, LANES>(T, g, fit ? (double)kappa_max : 0.0, fw, cw, jl)
-                                    : fit_coordinate_wide<false, LANES>(T, g, fit ? (double)kappa_max : 0.0, fw, cw, jl);
+        const bool okw = angle_role ? fit_coordinate_wide<true, LANES>(T, g, fit ? (double)ecc_kappa_fit(kappa_max) : 0.0, fw, cw, jl)
+                                    : fit_coordinate_wide<false, LANES>(T, g, fit ? (double)ecc_kappa_fit(kappa_max) : 0.0, fw, cw, jl);
         if (fit) {
             ok = okw ? 1 : 0;
             fold0 = fw;
@@ -1120,7 +1124,7 @@ __device__ __forceinline__ void k01_fit_block(const EccPairParams& p, long long 
         const int d0 = sh.ok_flags[0][slot], d1 = sh.ok_flags[1][slot], d2 = sh.ok_flags[2][slot], d3 = sh.ok_flags[3][slot];
         const int degree = (d0 && d1 && d2 && d3) ? max(max(d0 & ~1, d1 & ~1), max(d2 & ~1, d3 & ~1)) : 0;
         r->poly_ok = degree ? (degree | (d0 & d1 & d2 & d3 & 1)) : 0;  // bit 0: no sample can reach a clamp
-        r->x_scale = degree ? (float)(1.0 / (double)kappa_max) : 0.f;
+        r->x_scale = degree ? (float)(1.0 / (double)ecc_kappa_fit(kappa_max)) : 0.f;  // the polynomials' range (ecc_layout.h)
     }
     __syncthreads();
 }
@@ -1135,27 +1139,22 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
                                                 int lane, double& acc, double& mom2, double& mom3, double& mom4, int sub = 0,
                                                 float* stage = nullptr)
 {
-    float K0[8], K1[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        K0[i] = uniformf(rec->K0[i]);
-        K1[i] = uniformf(rec->K1[i]);
-    }
     const unsigned pitch4 = (unsigned)p.pitch * 8u;  // row pitch of the paired copies in bytes
     const SlabView sv0 = {(GlobalBytes)p.dtrs[iD0], pitch4};
     const SlabView sv1 = {(GlobalBytes)p.dtrs[iD1], pitch4};
     const float n_alpha_f = (float)p.n_alpha, n_t_f = (float)p.n_t;
-    const float dist_scale = n_t_f / p.range_t, dist_bias = fmaf(0.5f, n_t_f, 0.5f);
     const float pitch4_f = (float)pitch4;
-    const float kappa_max = K1[7];
+    const float kappa_max = uniformf(rec->K1[7]);
 
     const bool reduce = kappa_max > 0.785398163397448f;  // wave-uniform
     const int poly_raw = __builtin_amdgcn_readfirstlane(rec->poly_ok);
     const int poly_ok = poly_raw & ~1;       // the degree
     const bool in_range = (poly_raw & 1) != 0;  // no sample of this pair can reach a clamp (k01_fit_block's bound)
+    int k_first = lane + 64 * sub;  // the lane's first sample of the exact loop
     if (poly_ok) {
+        const float kappa_fit = ecc_kappa_fit(kappa_max), dkappa = uniformf(rec->K1[6]), w06 = uniformf(rec->K0[6]);
 #define ECC_POLY_LOOP_NC(P4, DEG, NC) \
-    kappa_loop_poly<DERIV, CORR, P4, DEG, WPP, NC>(lane, p.k_limit, rec, K1[6], kappa_max, K0[6], sv0, sv1, n_alpha_f, n_t_f, pitch4_f, acc, mom2, mom3, mom4, sub, stage)
+    k_first = kappa_loop_poly<DERIV, CORR, P4, DEG, WPP, NC>(lane, p.k_limit, rec, dkappa, kappa_max, kappa_fit, w06, sv0, sv1, n_alpha_f, n_t_f, pitch4_f, acc, mom2, mom3, mom4, sub, stage)
 #define ECC_POLY_LOOP(P4, DEG) ECC_POLY_LOOP_NC(P4, DEG, false)
         if (p.wide_offsets) {
             if (poly_ok <= 6) ECC_POLY_LOOP(-1, 6);
@@ -1176,7 +1175,20 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
         }
 #undef ECC_POLY_LOOP
 #undef ECC_POLY_LOOP_NC
-    } else if (reduce && p.quads) {
+        if (!(kappa_fit < kappa_max)) return;  // wave-uniform: the polynomials covered the whole range (the normal case)
+        // what follows is read from the record afterwards: nothing of the exact loop occupies a register during the loops above
+        // (their scalar registers are the kernel's occupancy limit, pairs_kernel.hip)
+        if constexpr (WPP == 1) asm volatile("" : "+s"(rec));  // (the record pointer of pairs_kernel is a scalar)
+    }
+    // the exact loop: the whole range of a pair without polynomials, the outer part of one whose range exceeds theirs
+    float K0[8], K1[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        K0[i] = uniformf(rec->K0[i]);
+        K1[i] = uniformf(rec->K1[i]);
+    }
+    const float dist_scale = n_t_f / p.range_t, dist_bias = fmaf(0.5f, n_t_f, 0.5f);
+    if (reduce && p.quads) {
         // kappa_max > pi/4: in practice the pairs whose baseline passes through the object (kappa_max = pi/2).  Their
         // sampling curve crosses the whole Radon intermediate diagonally -- the 64 samples of a gather sit in ~17
         // different angle rows, one cache line each in the row-major copies -- and on their own they are memory-bound
@@ -1188,21 +1200,21 @@ __device__ __forceinline__ void pair_accumulate(const EccPairParams& p, const Ec
         // they sample.  Useful for per-sample / index-list workloads made of such pairs.
         const SlabView q0 = {(GlobalBytes)p.quads[iD0], p.quad_group_bytes};
         const SlabView q1 = {(GlobalBytes)p.quads[iD1], p.quad_group_bytes};
-        kappa_loop<DERIV, CORR, true, ECC_QUAD_LAYOUT, WPP>(lane, p.k_limit, K0, K1, q0, q1, n_alpha_f, n_t_f, dist_scale, dist_bias,
-                                                       pitch4_f, acc, mom2, mom3, mom4, sub, stage);
+        kappa_loop<DERIV, CORR, true, ECC_QUAD_LAYOUT, WPP>(k_first, p.k_limit, K0, K1, q0, q1, n_alpha_f, n_t_f, dist_scale, dist_bias,
+                                                       pitch4_f, acc, mom2, mom3, mom4, stage);
     } else if (p.wide_offsets) {
-        kappa_loop<DERIV, CORR, true, -1, WPP>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
-                                          pitch4_f, acc, mom2, mom3, mom4, sub, stage);
+        kappa_loop<DERIV, CORR, true, -1, WPP>(k_first, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
+                                          pitch4_f, acc, mom2, mom3, mom4, stage);
     } else if (pitch4 == 6400u) {  // 768 distance bins, the reference's default (Gui/ComputeRadonIntermediate.hxx:43-44)
         if (reduce)
-            kappa_loop<DERIV, CORR, true, 6400, WPP>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
-                                                dist_bias, pitch4_f, acc, mom2, mom3, mom4, sub, stage);
+            kappa_loop<DERIV, CORR, true, 6400, WPP>(k_first, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+                                                dist_bias, pitch4_f, acc, mom2, mom3, mom4, stage);
         else
-            kappa_loop<DERIV, CORR, false, 6400, WPP>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
-                                                 dist_bias, pitch4_f, acc, mom2, mom3, mom4, sub, stage);
+            kappa_loop<DERIV, CORR, false, 6400, WPP>(k_first, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
+                                                 dist_bias, pitch4_f, acc, mom2, mom3, mom4, stage);
     } else {
-        kappa_loop<DERIV, CORR, true, 0, WPP>(lane, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
-                                         pitch4_f, acc, mom2, mom3, mom4, sub, stage);
+        kappa_loop<DERIV, CORR, true, 0, WPP>(k_first, p.k_limit, K0, K1, sv0, sv1, n_alpha_f, n_t_f, dist_scale, dist_bias,
+                                         pitch4_f, acc, mom2, mom3, mom4, stage);
     }
 }
 

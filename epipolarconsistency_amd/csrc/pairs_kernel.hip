@@ -69,6 +69,13 @@ __device__ __forceinline__ void k01_block(const EccPairParams& p, K01Shared<LANE
     }
 }
 
+// The wide forms (LANES > 1: the few hundred pairs of a moved view, refitted on the side stream while the all-pairs launch runs)
+// must fit the hole ONE retiring workgroup of pairs_kernel leaves on its compute unit: 72 + 8 vector registers per SIMD.  At 79
+// registers k01_kernel<16> is through in 45 us beside the big launch and the moved pairs' own launch follows beside it as well; at
+// 126 -- what the compiler chose after a change elsewhere in this file -- it found no room until the big launch had drained
+// (283 us, kernel trace of bench.py) and the step paid for the refit and the list launch in full (+15 us).  (Forcing 80 with
+// amdgpu_num_vgpr(40) makes that version spill 212 bytes; writing the change so that the compiler stays at 79 by itself does
+// not.)  tests/test_kernel_resources.py fails the CPU suite when a build leaves the budget.
 template <int LANES>
 __global__ __launch_bounds__(256) void k01_kernel(EccPairParams p)
 {
@@ -99,8 +106,16 @@ __global__ __launch_bounds__(256) void k01_patched_kernel(EccPairParams p, EccSm
 // 0.329 ms).  With the allocation capped at 96 the compiler moves 40 scalar values into vector-register lanes (v_writelane /
 // v_readlane), every one of them outside the sampling loops: 0.329 -> 0.320 ms, 2 850-2 870 -> 2 935 evaluations/s A/B/A/B on one
 // box, the same bits.  A cap of 80 (8 waves) puts 258 such moves into the loops as well and ends at the same 0.320 ms.
+// (Since the exact loop reads its K0 / K1 only after the polynomial loops -- pair_accumulate -- the kernel needs 88 and nothing
+// is moved into lanes any more.)
+// Seven waves also need at most 72 vector registers (7 x 72 <= 512); the two-steps-per-trip loop sits right at that line (72 or 77
+// from one edit to the next), so it is pinned: amdgpu_num_vgpr counts BOTH halves of gfx950's unified register file and a kernel
+// without accumulation registers gets all of it as vector registers -- 36 means 72 (measured: 72 is accepted and changes nothing,
+// 36 gives 72 without scratch).  amdgpu_waves_per_eu(7, 8) reaches 65 registers and a 0.51 ms launch (0.305 without), on the
+// kernel of the round before this change as well: do not use it.  tests/test_kernel_resources.py reads the numbers back from
+// the built library.
 #ifndef PK_OCCUPANCY
-#define PK_OCCUPANCY __attribute__((amdgpu_num_sgpr(96)))
+#define PK_OCCUPANCY __attribute__((amdgpu_num_sgpr(96), amdgpu_num_vgpr(36)))
 #endif
 template <bool DERIV, bool CORR>
 __global__ __launch_bounds__(PK_MAIN_THREADS) PK_OCCUPANCY void pairs_kernel(EccPairParams p)

@@ -235,8 +235,8 @@ def _exact_coords(K, kappa, n_alpha, n_t, range_t):
 
 def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
     """The per-pair polynomials of the pair-geometry kernel reproduce the exact line -> texel mapping to 2e-5 bins on
-    both the +kappa and the -kappa side (incl. the float-Pi offset between the two fold states), and pairs whose
-    fold state switches inside the kappa range are sent to the exact path."""
+    both the +kappa and the -kappa side (incl. the float-Pi offset between the two fold states) over the range they are fitted
+    on (min(kappa_max, 0.98 rad)), and pairs whose fold state switches inside that range are sent to the exact path."""
     import epipolarconsistency_amd as E
     from epipolarconsistency_amd import synthetic
     n, S, B = 24, 512, 384
@@ -248,18 +248,22 @@ def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
     recs = m.debug_polynomials(0, n_pairs)
     K01 = m.debug_K01(0, n_pairs)
     range_t = np.float32(B) * np.float32(np.sqrt(2.0) * S / B)
-    n_ok, worst, n_free = 0, 0.0, 0
+    n_ok, worst, n_free, n_partial, n_partial_ok = 0, 0.0, 0, 0, 0
+    KAPPA_FIT_MAX = float(np.float32(0.98))
     for ij, (r, K) in enumerate(zip(recs, K01)):
         kmax = float(K[15])
+        kfit = min(kmax, KAPPA_FIT_MAX)  # the polynomials' range (ecc_layout.h: ecc_kappa_fit); the pair kernel samples the rest exactly
+        n_partial += kfit < kmax
         if not r["poly_ok"]:
-            # the exact mapping of such a pair has a fold switch (or the baseline passes through the object)
-            kap = np.linspace(-kmax, kmax, 2001)
+            # the exact mapping of such a pair has a fold switch inside the fitted range (or the baseline passes through the object)
+            kap = np.linspace(-kfit, kfit, 2001)
             sw = any(len(np.unique(_exact_coords(K[8 * v:8 * v + 8], kap, B, B, range_t)[2])) > 1 for v in (0, 1))
             assert sw or kmax > 1.5
             continue
         n_ok += 1
-        assert abs(r["x_scale"] * kmax - 1) < 1e-6
-        kap = np.linspace(1e-4, kmax, 257)
+        n_partial_ok += kfit < kmax
+        assert abs(r["x_scale"] * kfit - 1) < 1e-6
+        kap = np.linspace(1e-4, kfit, 257)
         x = kap * r["x_scale"]
         for v in (0, 1):
             Kv = K[8 * v:8 * v + 8]
@@ -288,6 +292,7 @@ def test_fitted_sample_polynomials(gpu_ctx, oracle_mod):
                     n_free += 1
     assert n_ok > 0.8 * n_pairs
     assert worst < 2e-5, worst
+    assert n_partial > 0 and n_partial_ok > 0, (n_partial, n_partial_ok)  # pairs through the object: inner range from polynomials
     assert n_free > 0 and any(r["poly_ok"] and not r["clamp_free"] for r in recs) or n_free == 4 * n_ok  # both loops, or all free
 
 
