@@ -108,6 +108,88 @@ def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan):
     m1.close()
 
 
+def test_pairs_through_the_object_mix_polynomial_and_exact_samples(gpu_ctx, oracle_mod):
+    """Pairs whose kappa range goes beyond the polynomials' 0.98 rad (ecc_layout.h: ecc_kappa_fit; kappa_max = pi/2 when the
+    baseline passes through the object) take the inner samples from the polynomials and the rest from the exact loop.  On a
+    short scan with many such pairs: they do carry polynomials; their values agree with the per-sample path and with the
+    oracle like everybody else's; every kernel form gives the bits of the one-wave kernel (eight / four / two waves per pair,
+    the small-evaluation kernel, row-quad copies for the exact part); the correlation variant agrees with the oracle."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    n, S, B = 72, 128, 96
+    rng = np.random.default_rng(21)
+    Ps = synthetic.short_scan(n, S, S, 0.308 * 1024 / S)
+    host = [rng.standard_normal((B, B)).astype(np.float32) for _ in range(4)]
+    base = [E.RadonIntermediate.from_host(gpu_ctx, h, S, S) for h in host]
+    dtrs = [base[v % 4] for v in range(n)]
+    n_pairs = n * (n - 1) // 2
+    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSmallEval(False).setRecordReuse(False)
+    K = m.debug_K01(0, n_pairs)
+    recs = m.setSampling("polynomial").debug_polynomials(0, n_pairs)
+    far = np.flatnonzero(K[:, 15] > 0.98 + 1e-3)
+    mixed = np.array([q for q in far if recs[q]["poly_ok"]], np.int64)
+    assert len(far) >= 60 and len(mixed) >= 0.8 * len(far), (len(far), len(mixed))
+    for q in mixed[:10]:
+        assert abs(recs[q]["x_scale"] * np.float32(0.98) - 1) < 1e-6
+    # one wave per pair, all pairs (2556 <= 4096 would take the split kernel: ask for ranges above that with a repeated list below)
+    total_p, vp = m.evaluate_range(0, n_pairs, want_pairs=True)
+    total_s, vs = m.setSampling("per_sample").evaluate_range(0, n_pairs, want_pairs=True)
+    assert np.isfinite(vp).all() and (vp[mixed] > 0).all()
+    rel = np.abs(vp - vs) / np.maximum(np.abs(vs), 1e-30)
+    assert rel[mixed].max() < 2e-3 and abs(total_p - total_s) < 1e-5 * abs(total_s) * max(1.0, 30 / np.sqrt(n_pairs)), (rel[mixed].max(), total_p, total_s)
+    assert not np.array_equal(vp[mixed], vs[mixed])  # (they are on a different path now)
+    idx_all = np.array([(*E.get_ij(int(q), n), *E.get_ij(int(q), n)) for q in range(n_pairs)], np.int32)
+    dt_host = [host[v % 4] for v in range(n)]
+    sub = mixed[:: max(1, len(mixed) // 24)][:24]
+    want = oracle_mod.evaluate_pairs(Ps, dt_host, S, S, idx_all[sub])
+    got = vp[sub]
+    assert np.abs(got - want["pairs"]).max() < 2e-3 * np.abs(want["pairs"]).max(), (got, want["pairs"])
+    # every launch form against the 4-pairs-per-workgroup, one-wave-per-pair kernel: a list of > 4096 entries goes through it
+    m.setSampling("polynomial")
+    big = np.tile(mixed, 4096 // len(mixed) + 2)
+    out_big = np.empty(len(big), np.float32)
+    m.evaluate(idx_all[big], out_big)
+    for L in (1, 5, 700, 2000, 4000):  # eight, eight, eight, four, two waves per pair
+        sel = big[:L]
+        out = np.empty(L, np.float32)
+        m.evaluate(idx_all[sel], out)
+        assert np.array_equal(out, out_big[:L]), L
+    assert np.array_equal(out_big[:len(mixed)], vp[mixed])  # (the all-pairs launch of 2556 pairs used two waves per pair)
+    m_small = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSampling("polynomial")  # small evaluations: one launch (small_eval_kernel)
+    out = np.empty(300, np.float32)
+    m_small.evaluate(idx_all[big[:300]], out)
+    assert np.array_equal(out, out_big[:300])
+    m_small.close()
+    # row-quad copies serve the exact part of such a pair: the same taps, the same bits
+    gpu_ctx.debugSetQuadCopies(True)
+    try:
+        base_q = [E.RadonIntermediate.from_host(gpu_ctx, h, S, S) for h in host]
+        mq = E.MetricRadonIntermediate(gpu_ctx, Ps, [base_q[v % 4] for v in range(n)]).setSmallEval(False).setRecordReuse(False).setSampling("polynomial")
+    finally:
+        gpu_ctx.debugSetQuadCopies(False)
+    tq, vq = mq.evaluate_range(0, n_pairs, want_pairs=True)
+    assert tq == total_p and np.array_equal(vq, vp)
+    mq.close()
+    # correlation variant: the moments of the polynomial part and of the exact part in one sum
+    m.useCorrelation(True)
+    oracle_mod.set_use_corr(1)
+    try:
+        want_c = oracle_mod.evaluate_pairs(Ps, dt_host, S, S, idx_all[sub])
+    finally:
+        oracle_mod.set_use_corr(0)
+    out = np.empty(len(sub), np.float32)
+    m.evaluate(idx_all[sub], out)
+    assert np.abs(out - want_c["pairs"]).max() < 5e-5, (out, want_c["pairs"])
+    cost = np.zeros((n, n), np.float32)
+    m.evaluate(cost)  # the one-wave kernel with the cost image
+    for q in sub:
+        i, j = E.get_ij(int(q), n)
+        assert abs(cost[j, i] - want_c["pairs"][list(sub).index(q)]) < 5e-5
+    m.close()
+    for d in base + base_q:
+        d.close()
+
+
 def test_auto_resolves_from_the_evaluation_not_the_shard(gpu_ctx):
     """ECC_SAMPLING_AUTO is a function of the size of the EVALUATION (n (n - 1) / 2 for evaluate_all and every range /
     shard of it): 40 views = 780 pairs -> polynomial, although every one of three shards has fewer than 512 pairs; a
