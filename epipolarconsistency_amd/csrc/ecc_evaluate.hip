@@ -539,7 +539,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 if (split) {  // the changed pairs' own launch: records and values in their slots
                     q.pair_values = pair_values_d;
                     q.value_slots = q.record_slots;
-                    q.beside_another_launch = 1;
+                    q.beside_another_launch = count >= ECC_BESIDE_ONE_WAVE_MIN_PAIRS ? 2 : 1;
                     SIDE_TRY(ecc_launch_pairs(&q, m->side_stream));
                     SIDE_TRY(hipEventRecord(m->join_ev, m->side_stream));
                     SIDE_TRY(hipStreamWaitEvent(ctx->stream, m->join_ev, 0));

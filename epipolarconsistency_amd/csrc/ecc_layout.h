@@ -73,6 +73,9 @@ struct EccRadonParams {
 #ifndef ECC_PAIRS_SPLIT8_MAX
 #define ECC_PAIRS_SPLIT8_MAX 768   // ... eight (one pair per 512-thread workgroup) up to here
 #endif
+#ifndef ECC_BESIDE_ONE_WAVE_MIN_PAIRS
+#define ECC_BESIDE_ONE_WAVE_MIN_PAIRS 32768  // all-pairs launches from here on: the moved view's pairs beside them with one wave per pair
+#endif
 #define ECC_POLY_DEG 10
 #define ECC_POLY_CHECKS 3
 // The polynomials cover |kappa| <= ecc_kappa_fit(kappa_max); a pair whose range goes on beyond that (kappa_max = pi/2: the baseline
@@ -128,7 +131,8 @@ struct EccPairParams {
     float* pair_values;        // optional, `count` floats (local pair order)
     const int32_t* value_slots;  // optional, `count` entries: pair_values[value_slots[k]] instead of pair_values[k]
     int reference_split;       // reference arithmetic: waves per pair, 1 or 4 (4: one pair per workgroup, for few pairs)
-    int beside_another_launch; // host only: this launch runs beside a chip-filling one on another stream -- 256-thread workgroups only
+    int beside_another_launch; // host only: this launch runs beside a chip-filling one on another stream -- 1: 256-thread workgroups only;
+                               // 2: that launch lasts far longer than one pair's wave -- one wave per pair (pairs_kernel), see ecc_launch_pairs
                                // (a 512-thread workgroup waits until eight wave slots of ONE CU are free at once: the moved view's
                                // 399 pairs took 304 us instead of 29 beside the all-pairs launch)
     float* cost;               // optional n x n cost image (index i + j*n)
