@@ -454,10 +454,15 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                     split = false;
                 }
             }
-            if (split) {
-                // whatever this metric queued on the context's stream before this call comes first for the side stream too
-                // (the side stream reads nothing anybody else writes); nothing to wait for after a synchronous evaluation
-                if (!was_quiet) HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
+            // The all-pairs launch (skipping the changed views' pairs) goes out FIRST when it is long (the refit then trickles
+            // into the holes its retiring workgroups leave and is through long before it), and AFTER the refit's launch when it
+            // is a shard-sized one: beside a 46-us launch of 2 718 workgroups (1.5 rounds of resident ones) the ten workgroups of
+            // k01_kernel<16> waited 29 us for room (5 alone), the moved pairs' launch ended after the big one and the sum paid the
+            // late cross-stream join (12 us instead of 6) -- kernel trace of scripts/step_fixed_cost.py 8.
+            // (One rank's share of an 8-rank job, 10 873 pairs: 70.1 / 71.0 -> 65.9 / 65.9 us per step A/B/A/B; of a 4-rank job,
+            // 22 323 pairs, 3.1 rounds: the old order is as good or better -- 101 / 99 against 102 / 114 us.)
+            const bool refit_first = split && count < ECC_REFIT_FIRST_MAX_PAIRS;
+            auto launch_all_pairs = [&]() -> int {
                 EccPairParams pa = p;
                 pa.skip_enabled = 1;
                 for (int v : changed) pa.skip_mask[v >> 5] |= 1u << (v & 31);
@@ -469,6 +474,16 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 }
                 pairs_launched = true;
                 ecc_stamp(m, 4);
+                return ECC_OK;
+            };
+            if (split) {
+                // whatever this metric queued on the context's stream before this call comes first for the side stream too
+                // (the side stream reads nothing anybody else writes); nothing to wait for after a synchronous evaluation
+                if (!was_quiet) HIP_TRY(hipEventRecord(m->fork_ev, ctx->stream));
+                if (!refit_first) {
+                    rc = launch_all_pairs();
+                    if (rc) return rc;
+                }
             }
             std::vector<char>& is_changed = m->scratch_is_changed;
             std::vector<int32_t>&idx = m->scratch_idx, &slots = m->scratch_slots, &refs = m->scratch_refs, &patch_of = m->scratch_patch_of;
@@ -536,6 +551,13 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
     } while (0)
                 if (split && !was_quiet) SIDE_TRY(hipStreamWaitEvent(m->side_stream, m->fork_ev, 0));
                 SIDE_TRY(ecc_launch_k01(&q, ks));
+                if (refit_first) {
+                    const int rl = launch_all_pairs();
+                    if (rl) {
+                        (void)hipStreamSynchronize(m->side_stream);
+                        return rl;
+                    }
+                }
                 if (split) {  // the changed pairs' own launch: records and values in their slots
                     q.pair_values = pair_values_d;
                     q.value_slots = q.record_slots;
@@ -555,6 +577,10 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
                 m->e1_pending = false;  // workgroup 0 of the list launch stores the patches: PinvTs / Cs are current again
             }
             // (L = 0: nothing was launched; dev_Ps says which views of the device arrays are behind, ensure_e1 will look)
+            if (refit_first && !pairs_launched) {  // no pair of this range contains a changed view
+                rc = launch_all_pairs();
+                if (rc) return rc;
+            }
             reused = true;
         }
     }

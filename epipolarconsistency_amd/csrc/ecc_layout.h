@@ -73,6 +73,9 @@ struct EccRadonParams {
 #ifndef ECC_PAIRS_SPLIT8_MAX
 #define ECC_PAIRS_SPLIT8_MAX 768   // ... eight (one pair per 512-thread workgroup) up to here
 #endif
+#ifndef ECC_REFIT_FIRST_MAX_PAIRS
+#define ECC_REFIT_FIRST_MAX_PAIRS 16384  // all-pairs launches below this (under two rounds of resident workgroups): the refit's launch goes out first
+#endif
 #ifndef ECC_BESIDE_ONE_WAVE_MIN_PAIRS
 #define ECC_BESIDE_ONE_WAVE_MIN_PAIRS 32768  // all-pairs launches from here on: the moved view's pairs beside them with one wave per pair
 #endif
