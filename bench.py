@@ -171,7 +171,7 @@ def parse():
                          "measures the pair kernel's HBM bytes and vector instructions for the roofline objects; the "
                          "committed profiles/pmc_current.json is used instead")
     ap.add_argument("--blocks", type=int, default=0,
-                    help="number of timed K-step blocks (0 = automatic: 5 to 25, about 0.6 s in total)")
+                    help="number of timed K-step blocks (0 = automatic: 5 to 60, about 1.2 s in total)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-sample-stride", type=int, default=1,
@@ -755,10 +755,11 @@ def main():
         blocks, last = [], None
         el, last = timed_block(step, 0)
         blocks.append(el)
-        # automatic: about 0.6 s of timed steps, 5 to 25 blocks -- the driver's 20-step blocks last 8 ms each and the clocks
-        # of a box that idled through the host-side set-up take 5+ such blocks to settle (round 4: blocks 1-5 0.40-0.45 ms
-        # per step, 6-9 0.364-0.370); the median of 9 sat on the ramp
-        n_blocks = args.blocks if args.blocks > 0 else int(min(25, max(5, 0.6 / max(el, 1e-6))))
+        # automatic: about 1.2 s of timed steps, 5 to 60 blocks -- the driver's 20-step blocks last 7 ms each and the clocks
+        # of a box that idled through the host-side set-up take a few tenths of a second to settle (round 4: blocks 1-5
+        # 0.40-0.45 ms per step, 6-9 0.364-0.370; round 5, one box: eight 67-ms blocks falling from 0.333 to 0.312 ms per step,
+        # the median of nine on the ramp); every block's time is in timing.blocks_ms_per_step
+        n_blocks = args.blocks if args.blocks > 0 else int(min(60, max(5, 1.2 / max(el, 1e-6))))
         if grouped:  # every rank must run the same number of blocks
             nb = torch.tensor([n_blocks], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
             dist.broadcast(nb, 0)

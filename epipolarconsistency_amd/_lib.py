@@ -133,6 +133,7 @@ SIGNATURES = {
     "ecc_debug_set_small_eval_bound": (_i, [_vp, _i64]),
     "ecc_debug_set_result_polling": (_i, [_i]),
     "ecc_debug_set_quad_copies": (_i, [_vp, _i]),
+    "ecc_ctx_set_quad_copies": (_i, [_vp, _i]),
     "ecc_debug_small_stamps": (_i, [_vp, _i]),
     "ecc_debug_step_stamps": (_i, [_vp, _vp]),
     "ecc_ctx_enable_timing": (_i, [_vp, _i]),

@@ -54,8 +54,15 @@ class Context:
         return ms.value
 
     def debugSetQuadCopies(self, on=True):
-        """ecc_debug_set_quad_copies (experiments): metrics created from this context afterwards build row-quad copies."""
+        """ecc_debug_set_quad_copies (experiments' old name): setQuadCopies("on" / "off")."""
         check(_lib.lib().ecc_debug_set_quad_copies(self._h, 1 if on else 0))
+        return self
+
+    def setQuadCopies(self, mode="auto"):
+        """ecc_ctx_set_quad_copies: whether metrics created from this context afterwards build row-quad copies of their Radon
+        intermediates (4x the slab memory; the exact part of the kappa_max = pi/2 pairs samples them; same bits): "auto"
+        (default: while they fit a quarter of the free device memory), "off", "on"."""
+        check(_lib.lib().ecc_ctx_set_quad_copies(self._h, {"auto": -1, "off": 0, "on": 1}[mode]))
         return self
 
     def setRadonArithmetic(self, mode="exact"):

@@ -269,12 +269,16 @@ ECC_EXPORT int ecc_debug_set_result_polling(int on)
     return ECC_OK;
 }
 
-ECC_EXPORT int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on)
+ECC_EXPORT int ecc_ctx_set_quad_copies(ecc_ctx* ctx, int mode)
 {
     if (!ctx) return fail(ECC_ERR_INVALID_ARGUMENT, "context is null");
-    ctx->quad_copies = on != 0;
+    if (mode != ECC_QUAD_COPIES_AUTO && mode != ECC_QUAD_COPIES_OFF && mode != ECC_QUAD_COPIES_ON)
+        return fail(ECC_ERR_INVALID_ARGUMENT, "quad-copy mode must be ECC_QUAD_COPIES_AUTO, _OFF or _ON");
+    ctx->quad_copies = mode;
     return ECC_OK;
 }
+
+ECC_EXPORT int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on) { return ecc_ctx_set_quad_copies(ctx, on ? ECC_QUAD_COPIES_ON : ECC_QUAD_COPIES_OFF); }
 
 ECC_EXPORT int ecc_ctx_enable_timing(ecc_ctx* ctx, int enable)
 {

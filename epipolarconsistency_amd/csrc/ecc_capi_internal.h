@@ -92,7 +92,7 @@ struct ecc_ctx {
     hipStream_t stream = nullptr;
     bool timing = false;
     int radon_arithmetic = ECC_RADON_EXACT;  // ecc_radon_set_arithmetic
-    bool quad_copies = false;                // ecc_debug_set_quad_copies: metrics created from this context build row-quad copies
+    int quad_copies = ECC_QUAD_COPIES_AUTO;  // ecc_ctx_set_quad_copies: whether metrics created from this context build row-quad copies
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // pair, radon, preprocess start/stop
     bool ev_valid[3] = {false, false, false};
     // trig table cache for the Radon kernel

@@ -58,11 +58,20 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) ptable[k] = m->paired_d + (size_t)paired_floats * k;
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->paired_table_d, ptable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
-    // row-quad copies: opt-in (ecc_debug_set_quad_copies on the context; 4x the slab memory, see pairs_kernel.hip); offsets
-    // must fit 32 bits
+    // row-quad copies (ecc_ctx_set_quad_copies; 4x the slab memory, see pair_accumulate): offsets must fit 32 bits; by default
+    // they are built while all of them together take at most a quarter of the device memory that is free now (400 views
+    // of 768 x 768 bins: 3.9 GB) -- the same bits with or without them
     std::vector<const float*> qtable(n_dtrs);
     m->quad_floats = (int64_t)((m->n_alpha + 1 + 3) / 4) * m->pitch * 16;
-    const bool want_quads = m->quad_floats * 4 < ((int64_t)1 << 32) && ctx->quad_copies;
+    bool want_quads = m->quad_floats * 4 < ((int64_t)1 << 32) && ctx->quad_copies != ECC_QUAD_COPIES_OFF;
+    if (want_quads && ctx->quad_copies == ECC_QUAD_COPIES_AUTO) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            free_b = 0;
+        }
+        want_quads = (uint64_t)m->quad_floats * 4u * (uint64_t)n_dtrs <= (uint64_t)free_b / 4u;
+    }
     if (e == hipSuccess && want_quads) {
         e = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
         if (e == hipSuccess) e = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);

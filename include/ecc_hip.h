@@ -564,14 +564,24 @@ int ecc_ctx_last_kernel_ms(ecc_ctx* ctx, int which, float* ms);
  *   the path's other conditions still apply); -1 restores the default.  Same bits either way.
  * ecc_debug_set_result_polling: process-wide; 0 = synchronous calls wait for the stream instead of polling the pinned
  *   result slot.  Same bits.
- * ecc_debug_set_quad_copies: metrics created from ctx AFTERWARDS also build row-quad copies of their Radon intermediates
- *   (4x the slab memory) for the pairs with kappa_max > pi/4.  Same bits.
+ * ecc_debug_set_quad_copies: ecc_ctx_set_quad_copies(ctx, on ? ECC_QUAD_COPIES_ON : ECC_QUAD_COPIES_OFF), the experiments' old name.
  * ecc_debug_small_stamps: only in builds with -DECC_SMALL_STAMPS (returns ECC_ERR_INVALID_ARGUMENT otherwise). */
 #define ECC_POLY_ECONOMISE_TOL_BINS 2e-8f
 int ecc_debug_set_poly_tolerance(ecc_metric* m, float tol_bins);
 int ecc_debug_set_small_eval_bound(ecc_metric* m, int64_t max_pairs);
 int ecc_debug_set_result_polling(int on);
 int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on);
+/* Row-quad copies.  Metrics created from ctx AFTERWARDS keep, beside the row-paired copy of every Radon intermediate (one
+ * 16-byte footprint per sample), a second copy in which four consecutive angle rows share a 128-byte line (4x the slab's
+ * memory: 3.9 GB for 400 views of 768 x 768 bins).  The pairs whose baseline passes through the object (kappa_max = pi/2,
+ * 3.5 % of a short scan's pairs, a fifth of its evaluation time) cross the Radon intermediates diagonally, a new angle row
+ * every sample or two; the exact part of their sampling reads the row-quad copies: +2 % evaluations/s on the 400-view
+ * benchmark, bit-identical values (tests/test_gpu_sampling_modes.py).  ECC_QUAD_COPIES_AUTO (default): built while all of
+ * them together take at most a quarter of the device memory free at the time; _OFF: never; _ON: always (offsets permitting). */
+#define ECC_QUAD_COPIES_AUTO (-1)
+#define ECC_QUAD_COPIES_OFF 0
+#define ECC_QUAD_COPIES_ON 1
+int ecc_ctx_set_quad_copies(ecc_ctx* ctx, int mode);
 int ecc_debug_small_stamps(unsigned long long* out, int n_blocks);
 /* Host clock (seconds, std::chrono::steady_clock) at fixed points of the metric's last ecc_metric_set_projections and last
  * synchronous all-pairs / range evaluation -- where the host's share of a step goes (scripts/step_fixed_cost.py):

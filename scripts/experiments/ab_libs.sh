@@ -1,8 +1,9 @@
 #!/bin/bash
 # usage (GPU box): scripts/experiments/ab_libs.sh <tag> [<tag> ...]  -- bench.py once per tag, in the order given (repeat a tag for
-# A/B/A/B), each with ECC_HIP_LIB=scripts/experiments/_build/libecc_<tag>.so; one summary line per run
+# A/B/A/B), each with ECC_HIP_LIB=scripts/experiments/_build/libecc_<tag>.so; one summary line per run.  BENCH=<script> runs that
+# instead of bench.py (scripts/experiments/bench_with_quads.py)
 i=0
-for t in "$@"; do i=$((i+1)); ECC_HIP_LIB=$PWD/scripts/experiments/_build/libecc_$t.so python bench.py --no-cpu-baseline --no-live-pmc --no-power > gpurun_out/ab_${i}_$t.json 2>gpurun_out/ab_${i}_$t.err; done
+for t in "$@"; do i=$((i+1)); ECC_HIP_LIB=$PWD/scripts/experiments/_build/libecc_$t.so python ${BENCH:-bench.py} --no-cpu-baseline --no-live-pmc --no-power > gpurun_out/ab_${i}_$t.json 2>gpurun_out/ab_${i}_$t.err; done
 python - "$@" <<PY
 import json, sys
 for i, t in enumerate(sys.argv[1:], 1):

@@ -83,17 +83,19 @@ def test_reference_mode_variants(gpu_ctx, oracle_mod, small_scan):
 
 
 def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan):
-    """Opt-in row-quad copies (ecc_debug_set_quad_copies on the context before the metric is created): the pairs with kappa_max > pi/4 on the per-sample
-    path sample them instead of the row-paired copies -- the same taps, the same arithmetic, identical values; also
-    after refreshRadonIntermediates()."""
+    """Row-quad copies (ecc_ctx_set_quad_copies on the context before the metric is created; built by default while they fit):
+    the pairs with kappa_max > pi/4 on the per-sample path, and the exact part of the pairs whose range exceeds the
+    polynomials', sample them instead of the row-paired copies -- the same taps, the same arithmetic, identical values;
+    also after refreshRadonIntermediates()."""
     import epipolarconsistency_amd as E
     s = small_scan
-    m0, _ = _metric(gpu_ctx, s)
-    gpu_ctx.debugSetQuadCopies(True)
+    gpu_ctx.setQuadCopies("off")
     try:
+        m0, _ = _metric(gpu_ctx, s)
+        gpu_ctx.setQuadCopies("on")
         m1, dtrs1 = _metric(gpu_ctx, s)
     finally:
-        gpu_ctx.debugSetQuadCopies(False)
+        gpu_ctx.setQuadCopies("auto")
     K = m0.debug_K01(0, 28)
     assert (K[:, 15] > np.pi / 4).sum() >= 3, "the scan needs pairs with kappa_max > pi/4 for this test"
     for mode in ("per_sample", "polynomial"):
@@ -123,7 +125,11 @@ def test_pairs_through_the_object_mix_polynomial_and_exact_samples(gpu_ctx, orac
     base = [E.RadonIntermediate.from_host(gpu_ctx, h, S, S) for h in host]
     dtrs = [base[v % 4] for v in range(n)]
     n_pairs = n * (n - 1) // 2
-    m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSmallEval(False).setRecordReuse(False)
+    gpu_ctx.setQuadCopies("off")
+    try:
+        m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setSmallEval(False).setRecordReuse(False)
+    finally:
+        gpu_ctx.setQuadCopies("auto")
     K = m.debug_K01(0, n_pairs)
     recs = m.setSampling("polynomial").debug_polynomials(0, n_pairs)
     far = np.flatnonzero(K[:, 15] > 0.98 + 1e-3)
@@ -160,13 +166,13 @@ def test_pairs_through_the_object_mix_polynomial_and_exact_samples(gpu_ctx, orac
     m_small.evaluate(idx_all[big[:300]], out)
     assert np.array_equal(out, out_big[:300])
     m_small.close()
-    # row-quad copies serve the exact part of such a pair: the same taps, the same bits
-    gpu_ctx.debugSetQuadCopies(True)
+    # row-quad copies serve the exact part of such a pair (the default; `m` above was made without): the same taps, the same bits
+    gpu_ctx.setQuadCopies("on")
     try:
         base_q = [E.RadonIntermediate.from_host(gpu_ctx, h, S, S) for h in host]
         mq = E.MetricRadonIntermediate(gpu_ctx, Ps, [base_q[v % 4] for v in range(n)]).setSmallEval(False).setRecordReuse(False).setSampling("polynomial")
     finally:
-        gpu_ctx.debugSetQuadCopies(False)
+        gpu_ctx.setQuadCopies("auto")
     tq, vq = mq.evaluate_range(0, n_pairs, want_pairs=True)
     assert tq == total_p and np.array_equal(vq, vp)
     mq.close()
