@@ -208,6 +208,11 @@ inline ecc_ctx* default_context()
 /// ECC metric moves by < 2e-6 relative on means over pairs).
 inline void setRadonArithmetic(bool contracted) { detail::check(ecc_radon_set_arithmetic(detail::default_context(), contracted ? ECC_RADON_FMA : ECC_RADON_EXACT)); }
 
+/// Not in the reference: ecc_ctx_set_quad_copies of the default context -- whether MetricRadonIntermediates created afterwards
+/// keep row-quad copies of their Radon intermediates (4x the slab memory; the pairs whose baseline passes through the object
+/// sample them; bit-identical values, ~2 % per evaluation).  Default: ECC_QUAD_COPIES_AUTO (built while they fit).
+inline void setQuadCopies(int mode) { detail::check(ecc_ctx_set_quad_copies(detail::default_context(), mode)); }
+
 /// Not in the reference: evaluate() of every MetricRadonIntermediate created afterwards is sharded over these HIP
 /// devices (one host thread per device inside the library).  Call before the first dtr / metric is created.
 inline void setDefaultDevices(const std::vector<int>& devices)
