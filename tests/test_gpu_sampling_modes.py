@@ -102,6 +102,9 @@ def test_row_quad_copies_give_the_same_bits(gpu_ctx, small_scan):
         a = m0.setSampling(mode).evaluate_range(0, 28, want_pairs=True)
         b = m1.setSampling(mode).evaluate_range(0, 28, want_pairs=True)
         assert a[0] == b[0] and np.array_equal(a[1], b[1]), mode
+    from epipolarconsistency_amd import _lib
+    with pytest.raises(E.EccError):  # only ECC_QUAD_COPIES_AUTO / _OFF / _ON
+        _lib.check(_lib.lib().ecc_ctx_set_quad_copies(gpu_ctx._h, 7))
     m1.refreshRadonIntermediates()
     b = m1.setSampling("per_sample").evaluate_range(0, 28, want_pairs=True)
     a = m0.setSampling("per_sample").evaluate_range(0, 28, want_pairs=True)
