@@ -549,7 +549,9 @@ __device__ __forceinline__ void kappa_loop(int k_first, int k_limit, const float
 {
     const float dkappa = K1[6], kappa_max = K1[7];
     // (Two kappa steps per trip with all eight gathers issued before the first is consumed were measured for the pairs
-    // with kappa_max > pi/4, which wait on memory: no change, 0.3349 vs 0.3340 ms for the benchmark's launch.)
+    // with kappa_max > pi/4, which wait on memory: no change, 0.3349 vs 0.3340 ms for the benchmark's launch.  Again in round 5
+    // for the exact part on the row-quad copies, at the kernel's 72-register budget: 36 bytes of scratch and 3 157 / 3 179 / 3 162
+    // -> 3 128 / 3 123 / 3 109 evaluations/s A/B/A/B/A/B -- slower.)
     for (int k = k_first; k < k_limit; k += 64 * WPP)
         if (!kappa_step<DERIV, CORR, REDUCE, PITCH4, WPP>(k, K0, K1, dkappa, kappa_max, sv0, sv1, n_alpha_f, n_t_f, dist_scale,
                                                           dist_bias, pitch4_f, acc, mom2, mom3, mom4, stage))
