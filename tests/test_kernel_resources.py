@@ -2,7 +2,8 @@
 scripts/kernel_resources.py parses the offload bundles and the AMDGPU metadata notes of libecc_hip.so.
 
   * pairs_kernel: at most 96 scalar registers (+16 the hardware keeps per wave: 7 x 112 <= 800) and at most 72
-    vector registers (7 x 72 <= 512) -- seven waves per SIMD; no scratch.
+    vector registers (7 x 72 <= 512) -- seven waves per SIMD; no scratch (8 bytes of it are a reload per trip inside the sampling
+    loops: +14 % per launch); and not fewer than 65 vector registers in the sum-of-squares kernels (see the test).
   * k01_kernel<8 / 16>, k01_patched_kernel (the refit of a moved view's pairs on the side stream): at most 80 vector registers,
     the hole one retiring pairs_kernel workgroup leaves (72 + the 8 that were free); with 126 the refit found no room until the
     all-pairs launch had drained and the step paid for it in full (CHANGELOG, round 5).
@@ -32,6 +33,10 @@ def test_pair_kernel_runs_seven_waves_per_simd():
     for name, k in main.items():
         assert k[".sgpr_count"] <= 96, (name, k[".sgpr_count"])
         assert k[".vgpr_count"] <= 72, (name, k[".vgpr_count"])
+        # (the sum-of-squares kernels: below 65 registers the compiler's scheduler has aimed at eight waves per SIMD, which the
+        # scalar registers do not allow, and given up the overlap of a trip's eight gathers for it: 7 % per launch, CHANGELOG round 5)
+        if "ELb0EEE" in name:
+            assert k[".vgpr_count"] >= 65, (name, k[".vgpr_count"])
         assert k[".private_segment_fixed_size"] == 0, name
         assert k[".group_segment_fixed_size"] == 0, name
 
