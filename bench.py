@@ -353,29 +353,56 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
 
     mine = list(range(rank, 600, world))
     poses = [pose(q) for q in mine]  # producing a pose is the optimiser's work, not the metric's
+    flat = np.ascontiguousarray(np.stack(poses))
     for q in range(3):
         metric.setProjectionMatrices(poses[q % len(poses)]).evaluate()  # warm-up
+    metric.setProjectionMatrices(packed)
+    metric.evaluate_poses(flat[:16])  # (allocates the batch's scratch)
+    metric.setProjectionMatrices(packed)
     values = np.zeros(600)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # ecc_metric_evaluate_poses: the rank's poses two deep on its one context -- the hand-over of pose k + 1 overlaps the
-    # device's work on pose k; the same launches in the same order as one setProjectionMatrices + evaluate per pose
-    values[mine] = metric.evaluate_poses(poses)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # the same poses one at a time (what round 3 timed), and the proof that nothing but the waiting changed
-    t1 = time.perf_counter()
-    one_by_one = np.array([metric.setProjectionMatrices(Pq).evaluate() for Pq in poses])
-    torch.cuda.synchronize()
-    elapsed_seq = time.perf_counter() - t1
-    if not np.array_equal(one_by_one, values[mine]):
-        raise SystemExit("rank %d: two-deep pose evaluation changed %d of %d values" % (rank, int((one_by_one != values[mine]).sum()), len(mine)))
+
+    def fenced(fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    # ecc_metric_evaluate_poses: this rank's poses handed over as FULL matrix sets; the library finds the moved view of every pose
+    # and runs all of them as ONE record launch, ONE pair launch and ONE segmented sum (csrc/ecc_poses.hip)
+    ctx.enable_timing(True)
+    got, elapsed = fenced(lambda: metric.evaluate_poses(flat))
+    batch_pairs_ms = ctx.last_kernel_ms("pairs")
+    ctx.enable_timing(False)
+    batched = metric.last_batched_poses()
+    values[mine] = got
+    # the same poses as deltas of the current matrices (what a caller that knows which view it moves hands over: 96 bytes a pose)
+    metric.setProjectionMatrices(packed)
+    d_off = np.arange(len(poses) + 1, dtype=np.int32)
+    d_views = np.full(len(poses), moving, np.int32)
+    d_Ps = np.ascontiguousarray(flat[:, moving, :])
+    got_sparse, elapsed_sparse = fenced(lambda: metric.evaluate_pose_deltas_packed(d_off, d_views, d_Ps))
+    # the rounds-4/5 forms, for the record: two deep on the stream; one setProjectionMatrices + evaluate at a time; the latter in
+    # the pose-delta mode (only the moved view's pairs re-evaluated per step)
+    metric.setPoseBatching(False)
+    got_two_deep, elapsed_two_deep = fenced(lambda: metric.evaluate_poses(flat))
+    one_by_one, elapsed_seq = fenced(lambda: np.array([metric.setProjectionMatrices(Pq).evaluate() for Pq in poses]))
+    metric.setIncremental(True)
+    metric.setProjectionMatrices(packed).evaluate()
+    got_delta, elapsed_delta = fenced(lambda: np.array([metric.setProjectionMatrices(Pq).evaluate() for Pq in poses]))
+    metric.setIncremental(False)
+    metric.setPoseBatching(True)
+    for name, other in (("deltas", got_sparse), ("two-deep", got_two_deep), ("pose-delta mode", got_delta), ("batched", values[mine])):
+        if not np.array_equal(one_by_one, other):
+            raise SystemExit("rank %d: the %s form changed %d of %d values" % (rank, name, int((one_by_one != other).sum()), len(mine)))
+    if batched != len(mine):
+        raise SystemExit("rank %d: %d of %d poses went through the batch" % (rank, batched, len(mine)))
     if world > 1:
         on = dev if args.backend == "nccl" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=on)
@@ -396,11 +423,20 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
                       "k01_record_reuse": "on (library default)", "ranks_seen_by_collective_backend": ranks_seen,
                       "devices": devices_seen},
            "ms_per_step_note": "per rank: each rank evaluates %d poses" % len(mine),
-           "timing": {"value_is": "ecc_metric_evaluate_poses: this rank's poses two deep on its context",
+           "timing": {"value_is": "ecc_metric_evaluate_poses (full matrix sets per pose): this rank's poses as one batched record / pair / "
+                                  "sum launch each (csrc/ecc_poses.hip); every value bit-identical to setProjectionMatrices + evaluate",
+                      "batch_pair_kernel_ms": batch_pairs_ms, "batch_pairs": len(mine) * (n - 1),
+                      "pose_deltas": {"value": len(mine) * world / elapsed_sparse, "ms_total": 1e3 * elapsed_sparse,
+                                      "note": "ecc_metric_evaluate_pose_deltas: the same poses handed over as (moved view, its matrix)"},
+                      "two_deep": {"value": len(mine) * world / elapsed_two_deep, "ms_per_pose": 1e3 * elapsed_two_deep / len(mine),
+                                   "note": "ecc_metric_set_pose_batching(0): one stream-ordered all-pairs evaluation per pose, two deep "
+                                           "(rounds 4-5's headline)"},
                       "one_pose_at_a_time": {"value": len(mine) * world / elapsed_seq if elapsed_seq > 0 else None,
                                              "ms_per_pose": 1e3 * elapsed_seq / len(mine),
-                                             "note": "rank 0's poses by setProjectionMatrices + evaluate each, after the timed "
-                                                     "run; all values bit-identical to the two-deep run"}},
+                                             "note": "rank 0's poses by setProjectionMatrices + evaluate each"},
+                      "pose_delta_mode": {"value": len(mine) * world / elapsed_delta, "ms_per_pose": 1e3 * elapsed_delta / len(mine),
+                                          "note": "the same with ecc_metric_set_incremental: only the moved view's pairs per step"},
+                      "all_forms_bit_identical": True},
            "min_at_step": [int(np.argmin(values[p])) for p in range(6)],
            "values_checksum": float(values.sum())}
     if rank == 0 and not args.no_cpu_baseline:

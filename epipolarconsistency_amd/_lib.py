@@ -74,6 +74,10 @@ SIGNATURES = {
     "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
     "ecc_metric_evaluate_poses": (_i, [_vp, _i, _vp, _i, _vp]),
+    "ecc_metric_evaluate_poses_strided": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "ecc_metric_evaluate_pose_deltas": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "ecc_metric_set_pose_batching": (_i, [_vp, _i]),
+    "ecc_metric_last_batched_poses": (_i, [_vp, C.POINTER(_i64)]),
     "ecc_metric_evaluate_range": (_i, [_vp, _i64, _i64, _vp, _pd]),
     "ecc_metric_evaluate_range_async": (_i, [_vp, _i64, _i64, _vp, _vp]),
     "ecc_metric_evaluate_pairs": (_i, [_vp, _vp, _i, _vp, _pd]),

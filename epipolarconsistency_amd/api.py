@@ -570,18 +570,64 @@ class MetricRadonIntermediate:
         check(L.ecc_metric_evaluate_pairs(self._h, pi, len(idx), po, C.byref(mean)))
         return mean.value
 
-    def evaluate_poses(self, poses):
-        """ecc_metric_evaluate_poses: independent all-pairs evaluations of several poses on this metric, two deep (the
-        hand-over of pose k + 1 overlaps the device's work on pose k); poses: a sequence of (n, 12) column-major arrays
-        (pack_projection_matrices) or lists of 3x4 matrices; returns the means (bit-identical to evaluating them one by
-        one).  The last pose's matrices stay current."""
+    def evaluate_poses(self, poses, first=0, stride=1):
+        """ecc_metric_evaluate_poses[_strided]: independent all-pairs evaluations of several poses on this metric; poses: a
+        sequence of (n, 12) column-major arrays (pack_projection_matrices) or lists of 3x4 matrices; returns the means
+        (bit-identical to evaluating them one by one).  Poses that differ from the current matrices (or from the first pose)
+        in a few views go through ONE batched record / pair / sum launch each (setPoseBatching(False): all of them two deep on
+        the stream, as in rounds 4-5).  first / stride: only the poses first, first + stride, ... (the others' means stay 0).
+        The last evaluated pose's matrices stay current."""
         flat = np.ascontiguousarray(np.stack([p if (isinstance(p, np.ndarray) and p.ndim == 2 and p.shape[1] == 12)
                                               else _Ps_colmajor(p) for p in poses]), np.float64)
         means = np.zeros(len(flat), np.float64)
-        check(_lib.lib().ecc_metric_evaluate_poses(self._h, len(flat), C.c_void_p(flat.ctypes.data), flat.shape[1],
-                                                   C.c_void_p(means.ctypes.data)))
-        self._Ps = flat[-1]
+        check(_lib.lib().ecc_metric_evaluate_poses_strided(self._h, len(flat), C.c_void_p(flat.ctypes.data), flat.shape[1],
+                                                           int(first), int(stride), C.c_void_p(means.ctypes.data)))
+        mine = range(int(first), len(flat), int(stride))
+        if len(mine):
+            self._Ps = flat[mine[-1]]
         return means
+
+    def evaluate_pose_deltas(self, moved_views, moved_Ps):
+        """ecc_metric_evaluate_pose_deltas: pose k = the current matrices with the views moved_views[k] (a sequence of view
+        indices, strictly ascending) replaced by moved_Ps[k] (the same number of 3x4 matrices, or (c, 12) column-major rows).
+        Returns the means, every one bit-identical to setProjectionMatrices + evaluate of that pose; the current matrices stay."""
+        off = [0]
+        views = []
+        rows = []
+        for vk, Pk in zip(moved_views, moved_Ps):
+            vk = [int(v) for v in np.atleast_1d(vk)]
+            Pk = np.asarray(Pk, np.float64)
+            Pk = Pk.reshape(len(vk), 12) if (Pk.shape[-1] == 12 and Pk.ndim <= 2) else _Ps_colmajor(Pk)
+            views += vk
+            rows.append(Pk)
+            off.append(len(views))
+        flat = np.concatenate(rows) if rows and len(views) else np.zeros((0, 12))
+        return self.evaluate_pose_deltas_packed(off, views, flat)
+
+    def evaluate_pose_deltas_packed(self, moved_offsets, moved_views, moved_Ps):
+        """The C signature itself: moved_offsets (K + 1 int32, [0] = 0), moved_views (Q int32, ascending within a pose), moved_Ps
+        ((Q, 12) float64, column-major per matrix).  No per-pose Python work."""
+        off = np.ascontiguousarray(moved_offsets, np.int32)
+        views = np.ascontiguousarray(moved_views, np.int32)
+        flat = np.ascontiguousarray(moved_Ps, np.float64).reshape(-1, 12)
+        if len(off) < 1 or int(off[-1]) != len(views) or len(flat) != len(views):
+            raise ValueError("moved_offsets / moved_views / moved_Ps disagree")
+        means = np.zeros(len(off) - 1, np.float64)
+        check(_lib.lib().ecc_metric_evaluate_pose_deltas(self._h, len(means), C.c_void_p(off.ctypes.data),
+                                                         C.c_void_p(views.ctypes.data) if len(views) else None,
+                                                         C.c_void_p(flat.ctypes.data) if len(views) else None,
+                                                         C.c_void_p(means.ctypes.data)))
+        return means
+
+    def setPoseBatching(self, on=True):
+        """ecc_metric_set_pose_batching: off = evaluate_poses runs every pose as its own stream-ordered evaluation."""
+        check(_lib.lib().ecc_metric_set_pose_batching(self._h, 1 if on else 0))
+        return self
+
+    def last_batched_poses(self):
+        v = C.c_int64(0)
+        check(_lib.lib().ecc_metric_last_batched_poses(self._h, C.byref(v)))
+        return v.value
 
     def evaluateForImagePair(self, i, j):
         """ref: evaluateForImagePair(i, j, redundant_samples0, redundant_samples1, kappas, radon_samples0,

@@ -246,6 +246,29 @@ struct ecc_metric {
     int64_t svals_capacity = 0;
     unsigned* small_ticket_d = nullptr;
     int64_t small_pending_count = 0;  // > 0: the result slot will receive the "done" word of a one-launch evaluation of that many pairs
+    // ecc_metric_evaluate_pose_deltas (ecc_poses.hip): K poses as ONE record launch, ONE pair launch and ONE segmented sum.
+    // Everything below is scratch of that path, grown on demand: the extended geometry (the base views, then one entry per
+    // moved view of every pose), the pose-major x partner-major index grid, its records and values, the slice sums, and one
+    // pinned, device-mapped block (extended matrices, the lists, the results).
+    int pose_batching = 1;  // ecc_metric_set_pose_batching
+    char* pose_h = nullptr;
+    char* pose_h_dev = nullptr;
+    int64_t pose_h_bytes = 0;
+    float* pose_PinvTs_d = nullptr;
+    int64_t pose_PinvTs_capacity = 0;  // floats
+    float* pose_Cs_d = nullptr;
+    int64_t pose_Cs_capacity = 0;      // floats
+    int32_t* pose_idx_d = nullptr;
+    int64_t pose_idx_capacity = 0;     // ints
+    EccPairRecord* pose_records_d = nullptr;
+    int64_t pose_records_capacity = 0;
+    float* pose_values_d = nullptr;
+    int64_t pose_values_capacity = 0;
+    double* pose_partial_d = nullptr;
+    int64_t pose_partial_capacity = 0;
+    int32_t* pose_lists_d = nullptr;
+    int64_t pose_lists_capacity = 0;   // ints
+    int64_t last_batched_poses = 0;    // poses the last ecc_metric_evaluate_poses* call took through the batch (ecc_metric_last_batched_poses)
     // ecc_debug_step_stamps: host clock (seconds, steady) at fixed points of the last set_projections / synchronous evaluation
     double stamps[ECC_STEP_STAMPS] = {0};
 };
@@ -263,6 +286,11 @@ hipError_t wait_result(ecc_metric* m, hipStream_t stream, double* value);
 int set_device(const ecc_ctx* ctx);
 int ensure_poly_tables(ecc_ctx* ctx);
 int ensure_e1(ecc_metric* m);  // E1 on the device for the staged matrices, if the device arrays are behind them
+// ecc_evaluate.hip: the parameters of a launch; the stream-ordered launches over a pair range; the pose-delta path
+int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool need_e1 = true);
+int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d, float* cost_d, float* K01_d, double* sum_d,
+                 bool synchronous = false);
+int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, float** vals_out);
 
 template <class T>
 int ensure_capacity(T** ptr, int64_t* cap, int64_t need, hipStream_t stream)

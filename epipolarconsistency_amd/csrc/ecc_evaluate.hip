@@ -14,10 +14,7 @@ using namespace ecc_internal;
 
 namespace {
 
-// ecc_metric_evaluate_poses: its own "pending" pattern in the two result slots it uses, and a clock
-constexpr uint64_t ECC_POSE_PENDING = 0x7ff8ecc0dead0002ull;
 double pose_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int result_slots(const ecc_metric* m) { return m->sum_h ? 8 : 0; }  // the pinned result block holds 64 bytes
 
 // ECC_SAMPLING_AUTO -> the mode one evaluation of `count` pairs runs in (include/ecc_hip.h)
 int resolve_sampling(const ecc_metric* m, int64_t count)
@@ -30,7 +27,9 @@ int resolve_sampling(const ecc_metric* m, int64_t count)
 // (range) of one, the list length for index lists -- which is what ECC_SAMPLING_AUTO resolves from: a shard of an
 // evaluation runs in the mode of the whole, whatever its own size, so the sum of G shard sums is the one-device sum's
 // arithmetic and a re-balanced shard does not change mode.
-int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool need_e1 = true)
+}  // namespace
+namespace ecc_internal {
+int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool need_e1)
 {
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     if (need_e1) {
@@ -75,6 +74,8 @@ int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool n
     p->economise_tol = m->economise_tol;  // ECC_POLY_ECONOMISE_TOL_BINS unless ecc_debug_set_poly_tolerance changed it
     return ECC_OK;
 }
+}  // namespace ecc_internal
+namespace {
 
 // The pinned list buffer b of the reuse path with room for `words` 32-bit words.
 int ensure_reuse_list(ecc_metric* m, int b, int64_t words)
@@ -354,8 +355,10 @@ int try_small_eval(ecc_metric* m, EccPairParams p, const int32_t* idx4_host, boo
 // kernel through pinned memory, so e1_kernel is not launched at all.  pairs_kernel then samples EVERY pair as always:
 // the evaluation's result is bit-identical to one that refits everything (tests/test_gpu_record_reuse.py).
 // synchronous: the caller waits for the result before it returns (the list buffers need no event then).
+}  // namespace
+namespace ecc_internal {
 int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d, float* cost_d, float* K01_d,
-                 double* sum_d, bool synchronous = false)
+                 double* sum_d, bool synchronous)
 {
     ecc_ctx* ctx = m->ctx;
     const bool was_quiet = m->quiet;  // nothing of this metric's is pending on either stream (ecc_capi_internal.h)
@@ -725,7 +728,7 @@ int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, 
     return ECC_OK;
 }
 
-}  // namespace
+}  // namespace ecc_internal
 
 ECC_EXPORT int ecc_metric_evaluate_range_async(ecc_metric* m, int64_t first, int64_t count, float* pair_values_d,
                                                double* sum_d)
@@ -876,82 +879,6 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
     m->done_generation = m->set_generation;
     m->quiet = true;  // the result is the last thing this call queued, and it has been seen
     *mean = sum / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
-    return ECC_OK;
-}
-
-// n_poses independent all-pairs evaluations on ONE context, two deep: pose k + 1's hand-over (staging of the matrices, the
-// comparison with the kept records, host E1 of the changed views, the launches) is done while the device still runs pose k,
-// whose result is polled only afterwards -- the ~20 us between a result and the next evaluation's first kernel (poll,
-// caller, hand-over, dispatch) disappear from all evaluations but the first.  The device executes exactly the launches of
-// n_poses ecc_metric_set_projections + ecc_metric_evaluate_all calls in the same order, so every mean has the same bits
-// (ref for the pattern: Gui/Visualization.h:78-98 plotCostFunction, BASELINE config 5; a finite-difference gradient).
-ECC_EXPORT int ecc_metric_evaluate_poses(ecc_metric* m, int n_poses, const double* Ps_batch, int n_views, double* means)
-{
-    if (m) m->quiet = false;
-    if (!m || !Ps_batch || !means) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
-    if (n_poses < 1) return ECC_OK;
-    if (n_views < 2) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least two views (the reference divides 0/0 here)");
-    ecc_ctx* ctx = m->ctx;
-    int rc = set_device(ctx);
-    if (rc) return rc;
-    const int64_t n = n_views, n_pairs = n * (n - 1) / 2;
-    // one at a time: the pose-delta mode (it keeps the values of ONE previous evaluation), and evaluations small enough
-    // for the one-launch path (its hand-over goes through result slot 0 and the host's sum; a few microseconds of device
-    // work leave nothing to overlap anyway)
-    if (m->incremental || result_slots(m) < 2 || n_pairs <= ECC_SMALL_EVAL_MAX_PAIRS) {
-        for (int k = 0; k < n_poses; ++k) {
-            rc = ecc_metric_set_projections(m, Ps_batch + (size_t)12 * n * k, n_views);
-            if (rc) return rc;
-            rc = ecc_metric_evaluate_all(m, nullptr, &means[k]);
-            if (rc) return rc;
-        }
-        return ECC_OK;
-    }
-    rc = ensure_capacity(&m->pair_values_d, &m->pair_capacity, n_pairs, ctx->stream);
-    if (rc) return rc;
-    volatile uint64_t* slots = reinterpret_cast<volatile uint64_t*>(m->sum_h);
-    uint64_t gen_of[2] = {0, 0};
-    auto collect = [&](int k) -> int {  // waits for pose k's sum in slot k & 1 (bounded spin, then the stream)
-        const int sl = k & 1;
-        double t0 = 0.0;
-        for (unsigned spins = 0;; ++spins) {
-            const uint64_t bits = slots[sl];
-            if (bits != ECC_POSE_PENDING) {
-                double v;
-                std::memcpy(&v, &bits, sizeof(v));
-                means[k] = v / (double)n_pairs;  // ref: ...RadonIntermediate.cpp:224 (all weights are 1)
-                m->done_generation = gen_of[sl];
-                return ECC_OK;
-            }
-            if ((spins & 0xfff) == 0xfff) {
-                const double t = pose_now();
-                if (t0 == 0.0) t0 = t;
-                else if (t - t0 > 2.0) {
-                    HIP_TRY(hipStreamSynchronize(ctx->stream));
-                    if (slots[sl] == ECC_POSE_PENDING) return fail(ECC_ERR_HIP, "an evaluation ran and stored no result");
-                }
-            }
-        }
-    };
-    for (int k = 0; k < n_poses; ++k) {
-        rc = ecc_metric_set_projections(m, Ps_batch + (size_t)12 * n * k, n_views);  // buffer k & 1: its last device reader was pose k - 2
-        if (rc) return rc;
-        const int sl = k & 1;
-        slots[sl] = ECC_POSE_PENDING;
-        std::atomic_thread_fence(std::memory_order_seq_cst);
-        gen_of[sl] = m->set_generation;
-        // (slot 1 is not the result slot of the synchronous calls: those launches never take the one-launch path)
-        rc = launch_range(m, 0, n_pairs, m->pair_values_d, nullptr, nullptr, m->sum_h_dev + sl, /*synchronous=*/false);
-        if (rc) return rc;
-        m->small_pending_count = 0;
-        if (k >= 1) {
-            rc = collect(k - 1);
-            if (rc) return rc;
-        }
-    }
-    rc = collect(n_poses - 1);
-    if (rc) return rc;
-    m->last_evaluated_pairs = n_pairs;
     return ECC_OK;
 }
 

@@ -454,14 +454,9 @@ ECC_EXPORT int ecc_group_metric_evaluate_poses(ecc_group_metric* gm, int n_poses
     if (n_poses < 1 || n_views < 2) return ecc_set_error(ECC_ERR_INVALID_ARGUMENT, "need one pose of two views at least");
     ecc_group* g = gm->g;
     const int G = g->size();
-    const size_t pose_doubles = 12 * (size_t)n_views;
+    // rank r: the poses r, r + G, ... on its own metric -- batched where they are small deltas of one another (ecc_poses.hip)
     const int rc = run_all(g, [=](int r) -> int {
-        for (int p = r; p < n_poses; p += G) {
-            int e = ecc_metric_set_projections(gm->metrics[r], Ps_batch + pose_doubles * (size_t)p, n_views);
-            if (e == ECC_OK) e = ecc_metric_evaluate_all(gm->metrics[r], nullptr, &means[p]);
-            if (e != ECC_OK) return e;
-        }
-        return ECC_OK;
+        return ecc_metric_evaluate_poses_strided(gm->metrics[r], n_poses, Ps_batch, n_views, r, G, means);
     });
     // the ranks' metrics now hold the poses' matrices: the matrices of the last ecc_group_metric_set_projections stay the
     // group's current ones (as the header says) and are handed over again by the next sharded evaluation

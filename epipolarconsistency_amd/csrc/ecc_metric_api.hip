@@ -203,6 +203,14 @@ ECC_EXPORT int ecc_metric_destroy(ecc_metric* m)
     if (m->sidx_h) (void)hipHostFree(m->sidx_h);
     if (m->svals_h) (void)hipHostFree(m->svals_h);
     if (m->small_ticket_d) (void)hipFree(m->small_ticket_d);
+    if (m->pose_h) (void)hipHostFree(m->pose_h);
+    if (m->pose_PinvTs_d) (void)hipFree(m->pose_PinvTs_d);
+    if (m->pose_Cs_d) (void)hipFree(m->pose_Cs_d);
+    if (m->pose_idx_d) (void)hipFree(m->pose_idx_d);
+    if (m->pose_records_d) (void)hipFree(m->pose_records_d);
+    if (m->pose_values_d) (void)hipFree(m->pose_values_d);
+    if (m->pose_partial_d) (void)hipFree(m->pose_partial_d);
+    if (m->pose_lists_d) (void)hipFree(m->pose_lists_d);
     delete m;
     return ECC_OK;
 }

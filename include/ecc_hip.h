@@ -320,13 +320,38 @@ int ecc_metric_get_object_radius(const ecc_metric* m, double* radius_mm);
  * contiguous slices and the slice sums are added in slice order.  A sum over G shards is the rank-ordered sum of G such
  * sums.  So one-device and sharded sums of the same pair values agree to float64 rounding (~1e-16), not bit for bit. */
 int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean);
-/* n_poses INDEPENDENT all-pairs evaluations (Ps_batch: n_poses x n_views x 12 float64; means: n_poses results) on this one
- * metric, evaluated two deep: while the device runs pose k the host already hands over pose k + 1, and only then polls pose
- * k's result -- the ~20 us between a result and the next evaluation's first kernel are hidden.  Same launches in the same
- * order as n_poses x (ecc_metric_set_projections + ecc_metric_evaluate_all): every mean has the same bits.  The matrices
- * of the last pose stay the metric's current ones.  (ref: Gui/Visualization.h:78-98 plotCostFunction -- BASELINE config 5 --
- * or the probes of a finite-difference gradient; with ecc_metric_set_incremental the poses are evaluated one at a time.) */
+/* n_poses INDEPENDENT all-pairs evaluations of one data set (a sweep of poses, the probes of a finite-difference gradient;
+ * ref: Gui/Visualization.h:59-112 plotCostFunction -- 100 steps x 6 parameters, BASELINE config 5 -- through
+ * Gui/SingleImageMotion.h:84-90).  The reference evaluates them one setProjectionMatrices + evaluate at a time.
+ *
+ * ecc_metric_evaluate_pose_deltas: pose k = the metric's CURRENT matrices (the base: the last ecc_metric_set_projections)
+ * with the views moved_views[moved_offsets[k] .. moved_offsets[k + 1]) (strictly ascending within a pose) replaced by the
+ * matrices moved_Ps[12 * q ..] of the same entries q.  All poses of the call are ONE e1 launch over the moved matrices, ONE
+ * record launch and ONE pair launch over the (pose, moved view) x partner grid -- n_views - 1 pairs per moved view instead of
+ * n (n - 1) / 2 per pose -- and ONE segmented float64 sum that walks, per pose, the base's pair values with the pose's own
+ * substituted in exactly the order the all-pairs sum adds them: every mean has the bits of ecc_metric_set_projections +
+ * ecc_metric_evaluate_all on that pose's matrices (tests/test_gpu_pose_batch.py).  The base's pair values are kept between
+ * calls (only the pairs of views that changed since are redone).  The metric's current matrices are unchanged by the call.
+ * A pose with more than 32 moved views, or one that moves view 0 under the automatic object radius and changes it, is
+ * evaluated the sequential way inside the call (same bits).  400 views of 1024^2, 600 poses of one moved view on one MI355X:
+ * see DESIGN.md 4.9 (two orders of magnitude above the sequential steps: the work is 239 400 pairs, not 47 880 000).
+ *
+ * ecc_metric_evaluate_poses[_strided]: the same for FULL matrices per pose (Ps_batch: n_poses x n_views x 12 float64); the
+ * strided form evaluates the poses first, first + stride, ... only and leaves the other entries of `means` alone (rank r of
+ * N: first = r, stride = N -- poses shard with no exchange at all).  The library finds the moved views itself by comparing
+ * every pose with the metric's current matrices (or with the first pose when most poses are far from those) and takes the
+ * batch above; poses that are no small delta are evaluated two deep on the context's stream (pose k + 1 is handed over
+ * while the device runs pose k).  Same bits either way.  The matrices of the LAST evaluated pose stay the metric's current
+ * ones.  ecc_metric_set_pose_batching(m, 0): everything two deep (the launches of n_poses x (ecc_metric_set_projections +
+ * ecc_metric_evaluate_all) in the same order) -- what rounds 4-5 measured.  ecc_metric_last_batched_poses: how many poses of
+ * the last of these calls went through the batch. */
+int ecc_metric_evaluate_pose_deltas(ecc_metric* m, int n_poses, const int32_t* moved_offsets, const int32_t* moved_views,
+                                    const double* moved_Ps, double* means);
 int ecc_metric_evaluate_poses(ecc_metric* m, int n_poses, const double* Ps_batch, int n_views, double* means);
+int ecc_metric_evaluate_poses_strided(ecc_metric* m, int n_poses, const double* Ps_batch, int n_views, int first, int stride,
+                                      double* means);
+int ecc_metric_set_pose_batching(ecc_metric* m, int on);
+int ecc_metric_last_batched_poses(const ecc_metric* m, int64_t* poses);
 
 /* Multi-GPU building block: evaluate only pairs ij in [first, first+count) of the get_ij order
  * (ref: EpipolarConsistencyCommon.hxx:52-79); returns the partial sum (float64) -- the caller
