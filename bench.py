@@ -503,14 +503,25 @@ def self_launch(args):
     sys.exit(rc if rc >= 0 else 1)  # (negative: torchrun itself was killed by a signal)
 
 
+def check_rank_devices(ids, world, single_device):
+    """One device per rank: `ids` holds every rank's device identity.  Raises SystemExit('ranks share devices ...')."""
+    if not single_device and len(set(ids)) != world:
+        raise SystemExit("ranks share devices: %r" % (ids,))
+
+
 def launch_check(args, rank, world):
-    """--launch-check: the process group of the launch, nothing else (runs without a GPU)."""
+    """--launch-check: the process group of the launch and the checks that run before anything is measured -- distinct
+    LOCAL_RANKs from the launcher, one device per rank, the ranks' agreement on whether the library's RCCL exchange is
+    usable -- without touching a GPU (gloo).  Test hooks: ECC_BENCH_FAIL_RANK (that rank dies before it joins),
+    ECC_BENCH_FAKE_SHARED_DEVICE (every rank reports local rank 0's device), ECC_BENCH_FAKE_NO_RCCL_RANK (that rank
+    pretends it cannot bind RCCL)."""
     import torch
     import torch.distributed as dist
     fail = os.environ.get("ECC_BENCH_FAIL_RANK")
     if fail is not None and int(fail) == rank:
         os._exit(7)  # a rank that dies before it joins the group
-    seen = 1
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    seen, local_ranks, rccl = 1, [local_rank], None
     if world > 1:
         dist.init_process_group("gloo")
         probe = torch.tensor([float(rank + 1)], dtype=torch.float64)
@@ -518,9 +529,28 @@ def launch_check(args, rank, world):
         if probe.item() != world * (world + 1) / 2.0:
             raise SystemExit("all-reduce over %d ranks returned %r" % (world, probe.item()))
         seen = dist.get_world_size()
+        local_ranks = [None] * world
+        dist.all_gather_object(local_ranks, local_rank)
+        if sorted(local_ranks) != list(range(world)):  # one node: the launcher must hand out 0 .. N-1
+            raise SystemExit("the launcher did not hand out distinct LOCAL_RANKs: %r" % (local_ranks,))
+        ids = [None] * world
+        dist.all_gather_object(ids, "cuda:%d" % (0 if os.environ.get("ECC_BENCH_FAKE_SHARED_DEVICE") else local_rank))
+        check_rank_devices(ids, world, args.single_device)
+        # the agreement in front of ecc_comm_create (sharding.RcclComm): all ranks learn the same answer and nobody enters
+        # ncclCommInitRank unless everybody can
+        from epipolarconsistency_amd import _lib, sharding
+        fake = os.environ.get("ECC_BENCH_FAKE_NO_RCCL_RANK")
+        local_ok = _lib.lib().ecc_comm_available() == 0 and not (fake is not None and int(fake) == rank)
+        agreed = sharding.torch_agree_min()(1 if local_ok else 0)
+        answers = [None] * world
+        dist.all_gather_object(answers, {"rank": rank, "local": bool(local_ok), "agreed": bool(agreed)})
+        rccl = answers
+        if len({a["agreed"] for a in answers}) != 1:
+            raise SystemExit("the ranks disagree on the RCCL exchange: %r" % (answers,))
     if rank == 0:
         emit({"metric": "launch check (nothing measured)", "value": None, "n_gpus": world,
-              "config": {"ranks_seen_by_collective_backend": seen, "launch_check": True}})
+              "config": {"ranks_seen_by_collective_backend": seen, "launch_check": True, "local_ranks": local_ranks,
+                         "rccl_agreement": rccl}})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -587,8 +617,7 @@ def main():
             uuid = "cuda:%d" % local_rank
         dist.all_gather_object(ids, "%s (local rank %d)" % (uuid, local_rank))
         devices_seen = ids
-        if not args.single_device and len(set(ids)) != world:
-            raise SystemExit("ranks share devices: %r" % (ids,))
+        check_rank_devices(ids, world, args.single_device)
 
     n, S, B = args.views, args.size, args.bins
     pixel_mm = 0.308 * 1024.0 / S
@@ -734,16 +763,23 @@ def main():
 
     # the library's own RCCL communicator (ecc_comm_*): the all-reduce queued by the library between its sum kernel and the
     # kernel that publishes the scalar -- no torch.distributed call on the step's path
-    comm = None
+    comm, comm_status = None, "not attempted"
     if grouped and args.backend == "nccl" and args.exchange in ("both", "rccl"):
+        # (the ranks first AGREE that all of them can bind RCCL -- a rank that cannot must not leave the others inside
+        # ncclCommInitRank --, and this rank gives the collective two minutes: it has never run on more than one GPU)
         try:
-            comm = sharding.RcclComm(ctx, rank, world, sharding.torch_broadcast_bytes(dev))
+            comm = sharding.RcclComm(ctx, rank, world, sharding.torch_broadcast_bytes(dev), agree=sharding.torch_agree_min(dev),
+                                     timeout_s=120.0)
+            comm_status = "ncclCommInitRank ok"
         except Exception as e:
             sys.stderr.write("rank %d: the library's RCCL communicator is unavailable (%s)\n" % (rank, e))
+            comm_status = "%s: %s" % (type(e).__name__, e)
             comm = None
         flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if flag.item() == 0:
+            if comm is not None:
+                comm_status += " (dropped: another rank has none)"
             comm = None
         elif abs(metric.evaluate_range_allreduce(comm, 0, 0) - 0.0) > 0:
             raise SystemExit("the library's all-reduce of empty shards returned a non-zero sum")
@@ -822,7 +858,16 @@ def main():
     # north_star names; the shared-memory exchange is reported next to it under timing.other_exchange
     # the headline is the RCCL all-reduce: issued by the library where its communicator exists (one call per step, everything
     # stream-ordered), else through torch.distributed
-    best = "rccl" if "rccl" in modes else ("collective" if "collective" in modes else modes[0])
+    # (Round 6, advisor: the library-issued form has only ever run with ONE rank -- torch.distributed's all-reduce is the headline
+    # until a run on two or more GPUs has shown the library's agrees with it; with one rank, the rehearsal, the library's form is.)
+    if world > 1:
+        best = "collective" if "collective" in modes else ("rccl" if "rccl" in modes else modes[0])
+    else:
+        best = "rccl" if "rccl" in modes else ("collective" if "collective" in modes else modes[0])
+    same_step = {m: results[m]["step"](3) for m in modes}  # the same pose through every exchange (every rank, the same order)
+    for m in modes:
+        if abs(same_step[m] - same_step[modes[0]]) > 1e-12 * abs(same_step[modes[0]]):
+            raise SystemExit("the exchanges disagree on the same step: %r" % (same_step,))
     res = results[best]
     elapsed, last, step = res["steady"], res["last"], res["step"]
     # pair-kernel duration: HIP events on the context's stream around the pair kernel alone, averaged over a
@@ -1058,8 +1103,14 @@ def main():
     others = [{"sum_exchange": exch_name[m], "ms_per_step": 1e3 * results[m]["steady"] / args.steps,
                "value": args.steps / results[m]["steady"], "cold_ms_per_step": 1e3 * results[m]["cold"] / args.steps}
               for m in modes if m != best]
-    if others:
-        out["timing"]["other_exchange"] = others[0] if len(others) == 1 else others
+    out["timing"]["other_exchange"] = others  # always a list (advisor, round 5: one schema whatever the number of modes)
+    if grouped:
+        # what every rank actually used: the exchanges it timed, the one behind `value`, and how its ncclCommInitRank went
+        mine_status = {"rank": rank, "exchanges_timed": [exch_name[m] for m in modes], "value_is": exch_name[best],
+                       "ecc_comm_create": comm_status}
+        statuses = [None] * world
+        dist.all_gather_object(statuses, mine_status)
+        out["config"]["exchange_per_rank"] = statuses
 
     # ---- CPU baseline: the oracle timed on this box's host cores (rank 0, N = 1 only) -----------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -1116,6 +1167,8 @@ def main():
     if rank == 0:
         emit(out)
     if grouped:
+        if comm is not None:
+            comm.close()  # ncclCommDestroy here, on every rank, not from __del__ at interpreter exit
         dist.barrier()
         if exchange is not None:
             exchange.close()

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ecc_metric_publish_scalar": (_i, [_vp, _vp]),
     "ecc_metric_wait_scalar": (_i, [_vp, _pd]),
     "ecc_metric_last_evaluated_pairs": (_i, [_vp, C.POINTER(_i64)]),
+    "ecc_metric_device_bytes": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "ecc_metric_get_object_radius": (_i, [_vp, _pd]),
     "ecc_metric_evaluate_all": (_i, [_vp, _vp, _pd]),
     "ecc_metric_evaluate_poses": (_i, [_vp, _i, _vp, _i, _vp]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "ecc_pair_shard": (None, [_i64, _i, _i, C.POINTER(_i64), C.POINTER(_i64)]),
     "ecc_pair_shards_balanced": (_i, [_vp, _i, _d, _i, _vp]),
     "ecc_metric_balanced_shards": (_i, [_vp, _i, _vp]),
+    "ecc_comm_available": (_i, []),
     "ecc_comm_unique_id": (_i, [_vp]),
     "ecc_comm_create": (_i, [_vp, _vp, _i, _i, _vp]),
     "ecc_comm_destroy": (_i, [_vp]),

@@ -518,6 +518,13 @@ class MetricRadonIntermediate:
             check(_lib.lib().ecc_metric_set_small_eval(self._h, self._small_eval))
         return self
 
+    def device_bytes(self):
+        """ecc_metric_device_bytes -> {"paired_copies", "quad_copies", "other"}: device memory this metric owns right now (the
+        Radon intermediates themselves belong to their RadonIntermediate objects)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(_lib.lib().ecc_metric_device_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"paired_copies": a.value, "quad_copies": b.value, "other": c.value}
+
     def last_evaluated_pairs(self):
         """Pairs the last evaluate() / evaluate_range() actually recomputed."""
         v = C.c_int64()
@@ -577,8 +584,12 @@ class MetricRadonIntermediate:
         in a few views go through ONE batched record / pair / sum launch each (setPoseBatching(False): all of them two deep on
         the stream, as in rounds 4-5).  first / stride: only the poses first, first + stride, ... (the others' means stay 0).
         The last evaluated pose's matrices stay current."""
-        flat = np.ascontiguousarray(np.stack([p if (isinstance(p, np.ndarray) and p.ndim == 2 and p.shape[1] == 12)
-                                              else _Ps_colmajor(p) for p in poses]), np.float64)
+        if isinstance(poses, np.ndarray) and poses.ndim == 3 and poses.shape[2] == 12 and poses.dtype == np.float64 \
+                and poses.flags["C_CONTIGUOUS"]:
+            flat = poses  # (K, n, 12) already packed: no copy (600 poses of 400 views are 23 MB)
+        else:
+            flat = np.ascontiguousarray(np.stack([p if (isinstance(p, np.ndarray) and p.ndim == 2 and p.shape[1] == 12)
+                                                  else _Ps_colmajor(p) for p in poses]), np.float64)
         means = np.zeros(len(flat), np.float64)
         check(_lib.lib().ecc_metric_evaluate_poses_strided(self._h, len(flat), C.c_void_p(flat.ctypes.data), flat.shape[1],
                                                            int(first), int(stride), C.c_void_p(means.ctypes.data)))

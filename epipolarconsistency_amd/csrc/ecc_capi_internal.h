@@ -232,6 +232,11 @@ struct ecc_metric {
     // row-paired copies, the pinned lists -- is written by this metric's own launches only, so nothing it must wait for is pending.
     // (hipEventRecord + hipStreamWaitEvent in front of the first launch cost the shard step of an 8-rank job 3.5-4.7 us of 72.)
     bool quiet = false;
+    // What `quiet` may be set from: every call that queues work for the metric bumps queue_seq (ecc_mark_busy);
+    // ecc_metric_publish_scalar remembers the value right after its own kernel.  ecc_metric_wait_scalar has only seen THAT kernel
+    // complete -- in a pipelined order (async k, publish k, async k + 1, wait k) later work is still pending, and the wait
+    // must not declare the metric quiet (advisor, round 5).
+    uint64_t queue_seq = 0, publish_seq = 0, publish_generation = 0;
     // ecc_metric_set_small_eval: evaluations of at most ECC_SMALL_EVAL_MAX_PAIRS pairs as ONE launch (small_eval_kernel.hip).
     // E1 of the views whose matrix changed since the device arrays were made is done on the host and handed over in the
     // kernel arguments (dev_Ps above says which views those are).
@@ -272,6 +277,12 @@ struct ecc_metric {
     // ecc_debug_step_stamps: host clock (seconds, steady) at fixed points of the last set_projections / synchronous evaluation
     double stamps[ECC_STEP_STAMPS] = {0};
 };
+
+inline void ecc_mark_busy(ecc_metric* m)
+{
+    m->quiet = false;
+    ++m->queue_seq;
+}
 
 inline void ecc_stamp(ecc_metric* m, int k)
 {

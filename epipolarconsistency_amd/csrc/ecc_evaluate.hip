@@ -362,7 +362,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
 {
     ecc_ctx* ctx = m->ctx;
     const bool was_quiet = m->quiet;  // nothing of this metric's is pending on either stream (ecc_capi_internal.h)
-    m->quiet = false;
+    ecc_mark_busy(m);
     const int64_t n = m->n_views;
     const int64_t n_pairs = n * (n - 1) / 2;
     if ((int)m->dtrs.size() < m->n_views)
@@ -634,7 +634,7 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
 // is the one the full range resolves to, and the sum's order is fixed.
 int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, float** vals_out)
 {
-    m->quiet = false;  // (queues work; the synchronous callers set it again once they have seen the result)
+    ecc_mark_busy(m);  // (queues work; the synchronous callers set it again once they have seen the result)
     ecc_ctx* ctx = m->ctx;
     const int64_t n = m->n_views;
     if (n < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
@@ -783,11 +783,13 @@ ECC_EXPORT int ecc_metric_evaluate_range_allreduce(ecc_metric* m, ecc_comm* comm
 ECC_EXPORT int ecc_metric_publish_scalar(ecc_metric* m, const double* value_d)
 {
     if (!m || !value_d) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
-    m->quiet = false;
+    ecc_mark_busy(m);
     int rc = set_device(m->ctx);
     if (rc) return rc;
     arm_result(m);
     HIP_TRY(ecc_launch_publish_scalar(value_d, m->sum_h_dev, m->ctx->stream));
+    m->publish_seq = m->queue_seq;  // nothing has been queued behind the publishing kernel yet
+    m->publish_generation = m->set_generation;  // every launch so far read the staging buffers of generations up to this one
     return ECC_OK;
 }
 
@@ -797,8 +799,12 @@ ECC_EXPORT int ecc_metric_wait_scalar(ecc_metric* m, double* value)
     int rc = set_device(m->ctx);
     if (rc) return rc;
     HIP_TRY(wait_result(m, m->ctx->stream, value));
-    m->done_generation = m->set_generation;  // the publishing kernel is ordered behind everything the metric launched
-    m->quiet = true;  // (and it has run)
+    // The publishing kernel is ordered behind everything the metric had queued when ecc_metric_publish_scalar was called,
+    // and it has run.  Work queued SINCE (the next asynchronous range of a pipelined caller) may still be pending: only
+    // when there is none is the metric quiet; the staging buffers known to be free are those of the set_projections calls
+    // made before the publish.
+    m->done_generation = std::max(m->done_generation, m->publish_generation);
+    if (m->queue_seq == m->publish_seq) m->quiet = true;
     return ECC_OK;
 }
 
@@ -884,7 +890,7 @@ ECC_EXPORT int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* m
 
 ECC_EXPORT int ecc_metric_evaluate_pairs(ecc_metric* m, const int32_t* idx4, int n_pairs, float* out, double* mean)
 {
-    if (m) m->quiet = false;
+    if (m) ecc_mark_busy(m);
     if (!m || !idx4 || !mean) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (n_pairs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "empty index list (the reference divides 0/0 here)");
     ecc_ctx* ctx = m->ctx;
@@ -987,7 +993,7 @@ ECC_EXPORT int ecc_metric_evaluate_external(ecc_metric* m, int num_Ps, const flo
                                             const int32_t* indices_d, float* K01s_d, float* out_d, float object_radius_mm,
                                             float dkappa, int use_corr)
 {
-    if (m) m->quiet = false;
+    if (m) ecc_mark_busy(m);
     if (!m || !Cs_d || !PinvTs_d || !out_d) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (num_Ps < 2 || num_pairs < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "need at least two views and one pair");
     if ((int)m->dtrs.size() < num_Ps && !indices_d)

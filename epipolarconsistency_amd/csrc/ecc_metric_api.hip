@@ -73,11 +73,22 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
         want_quads = (uint64_t)m->quad_floats * 4u * (uint64_t)n_dtrs <= (uint64_t)free_b / 4u;
     }
     if (e == hipSuccess && want_quads) {
-        e = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
-        if (e == hipSuccess) e = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);
-        for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) qtable[k] = m->quads_d + (size_t)m->quad_floats * k;
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(m->quads_table_d, qtable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t eq = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
+        if (eq == hipSuccess) eq = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);
+        for (int k = 0; k < n_dtrs && eq == hipSuccess; ++k) qtable[k] = m->quads_d + (size_t)m->quad_floats * k;
+        if (eq == hipSuccess)
+            eq = hipMemcpyAsync(m->quads_table_d, qtable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
+        if (eq != hipSuccess && ctx->quad_copies == ECC_QUAD_COPIES_AUTO && (eq == hipErrorOutOfMemory || eq == hipErrorMemoryAllocation)) {
+            // The copies are optional (the same bits without them): in the automatic mode an allocation that fails after all --
+            // fragmentation, another process on the device between hipMemGetInfo and here -- means "no row-quad copies", not
+            // "no metric" (advisor, round 5).  ECC_QUAD_COPIES_ON keeps the error: the caller asked for them.
+            (void)hipGetLastError();
+            if (m->quads_d) (void)hipFree(m->quads_d);
+            if (m->quads_table_d) (void)hipFree((void*)m->quads_table_d);
+            m->quads_d = nullptr;
+            m->quads_table_d = nullptr;
+        } else
+            e = eq;
     }
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&m->sum_scratch_d, ecc_sum_scratch_bytes());
@@ -104,7 +115,7 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
 
 ECC_EXPORT int ecc_metric_refresh_dtrs(ecc_metric* m, int first, int count)
 {
-    if (m) m->quiet = false;
+    if (m) ecc_mark_busy(m);
     if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
     const int n = (int)m->dtrs.size();
     if (first < 0 || count < 0 || first > n || count > n - first) return fail(ECC_ERR_INVALID_ARGUMENT, "dtr range outside the metric's list");
@@ -135,7 +146,7 @@ int ensure_e1(ecc_metric* m)
         m->e1_pending = false;  // the device arrays already belong to these matrices (patched view by view, or set back)
         return ECC_OK;
     }
-    m->quiet = false;
+    ecc_mark_busy(m);
     HIP_TRY(ecc_launch_e1(m->Ps_h_dev[slot], m->n_views, m->PinvTs_d, m->Cs_d, m->ctx->stream));
     m->dev_Ps.assign(m->Ps_h[slot], m->Ps_h[slot] + n12);
     m->dev_valid = true;
@@ -311,6 +322,28 @@ ECC_EXPORT int ecc_metric_set_incremental(ecc_metric* m, int enable)
     return ECC_OK;
 }
 
+// Device memory the metric owns right now (include/ecc_hip.h): the two sampling copies of the Radon-intermediate stack and
+// everything else (geometry, records, pair values, cost image, lists, the pose batch's scratch).
+ECC_EXPORT int ecc_metric_device_bytes(const ecc_metric* m, int64_t* paired_bytes, int64_t* quad_bytes, int64_t* other_bytes)
+{
+    if (!m) return fail(ECC_ERR_INVALID_ARGUMENT, "metric is null");
+    const int64_t n = (int64_t)m->dtrs.size();
+    const int64_t paired = m->paired_d ? (int64_t)(m->n_alpha + 1) * m->pitch * 2 * 4 * n : 0;
+    const int64_t quads = m->quads_d ? m->quad_floats * 4 * n : 0;
+    int64_t other = 0;
+    other += (int64_t)sizeof(float*) * n * (2 + (m->quads_table_d ? 1 : 0));
+    other += (int64_t)m->geom_capacity * (16 * (int64_t)sizeof(float) + 12 * (int64_t)sizeof(double));
+    other += m->pair_capacity * 4 + (int64_t)m->cost_capacity * 4 + m->indices_capacity * 4 + m->K01_capacity * 4;
+    other += m->records_capacity * (int64_t)sizeof(EccPairRecord) + m->cache_capacity * 4;
+    other += m->pose_PinvTs_capacity * 4 + m->pose_Cs_capacity * 4 + m->pose_idx_capacity * 4 + m->pose_values_capacity * 4;
+    other += m->pose_records_capacity * (int64_t)sizeof(EccPairRecord) + m->pose_partial_capacity * 8 + m->pose_lists_capacity * 4;
+    other += (int64_t)ecc_sum_scratch_bytes() + 8;
+    if (paired_bytes) *paired_bytes = paired;
+    if (quad_bytes) *quad_bytes = quads;
+    if (other_bytes) *other_bytes = other;
+    return ECC_OK;
+}
+
 ECC_EXPORT int ecc_metric_last_evaluated_pairs(const ecc_metric* m, int64_t* pairs)
 {
     if (!m || !pairs) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
@@ -351,7 +384,7 @@ ECC_EXPORT int ecc_metric_evaluate_for_image_pair(ecc_metric* m, int i, int j, i
                                                   float* rs0, float* rs1, float* kappas, float* radon0, float* radon1,
                                                   float* K01, double* ecc)
 {
-    if (m) m->quiet = false;
+    if (m) ecc_mark_busy(m);
     if (!m || !n_samples) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (m->n_views < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "projection matrices have not been set");
     const int nD = (int)m->dtrs.size();

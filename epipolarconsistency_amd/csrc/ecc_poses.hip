@@ -21,6 +21,8 @@
 // ecc_metric_set_projections + ecc_metric_evaluate_all for that pose (tests/test_gpu_pose_batch.py).
 #include "ecc_capi_internal.h"
 
+#include <thread>
+
 using namespace ecc_internal;
 
 #ifndef ECC_POSE_BATCH_MAX_MOVED
@@ -361,7 +363,7 @@ int evaluate_deltas(ecc_metric* m, int n_poses, const int32_t* off, const int32_
 {
     ecc_ctx* ctx = m->ctx;
     const int64_t n = m->n_views, n_pairs = n * (n - 1) / 2;
-    m->quiet = false;
+    ecc_mark_busy(m);
     std::vector<double> base(m->Ps_h[m->set_generation & 1], m->Ps_h[m->set_generation & 1] + 12 * n);
     double base_radius = 0.0;
     ecc_metric_get_object_radius(m, &base_radius);
@@ -484,7 +486,7 @@ ECC_EXPORT int ecc_metric_evaluate_pose_deltas(ecc_metric* m, int n_poses, const
 ECC_EXPORT int ecc_metric_evaluate_poses_strided(ecc_metric* m, int n_poses, const double* Ps_batch, int n_views, int first, int stride,
                                                  double* means)
 {
-    if (m) m->quiet = false;
+    if (m) ecc_mark_busy(m);
     if (!m || !Ps_batch || !means) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
     if (first < 0 || stride < 1) return fail(ECC_ERR_INVALID_ARGUMENT, "first must be >= 0 and stride >= 1");
     if (n_poses < 1 || first >= n_poses) return ECC_OK;
@@ -501,24 +503,60 @@ ECC_EXPORT int ecc_metric_evaluate_poses_strided(ecc_metric* m, int n_poses, con
 
     // The poses as deltas of a base: the metric's current matrices if at least half of the poses differ from them in a few
     // views, else the first pose (a sweep around an estimate the metric has not seen yet).
+    // (600 poses of 400 views are 23 MB to compare: one thread reads them in ~2 ms, which is what the whole batch takes on the
+    // device -- so the comparison runs on up to eight threads, a contiguous run of poses each)
     std::vector<int32_t> off, views;
     std::vector<int> batch_pose, rest;
     auto diff_against = [&](const double* base) {
+        const size_t count = mine.size();
+        const size_t bytes = count * pose_doubles * sizeof(double);
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t T = bytes < ((size_t)4 << 20) ? 1 : std::min<size_t>({(size_t)8, (size_t)hw, count / 32 + 1});
+        std::vector<std::vector<int32_t>> part_views(T);
+        std::vector<std::vector<int32_t>> part_count(T);  // per pose of the part: moved views, or -1 = not a small delta
+        auto work = [&](size_t t) {
+            const size_t lo = count * t / T, hi = count * (t + 1) / T;
+            std::vector<int32_t>&pv = part_views[t], &pc = part_count[t];
+            pc.reserve(hi - lo);
+            for (size_t q = lo; q < hi; ++q) {
+                const double* Pp = Ps_batch + pose_doubles * (size_t)mine[q];
+                const size_t before = pv.size();
+                // blocks of eight views first: a sweep's poses differ from the base in one view or two
+                for (int v0 = 0; v0 < n_views && pv.size() - before <= (size_t)ECC_POSE_BATCH_MAX_MOVED; v0 += 8) {
+                    const int v1 = std::min(n_views, v0 + 8);
+                    if (std::memcmp(Pp + 12 * (size_t)v0, base + 12 * (size_t)v0, sizeof(double) * 12 * (size_t)(v1 - v0)) == 0) continue;
+                    for (int v = v0; v < v1; ++v)
+                        if (std::memcmp(Pp + 12 * (size_t)v, base + 12 * (size_t)v, sizeof(double) * 12) != 0) pv.push_back(v);
+                }
+                if (pv.size() - before > (size_t)ECC_POSE_BATCH_MAX_MOVED) {
+                    pv.resize(before);
+                    pc.push_back(-1);
+                } else pc.push_back((int32_t)(pv.size() - before));
+            }
+        };
+        if (T == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+            work(0);
+            for (std::thread& x : th) x.join();
+        }
         off.assign(1, 0);
         views.clear();
         batch_pose.clear();
         rest.clear();
-        for (int p : mine) {
-            const double* Pp = Ps_batch + pose_doubles * (size_t)p;
-            const size_t before = views.size();
-            for (int v = 0; v < n_views && views.size() - before <= (size_t)ECC_POSE_BATCH_MAX_MOVED; ++v)
-                if (std::memcmp(Pp + 12 * (size_t)v, base + 12 * (size_t)v, sizeof(double) * 12) != 0) views.push_back(v);
-            if (views.size() - before > (size_t)ECC_POSE_BATCH_MAX_MOVED) {
-                views.resize(before);
-                rest.push_back(p);
-            } else {
-                batch_pose.push_back(p);
-                off.push_back((int32_t)views.size());
+        for (size_t t = 0; t < T; ++t) {
+            const size_t lo = count * t / T;
+            size_t at = 0;
+            for (size_t q = 0; q < part_count[t].size(); ++q) {
+                const int32_t c = part_count[t][q];
+                if (c < 0) rest.push_back(mine[lo + q]);
+                else {
+                    views.insert(views.end(), part_views[t].begin() + at, part_views[t].begin() + at + c);
+                    at += (size_t)c;
+                    batch_pose.push_back(mine[lo + q]);
+                    off.push_back((int32_t)views.size());
+                }
             }
         }
     };

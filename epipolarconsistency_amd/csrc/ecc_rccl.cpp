@@ -79,6 +79,15 @@ struct ecc_comm {
     int rank = 0, world = 1;
 };
 
+// Can this process bind RCCL at all?  No collective, no GPU call: ranks agree on the answer BEFORE any of them enters
+// ncclCommInitRank, so that a rank without the library does not leave the others waiting inside it.
+ECC_EXPORT int ecc_comm_available(void)
+{
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(ECC_ERR_UNSUPPORTED, r.error.c_str());
+    return ECC_OK;
+}
+
 ECC_EXPORT int ecc_comm_unique_id(void* id128)
 {
     if (!id128) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");

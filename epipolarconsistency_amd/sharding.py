@@ -135,21 +135,52 @@ class RcclComm:
     hands it to the others (a callable bytes -> bytes that every rank calls, e.g. over torch.distributed), then every rank joins
     (ncclCommInitRank on the context's device: a collective)."""
 
-    def __init__(self, ctx, rank, world, broadcast):
+    def __init__(self, ctx, rank, world, broadcast, agree=None, timeout_s=None):
+        """agree: callable int -> int that every rank calls, returning the MINIMUM over the ranks (torch_agree_min); with it the
+        ranks settle whether all of them can bind RCCL BEFORE anybody enters ncclCommInitRank -- a rank that cannot would
+        return at once and leave the others inside the collective for ever (advisor, round 5).
+        timeout_s: ncclCommInitRank runs on a helper thread and this rank gives up after that many seconds (TimeoutError; the
+        thread stays behind, `hung` is set: the caller should report and end the process with os._exit when it is done)."""
         from . import _lib
         from .api import check
         self._h = C.c_void_p()
         self.ctx, self.rank, self.world = ctx, rank, world
+        self.hung = False
+        L = _lib.lib()
+        local_ok = L.ecc_comm_available() == 0
+        why_local = "" if local_ok else L.ecc_last_error().decode(errors="replace")
+        if agree is not None and int(agree(1 if local_ok else 0)) == 0:
+            raise RuntimeError("RCCL cannot be bound on every rank" + (" (this rank: %s)" % why_local if why_local else " (this rank could)"))
         buf = (C.c_char * 128)()
         why = ""
-        if rank == 0 and _lib.lib().ecc_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
-            why = _lib.lib().ecc_last_error().decode(errors="replace")
+        if rank == 0 and L.ecc_comm_unique_id(C.cast(buf, C.c_void_p)) != 0:
+            why = L.ecc_last_error().decode(errors="replace")
             buf = (C.c_char * 128)()  # all zero: every rank learns that there is no id and raises, nobody waits for a collective
         ident = broadcast(bytes(buf))
         assert len(ident) == 128
         if not any(ident):
             raise RuntimeError("no RCCL communicator id from rank 0" + (": " + why if why else ""))
-        check(_lib.lib().ecc_comm_create(ctx._h, C.c_char_p(ident), int(rank), int(world), C.byref(self._h)))
+        if not local_ok:  # (without `agree`: this rank at least does not pretend)
+            raise RuntimeError("RCCL cannot be bound on this rank: " + why_local)
+        if timeout_s is None:
+            check(L.ecc_comm_create(ctx._h, C.c_char_p(ident), int(rank), int(world), C.byref(self._h)))
+            return
+        import threading
+        box = {}
+
+        def run():
+            rc = L.ecc_comm_create(ctx._h, C.c_char_p(ident), int(rank), int(world), C.byref(self._h))
+            box["rc"] = rc
+            box["err"] = L.ecc_last_error().decode(errors="replace") if rc else ""  # (the error text is thread-local)
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        t.join(float(timeout_s))
+        if t.is_alive():
+            self.hung = True
+            raise TimeoutError("ncclCommInitRank did not return within %.0f s on rank %d of %d" % (timeout_s, rank, world))
+        if box["rc"] != 0:
+            from ._lib import EccError
+            raise EccError(box["rc"], box["err"])
 
     def close(self):
         from . import _lib
@@ -177,6 +208,19 @@ def torch_broadcast_bytes(device=None, group=None):
     return bc
 
 
+def torch_agree_min(device=None, group=None):
+    """-> agree(int) = the minimum over the ranks of the torch.distributed process group (for RcclComm); the identity without one"""
+    def agree(v):
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int32, device=device if (device is not None and dist.get_backend(group) == "nccl") else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item())
+    return agree
+
+
 def rccl_evaluate(metric, n_views, comm, shard=None):
     """One all-pairs evaluation sharded over the ranks of `comm` with the exchange inside the library call (pair kernel -> sum ->
     ncclAllReduce -> publish, one stream); returns the mean.  shard: (first, count) of this rank (default: the equal-count chunk)."""
@@ -200,7 +244,15 @@ def gather_cost_image(pair_values, n_views, rank, world, group=None, cost=None):
     counts = [pair_range(r, world, n_pairs)[1] for r in range(world)]
     mine = torch.zeros(max(counts), dtype=torch.float32)
     mine[:counts[rank]] = torch.from_numpy(np.ascontiguousarray(pair_values, np.float32))
-    if dist.is_initialized():  # (a one-rank group too: the RCCL all-gather then runs on the one GPU there is)
+    # The collective only when the process group IS the sharding (its size equals `world`: a one-rank group too -- the RCCL
+    # all-gather then runs on the one GPU there is).  world = 1 inside a larger group -- every rank evaluated all pairs --
+    # stays local; any other mismatch is a caller error (an all_gather with the wrong list length errors or hangs).
+    in_group = dist.is_available() and dist.is_initialized()
+    if in_group and dist.get_world_size(group) != world:
+        if world != 1:
+            raise ValueError("gather_cost_image: world = %d but the process group has %d ranks" % (world, dist.get_world_size(group)))
+        in_group = False
+    if in_group:
         on_gpu = dist.get_backend(group) == "nccl"
         if on_gpu:
             mine = mine.cuda()

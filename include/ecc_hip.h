@@ -559,9 +559,14 @@ int ecc_group_metric_rank_metric(ecc_group_metric* gm, int rank, ecc_metric** m)
  * published to pinned host memory -> poll; all on the context's stream, no host round trip in between.  *sum_all is the sum over
  * ALL ranks' pairs (the same bits on every rank); the mean is sum_all / (n (n - 1) / 2).  All ranks call it the same number of
  * times.  RCCL is loaded at run time (dlopen of librccl.so.1: the copy the process already has -- PyTorch's -- or ROCm's);
- * without it these calls fail with ECC_ERR_UNSUPPORTED and nothing else of the library is affected. */
+ * without it these calls fail with ECC_ERR_UNSUPPORTED and nothing else of the library is affected.
+ * ecc_comm_available: ECC_OK when RCCL can be bound in this process -- no GPU call, no collective.  A job must AGREE on it
+ * across its ranks (a MIN all-reduce of the answers) before any rank calls ecc_comm_create: a rank that cannot load RCCL
+ * returns from ecc_comm_create at once, and the others would wait for it inside ncclCommInitRank for ever
+ * (sharding.RcclComm does this when it is given an `agree` callable; bench.py passes one). */
 typedef struct ecc_comm ecc_comm;
 #define ECC_COMM_ID_BYTES 128
+int ecc_comm_available(void);
 int ecc_comm_unique_id(void* id128);
 int ecc_comm_create(ecc_ctx* ctx, const void* id128, int rank, int world, ecc_comm** out);
 int ecc_comm_destroy(ecc_comm* c);
@@ -602,11 +607,23 @@ int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on);
  * 3.5 % of a short scan's pairs, a fifth of its evaluation time) cross the Radon intermediates diagonally, a new angle row
  * every sample or two; the exact part of their sampling reads the row-quad copies: +2 % evaluations/s on the 400-view
  * benchmark, bit-identical values (tests/test_gpu_sampling_modes.py).  ECC_QUAD_COPIES_AUTO (default): built while all of
- * them together take at most a quarter of the device memory free at the time; _OFF: never; _ON: always (offsets permitting). */
+ * them together take at most a quarter of the device memory free at the time (and dropped silently if their allocation then
+ * fails after all); _OFF: never; _ON: always (offsets permitting; an allocation failure is the metric's failure).
+ * MEMORY a metric owns per Radon intermediate of n_alpha x n_t bins, pitch = roundup(n_t + 2, 32) floats (ecc_metric_device_bytes
+ * reports the totals; the Radon intermediates themselves, (n_alpha + 2) x pitch x 4 bytes each, belong to their ecc_dtr):
+ *   row-paired copy (always):  (n_alpha + 1) x pitch x 8 bytes                   768 x 768 bins: 4.92 MB, 400 views 1.97 GB
+ *   row-quad copy (see above): ceil((n_alpha + 1) / 4) x pitch x 64 bytes        768 x 768 bins: 9.88 MB, 400 views 3.95 GB
+ * i.e. 2x and 4x the slab (2.46 MB): a 400-view metric holds 5.9 GB beside the 0.99 GB of the stack itself -- for 0.300 -> 0.294 ms
+ * per evaluation in the row-quad case.  A process that keeps many metrics alive on one device should create them from a context
+ * with ECC_QUAD_COPIES_OFF (same bits, -2 %). */
 #define ECC_QUAD_COPIES_AUTO (-1)
 #define ECC_QUAD_COPIES_OFF 0
 #define ECC_QUAD_COPIES_ON 1
 int ecc_ctx_set_quad_copies(ecc_ctx* ctx, int mode);
+/* Device memory the metric owns right now, in bytes (any pointer may be null): the row-paired copies, the row-quad copies
+ * (0 when they were not built), everything else (geometry, per-pair records of 296 bytes, pair values, cost image, index
+ * lists, the pose batch's scratch -- grown on demand, kept until the metric is destroyed). */
+int ecc_metric_device_bytes(const ecc_metric* m, int64_t* paired_bytes, int64_t* quad_bytes, int64_t* other_bytes);
 int ecc_debug_small_stamps(unsigned long long* out, int n_blocks);
 /* Host clock (seconds, std::chrono::steady_clock) at fixed points of the metric's last ecc_metric_set_projections and last
  * synchronous all-pairs / range evaluation -- where the host's share of a step goes (scripts/step_fixed_cost.py):

@@ -45,3 +45,31 @@ def test_without_a_gpu_the_ranks_fail_loudly_and_so_does_the_parent():
         pytest.skip("needs a box without a GPU")
     r = _run(["--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-live-pmc"])
     assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+def test_launcher_hands_out_distinct_local_ranks_and_shared_devices_trip():
+    """what can be verified about N > 1 without a second GPU -- the self-launcher gives every rank its own
+    LOCAL_RANK (= its device), and the check that runs before anything is measured refuses ranks that report the same device."""
+    r = _run(["--gpus", "3", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert sorted(d["config"]["local_ranks"]) == [0, 1, 2]
+    r = _run(["--gpus", "2", "--launch-check"], ECC_BENCH_FAKE_SHARED_DEVICE="1")
+    assert r.returncode != 0 and "ranks share devices" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    r = _run(["--gpus", "2", "--launch-check", "--single-device"], ECC_BENCH_FAKE_SHARED_DEVICE="1")  # the one-GPU rehearsal form
+    assert r.returncode == 0
+
+
+def test_ranks_agree_on_the_rccl_exchange_before_anybody_joins_it():
+    """Advisor, round 5: a rank that cannot bind RCCL returns from ecc_comm_create at once and the others would wait inside
+    ncclCommInitRank for ever.  The ranks therefore agree first (MIN over `ecc_comm_available`); one rank without RCCL turns
+    the library's exchange off on ALL ranks."""
+    r = _run(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])["config"]["rccl_agreement"]
+    assert len(a) == 2 and len({x["agreed"] for x in a}) == 1 and all(x["agreed"] == all(y["local"] for y in a) for x in a)
+    r = _run(["--gpus", "2", "--launch-check"], ECC_BENCH_FAKE_NO_RCCL_RANK="1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    a = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])["config"]["rccl_agreement"]
+    assert [x["local"] for x in sorted(a, key=lambda x: x["rank"])][1] is False and not any(x["agreed"] for x in a)

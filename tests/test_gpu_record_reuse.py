@@ -291,3 +291,47 @@ def test_geometry_users_between_two_sets_drop_the_kept_records(gpu_ctx, small_sc
             assert np.array_equal(da[k], db[k]), k
         on.close()
         off.close()
+
+
+def test_pipelined_publish_and_wait_keep_the_fork_event(gpu_ctx):
+    """Round-5 advisor finding: ecc_metric_wait_scalar(k) proves only that the work queued BEFORE publish(k) has run.  In the
+    pipelined order async(k), publish(k), async(k + 1), wait(k), async(k + 2) the evaluation k + 1 may still be running on
+    both streams when k + 2's side-stream refit starts: the metric must not be declared quiet (which would drop the fork
+    event in front of the refit).  Sizes that take the two-stream form (the refit's k01 rewrites records, its list launch
+    rewrites value slots the pending launches read), every published value against a metric without reuse."""
+    import torch
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    rng = np.random.default_rng(17)
+    n, S, B = 150, 128, 48   # 11 175 pairs
+    Ps = synthetic.short_scan(n, S, S, 0.308 * 1024 / S)
+    base = [E.RadonIntermediate.from_host(gpu_ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(5)]
+    dtrs = [base[v % 5] for v in range(n)]
+    on = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(True, always=True)
+    off = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setRecordReuse(False)
+    n_pairs = n * (n - 1) // 2
+    dev = torch.device("cuda", 0)
+    sums = torch.zeros(40, dtype=torch.float64, device=dev)
+    pairs = [torch.zeros(n_pairs, dtype=torch.float32, device=dev) for _ in range(2)]
+    poses = [_moved(Ps, [(7 * k + 3) % n, (k * k) % n] if k % 3 else [(5 * k) % n], 0.05 * (k + 1)) for k in range(40)]
+    want = [off.setProjectionMatrices(P).evaluate_range(0, n_pairs) for P in poses]
+    on.setProjectionMatrices(poses[0]).evaluate_range(0, n_pairs)  # kept records: the calls below take the refit
+    got = []
+    on.setProjectionMatrices(poses[0])
+    on.evaluate_range_async(0, n_pairs, sums[0:1], pairs[0])
+    on.publish_scalar(sums[0:1])
+    for k in range(1, 40):
+        on.setProjectionMatrices(poses[k])
+        on.evaluate_range_async(0, n_pairs, sums[k:k + 1], pairs[k & 1])   # queued behind publish(k - 1) ...
+        got.append(on.wait_scalar())                                       # ... and possibly still running here
+        on.publish_scalar(sums[k:k + 1])
+    got.append(on.wait_scalar())
+    gpu_ctx.synchronize()
+    torch.cuda.synchronize()
+    assert got == want
+    assert sums.cpu().tolist() == want
+    # after a wait with nothing queued behind the publish the synchronous path continues unharmed
+    assert on.setProjectionMatrices(poses[3]).evaluate_range(0, n_pairs) == want[3]
+    on.close(); off.close()
+    for d in base:
+        d.close()

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _resources():
+    pytest.importorskip("msgpack")  # scripts/kernel_resources.py decodes the AMDGPU metadata notes with it
     spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
