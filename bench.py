@@ -43,7 +43,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # peaks from /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0       # HBM3E, spec (6.29 TB/s measured with a float4 copy)
+HBM_PEAK_GBS = 8000.0       # HBM3E, spec
+HBM_ACHIEVABLE_GBS = 6290.0  # what a float4 copy reaches (MI355X_MICROARCH.md: "8.0 TB/s spec; 6.29 TB/s measured (float4 copy, 79%)")
 ENGINE_CLOCK_GHZ = 2.4      # peak engine clock; the pair kernel runs at ~2.1 GHz under load
 N_CU, SIMD_PER_CU = 256, 4
 L1_BYTES_PER_CLK_CU = 64.0  # a 16-byte-per-lane gather occupies the CU's vector L1 for 16 cycles (profiles/r01_gather_rate.txt)
@@ -972,7 +973,11 @@ def main():
         traffic = int(2 * pmc["FETCH_SIZE"] * 1024 + pmc["WRITE_SIZE"] * 1024)
         traffic_src = "2 x FETCH_SIZE + WRITE_SIZE (KiB -> B; gfx950 counts 128-B fabric reads as 64 B); " + pmc_origin
         roofs["hbm_measured"] = {"achieved": traffic / pair_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": traffic / pair_s / 1e9 / HBM_PEAK_GBS}
+                                 "frac": traffic / pair_s / 1e9 / HBM_PEAK_GBS,
+                                 "achievable": HBM_ACHIEVABLE_GBS,
+                                 "frac_of_achievable": traffic / pair_s / 1e9 / HBM_ACHIEVABLE_GBS,
+                                 "note": "bytes the launch moved through the fabric (PMC) per second; `achievable` = what a float4 copy "
+                                         "reaches on this part (the guide's measured 6.29 TB/s): the roof a kernel can actually touch"}
     # SURVEY.md 8(d)'s compulsory figure: every Radon intermediate read once + the per-view geometry + one float per pair
     hbm_compulsory = 4 * n * B * B + 64 * n + 4 * count
     if power_report and power_report.get("pair_steps"):
@@ -981,9 +986,35 @@ def main():
             if r in roofs:
                 roofs[r]["frac_at_measured_clock"] = roofs[r]["frac"] * scale
                 roofs[r]["measured_clock_mhz"] = power_report["pair_steps"]["sclk_mhz_avg"]
-    bound = max(roofs, key=lambda r: roofs[r]["frac"])
-    roofline = {"bound": bound, "achieved": roofs[bound]["achieved"], "peak": roofs[bound]["peak"],
-                "unit": roofs[bound]["unit"], "frac": roofs[bound]["frac"], "traffic": traffic,
+    # The binding roof: every roof priced against what can actually be reached -- the measured HBM bytes against the achievable
+    # bandwidth, not the spec sheet's (round 5's verdict: against 6.29 TB/s HBM is the tightest of the three).
+    bound_key = max(roofs, key=lambda r: roofs[r].get("frac_of_achievable", roofs[r]["frac"]))
+    bound = {"hbm_measured": "hbm"}.get(bound_key, bound_key)
+    # on-chip / off-chip split: the same 79 800 pair geometries sampling only EIGHT Radon intermediates (view v -> v mod 8: 39 MB of
+    # row-paired copies, resident in the Infinity Cache) -- the launch with its HBM misses taken away
+    cache_resident_ms, one_slab_ms = None, None
+    if world == 1 and rank == 0 and not args.pmc_child and n >= 16:
+        ii, jj = np.triu_indices(n, 1)
+        out8 = np.empty(len(ii), np.float32)
+        ctx.enable_timing(True)
+        res_ms = {}
+        for alias in (8, 1):
+            m8 = E.MetricRadonIntermediate(ctx, Ps, dtrs[:alias])
+            idx8 = np.ascontiguousarray(np.stack([ii, jj, ii % alias, jj % alias], axis=1).astype(np.int32))
+            ts = []
+            for rep in range(6):
+                m8.evaluate(idx8, out8)
+                ts.append(ctx.last_kernel_ms("pairs"))
+            res_ms[alias] = float(np.median(ts[1:]))
+            m8.close()
+        cache_resident_ms, one_slab_ms = res_ms[8], res_ms[1]
+    roofline = {"bound": bound, "bound_roof": bound_key, "achieved": roofs[bound_key]["achieved"], "peak": roofs[bound_key]["peak"],
+                "unit": roofs[bound_key]["unit"], "frac": roofs[bound_key]["frac"],
+                "frac_of_achievable": roofs[bound_key].get("frac_of_achievable"), "traffic": traffic,
+                "kernel_ms_cache_resident": cache_resident_ms, "kernel_ms_one_slab": one_slab_ms,
+                "kernel_ms_cache_resident_note": "pairs_kernel over the same pair geometries with every view's Radon intermediate aliased to "
+                                                 "one of 8 (index list i, j, i mod 8, j mod 8; 39 MB of row-paired copies: Infinity-Cache resident) -- what the launch takes when "
+                                                 "nothing misses to HBM; kernel_ms_one_slab: all views aliased to ONE (4.9 MB: mostly L2 resident)",
                 "traffic_source": traffic_src, "kernel": "pairs_kernel<true, false>", "kernel_ms": pair_ms,
                 "algorithmic_bytes_per_launch": launch_bytes, "roofs": roofs,
                 "hbm_compulsory_bytes": hbm_compulsory,
@@ -1063,6 +1094,9 @@ def main():
                    "radon_arithmetic": "exact (the Radon intermediates the timed evaluations sample; ms_per_radon_intermediate is this mode)",
                    "n_kappa_per_pair": n_kappa, "pairs_per_rank": count, "parallelism": "pair-shard x%d (contiguous, cost-balanced)" % world,
                    "sum_exchange": exch_name[best],
+                   "metric_device_bytes": dict(metric.device_bytes(), radon_intermediates=int(4 * n * E.slab_floats(B, B)),
+                                               note="ecc_metric_device_bytes: the row-paired and row-quad sampling copies the metric "
+                                                    "owns (2x and 4x the stack; include/ecc_hip.h, ECC_QUAD_COPIES_*) and its scratch"),
                    # the step moves one view like the reference's optimiser loop does; the library's opt-in pose-delta mode
                    # (ecc_metric_set_incremental) would re-evaluate 399 pairs instead of all -- it is NOT used here
                    "pose_delta_evaluation": "off: every step evaluates all %d pairs" % n_pairs,
@@ -1157,6 +1191,32 @@ def main():
                 float(rel.max()), float(np.percentile(rel, 99)), float(np.percentile(rel, 50)))
             out["pair_rel_err_note"] = ("all %d pair values of the timed (polynomial) path vs oracle/; single values carry the fp32 "
                                         "rounding of the sample positions (DESIGN.md 2), the mean averages it out" % n_pairs)
+            # WHOSE error is that?  The normative oracle computes a sample's (angle, distance) in fp32 like the reference
+            # (ref: ...RadonIntermediate.cu:71-113, EpipolarConsistencyCommon.hxx:152-171); its variant 1 does the same mapping
+            # in binary64 and rounds once -- the noise-free pair values of the same formula.  Three distributions over all pairs:
+            # timed path vs normative (the one above), normative vs variant 1 (the reference arithmetic's own fp32 rounding),
+            # timed path vs variant 1 (this library's error against the noise-free values).
+            oracle.set_variant(1, native=True)
+            try:
+                ref64 = oracle.evaluate_all(Psub, host_dtrs, S, S, native=True)
+            finally:
+                oracle.set_variant(0, native=True)
+            p64 = np.asarray(ref64["pairs"], np.float64)
+
+            def dist3(a, b):
+                r = np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+                return {"max": float(r.max()), "p99": float(np.percentile(r, 99)), "p50": float(np.percentile(r, 50))}
+            g64 = gpu_pairs.astype(np.float64)
+            out["pair_rel_err_attribution"] = {
+                "timed_vs_normative_oracle": dist3(g64, ref_pairs),
+                "normative_oracle_vs_float64_geometry": dist3(ref_pairs, p64),
+                "timed_vs_float64_geometry": dist3(g64, p64),
+                "mean_rel_err": {"timed_vs_normative": abs(gpu_mean - ref["mean"]) / abs(ref["mean"]),
+                                 "normative_vs_float64_geometry": abs(ref["mean"] - ref64["mean"]) / abs(ref64["mean"]),
+                                 "timed_vs_float64_geometry": abs(gpu_mean - ref64["mean"]) / abs(ref64["mean"])},
+                "note": "oracle variant 1 = the reference's line -> (angle, distance) mapping in binary64, rounded once "
+                        "(oracle/ecc_oracle.c or_redundancy_f64): when the timed path is closer to it than the normative oracle "
+                        "is, a cost-image entry carries the REFERENCE arithmetic's fp32 rounding, not this library's"}
         # Radon baseline: 1/4 of the bins of one image
         img = synthetic.projections_numpy([Ps[n // 3]], S, S, phantom)[0]
         bins = np.arange(0, B * B, 4, dtype=np.int32)

@@ -245,7 +245,16 @@ int ecc_metric_set_params(ecc_metric* m, double object_radius_mm, double dkappa,
  *   ECC_SAMPLING_AUTO        (default) REFERENCE when one evaluation covers at most
  *                            ECC_SAMPLING_AUTO_REFERENCE_PAIRS pairs (the whole evaluation is one pair's latency either
  *                            way: 2-view metric values, index lists as in tools/Registration/Registration3D3D.hxx:95,109),
- *                            POLYNOMIAL above.  Callers that compare values ACROSS calls of different size fix the mode. */
+ *                            POLYNOMIAL above.  Callers that compare values ACROSS calls of different size fix the mode.
+ * WHOSE ROUNDING a cost-image entry carries (measured, scripts/pair_error_attribution.py, tests/test_configs.py; bench.py reports
+ * it at full size as pair_rel_err_attribution).  The same formulas with the line -> (angle, distance) mapping in binary64, rounded
+ * once, give the noise-free pair values.  The REFERENCE arithmetic (fp32 in source order = ECC_SAMPLING_REFERENCE = the CPU path)
+ * is p50 1.4e-5 / p99 7.0e-5 / max 1.3e-4 away from them at 64 views of 512^2 -- and its MEAN 9.9e-6, the systematic part being
+ * its float constant Pi (EpipolarConsistencyCommon.hxx:155,159).  POLYNOMIAL is 9.8e-6 / 5.0e-5 / 1.2e-4 away from the same
+ * noise-free values, PER_SAMPLE 9.9e-6 / 3.9e-5 / 5.8e-5: both are CLOSER to them than the reference arithmetic is, while they
+ * reproduce the reference's mean (float Pi included) to 6e-8 / 1.6e-7.  So the ~1e-5 (median) by which a single entry of the
+ * n x n cost image differs from the CPU path's is the fp32 rounding of the reference's own arithmetic, not an error this
+ * library adds; a caller that needs the CPU path's entry bit for bit selects ECC_SAMPLING_REFERENCE. */
 /* ECC_SAMPLING_AUTO resolves from the size of the EVALUATION, not of the launch: n (n - 1) / 2 for ecc_metric_evaluate_all
  * and for every ecc_metric_evaluate_range[_async] shard of it (so G shard sums add up to the one-device sum's arithmetic
  * whatever G, and cost-balanced or re-balanced shards never mix modes), the list length for index lists. */

@@ -379,10 +379,10 @@ def direct_evaluate(Ps, imgs, dkappa=0.0, object_radius_mm=0.0, fbcc=False):
     return dict(sum=total, cost=cost)
 
 
-def set_variant(v):
+def set_variant(v, native=False):
     """0 = normative fp32 path (correctly rounded elementary functions); 1 = line->(angle,distance)
     mapping in binary64 (noise-floor probe); 2 = platform float libm (what oracle/_ref is built on)."""
-    L = lib()
+    L = lib(native)
     L.eccor_set_variant.argtypes = [C.c_int]
     L.eccor_set_variant(int(v))
 
