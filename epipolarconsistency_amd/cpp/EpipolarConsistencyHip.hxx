@@ -678,6 +678,43 @@ public:
         return means;
     }
 
+    /// Not in the reference: ecc_metric_evaluate_pose_deltas -- K poses that each replace a few views of the CURRENT matrices
+    /// (moved_views[k]: strictly ascending view indices; moved_Ps[k]: their matrices), evaluated as one batched record / pair /
+    /// sum launch each (a sweep of one view as in Gui/Visualization.h:59-112, the probes of a finite-difference gradient):
+    /// every value bit-identical to replacing those views, setProjectionMatrices and evaluate(); the current matrices stay.
+    /// With a device group the poses are expanded and dealt to the ranks (ecc_group_metric_evaluate_poses).
+    std::vector<double> evaluatePoseDeltas(const std::vector<std::vector<int> >& moved_views,
+                                           const std::vector<std::vector<Geometry::ProjectionMatrix> >& moved_Ps)
+    {
+        if (moved_views.size() != moved_Ps.size()) throw std::runtime_error("evaluatePoseDeltas: one matrix list per pose");
+        std::vector<double> means(moved_views.size(), 0.0);
+        if (moved_views.empty()) return means;
+        if (m_gh) {
+            std::vector<std::vector<Geometry::ProjectionMatrix> > poses(moved_views.size(), Ps);
+            for (size_t k = 0; k < moved_views.size(); ++k) {
+                if (moved_views[k].size() != moved_Ps[k].size()) throw std::runtime_error("evaluatePoseDeltas: one matrix per moved view");
+                for (size_t q = 0; q < moved_views[k].size(); ++q) poses[k].at((size_t)moved_views[k][q]) = moved_Ps[k][q];
+            }
+            const std::vector<Geometry::ProjectionMatrix> keep = Ps;
+            means = evaluatePoses(poses);
+            setProjectionMatrices(keep);
+            return means;
+        }
+        std::vector<int32_t> off(1, 0), views;
+        std::vector<double> flat;
+        for (size_t k = 0; k < moved_views.size(); ++k) {
+            if (moved_views[k].size() != moved_Ps[k].size()) throw std::runtime_error("evaluatePoseDeltas: one matrix per moved view");
+            for (size_t q = 0; q < moved_views[k].size(); ++q) {
+                views.push_back(moved_views[k][q]);
+                flat.insert(flat.end(), moved_Ps[k][q].data(), moved_Ps[k][q].data() + 12);
+            }
+            off.push_back((int32_t)views.size());
+        }
+        detail::check(ecc_metric_evaluate_pose_deltas(m_h, (int)moved_views.size(), off.data(), views.empty() ? nullptr : views.data(),
+                                                      flat.empty() ? nullptr : flat.data(), means.data()));
+        return means;
+    }
+
     /// The metric borrows the dtrs: "DO NOT delete or change _dtrs during lifetime" (ref: .h:45).
     MetricRadonIntermediate& setRadonIntermediates(const std::vector<RadonIntermediate*>& _dtrs)
     {

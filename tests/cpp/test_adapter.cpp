@@ -115,6 +115,16 @@ int main(int argc, char** argv)
             for (int step = 0; same && step < 4; ++step) same = batch[step] == one_by_one[step] && small_off[step] == one_by_one[step];
             ecc.setProjectionMatrices(Ps);
             printf("round4 %d %.17g\n", (same && one_by_one[0] != one_by_one[1]) ? 1 : 0, batch[3]);
+            // round 6: the same four poses as deltas of the current matrices (one moved view each) -- the same bits again, and
+            // the current matrices stay
+            std::vector<std::vector<int> > moved_views(4, std::vector<int>(1, 1));
+            std::vector<std::vector<ProjectionMatrix> > moved_Ps;
+            for (int step = 0; step < 4; ++step) moved_Ps.push_back(std::vector<ProjectionMatrix>(1, poses[step][1]));
+            const double before = ecc.evaluate();
+            const std::vector<double> deltas = ecc.evaluatePoseDeltas(moved_views, moved_Ps);
+            bool same6 = deltas.size() == 4 && ecc.evaluate() == before;
+            for (int step = 0; same6 && step < 4; ++step) same6 = deltas[step] == one_by_one[step];
+            printf("round6 %d %.17g\n", same6 ? 1 : 0, deltas[3]);
         }
         {   // PreProccess (Gui/PreProccess.h): the two image calls one after the other on image 1, the fused stack call on
             // all images -- results written next to the input file for the driver to compare
