@@ -397,7 +397,7 @@ int evaluate_deltas(ecc_metric* m, int n_poses, const int32_t* off, const int32_
             not_batched->push_back(k);
             continue;
         }
-        if ((int64_t)b_views.size() + c > max_cols) {
+        if ((int64_t)b_views.size() + c > max_cols || b_pose.size() >= 32768) {  // (the sum's grid is slices x poses: y < 65 536)
             rc = flush();
             if (rc) return rc;
         }

@@ -16,13 +16,14 @@ for f in glob.glob("$out/**/*counter_collection.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 per=collections.defaultdict(float)
 for r in rows:
-    per[(r["Kernel_Name"][:90], r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    per[(r["Kernel_Name"][:90] + (" grid=%s" % r["Grid_Size"] if "Grid_Size" in r else ""), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for (name, d, c), v in per.items(): acc[name][c].append(v)
 dur=collections.defaultdict(list)
 for f in glob.glob("$out/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        dur[r["Kernel_Name"][:90]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        g = [int(float(r.get(k) or 1)) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")] if "Grid_Size_X" in r else None
+        dur[r["Kernel_Name"][:90] + (" grid=%d" % (g[0] * g[1] * g[2]) if g else "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 with open("$R/gpurun_out/pmc_$tag.summary.txt","w") as f:
     for k,v in sorted(acc.items()):
         line = k + " | " + ", ".join("%s=%.6g (n=%d)" % (c, sum(x)/len(x), len(x)) for c,x in sorted(v.items()))

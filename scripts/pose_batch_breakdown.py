@@ -11,6 +11,8 @@ from epipolarconsistency_amd import synthetic, geometry
 n, S, B = 400, 1024, 768
 if len(sys.argv) > 1:
     n = int(sys.argv[1])
+Ks = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [600, 100, 12, 1]
+forms = sys.argv[3].split(",") if len(sys.argv) > 3 else ["deltas", "dense"]
 ctx = E.Context(0)
 rng = np.random.default_rng(0)
 base_dtrs = [E.RadonIntermediate.from_host(ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(8)]
@@ -28,13 +30,13 @@ for q in range(600):
     rows.append((Ps[moving] @ geometry.rigid_transform(**{names[p]: x})).T.reshape(12))
 rows = np.ascontiguousarray(np.stack(rows))
 m.evaluate()
-for K in (600, 100, 12, 1):
+for K in Ks:
     off = np.arange(K + 1, dtype=np.int32)
     views = np.full(K, moving, np.int32)
     dense = np.repeat(packed[None], K, axis=0)
     dense[:, moving, :] = rows[:K]
     dense = np.ascontiguousarray(dense)
-    for form in ("deltas", "dense"):
+    for form in forms:
         ts = []
         for rep in range(6):
             m.setProjectionMatrices(packed)
