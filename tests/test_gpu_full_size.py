@@ -114,3 +114,56 @@ def test_multi_workgroup_sum_is_stable_under_repetition(full_scan):
     total, vals = m.evaluate_range(0, n_pairs, want_pairs=True)
     assert abs(total - float(np.sum(vals.astype(np.float64)))) <= 1e-13 * total
     assert total / n_pairs == next(iter(seen[0]))
+
+
+def test_pose_batch_at_full_size(full_scan, oracle_mod):
+    """BASELINE config 5's shape at full size (ref: Gui/Visualization.h:59-112): poses of view 200 (and a few of two views) as ONE
+    batched record / pair / sum launch each -- the sixteen-slice sum over 79 800 values with 399 or 797 substituted -- against
+    setProjectionMatrices + evaluate per pose, bit for bit; one pose against the oracle on the read-back Radon intermediates."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import geometry
+    m, Ps = full_scan["metric"], full_scan["Ps"]
+    P0 = E.pack_projection_matrices(Ps)
+    m.setProjectionMatrices(P0)
+    K = 37  # not a divisor of anything
+    views, rows, poses = [], [], []
+    for k in range(K):
+        vk = [200] if k % 5 else [3 + k, 200]
+        P = P0.copy()
+        for v in vk:
+            P[v] = (Ps[v] @ geometry.rigid_transform(tx=-2.0 + 0.1 * k, ry=0.0007 * k, rz=0.002 * (v % 3))).T.reshape(12)
+        views.append(vk)
+        rows.append(P[vk].copy())
+        poses.append(P)
+    got = m.evaluate_pose_deltas(views, rows)
+    assert m.last_batched_poses() == K
+    base = m.evaluate()
+    m.setPoseBatching(False)
+    want = np.array([m.setProjectionMatrices(P).evaluate() for P in poses])
+    m.setPoseBatching(True)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)
+    assert len(set(want.tolist())) == K
+    # the full-matrix form, rank 1 of 3, starting from the last pose's matrices (most poses are deltas of the FIRST pose then)
+    part = m.evaluate_poses(np.ascontiguousarray(np.stack(poses)), first=1, stride=3)
+    assert np.array_equal(part[1::3], want[1::3]) and not part[0::3].any() and not part[2::3].any()
+    m.setProjectionMatrices(P0)
+    assert m.evaluate() == base
+    # one pose against the oracle (every 8th view: 1 225 pairs among them, the moved view included)
+    sub = list(range(0, N, 8))
+    assert 200 in sub
+    Pk = [poses[7][v].reshape(4, 3).T.copy() for v in sub]
+    host = [full_scan["dtrs"][v].readback() for v in sub]
+    ref = oracle_mod.evaluate_all(Pk, host, S, S)["mean"]
+    m.setProjectionMatrices(poses[7])
+    assert abs(m.evaluate(set(sub)) - ref) <= 1e-5 * ref
+    m.setProjectionMatrices(P0)
+
+
+def test_device_bytes_of_the_defaults(full_scan):
+    """ecc_metric_device_bytes: what a 400-view metric holds beside the 0.99-GB stack -- the numbers
+    INTEGRATION.md and include/ecc_hip.h state: row-paired copies 2x, row-quad copies 4x the slab."""
+    b = full_scan["metric"].device_bytes()
+    pitch = (B + 2 + 31) // 32 * 32
+    assert b["paired_copies"] == N * (B + 1) * pitch * 8 == 1968640000
+    assert b["quad_copies"] in (0, N * ((B + 1 + 3) // 4) * pitch * 64)   # built while they fit a quarter of the free memory
+    assert 0 < b["other"] < 1 << 30
