@@ -31,9 +31,11 @@ def test_randomised_radon_sweep():
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("script,args,done", [("fuzz_preprocess.py", ["60", "4"], "0 of 60 cases differ"),
-                                              ("fuzz_direct.py", ["30", "2"], "0 of 30 cases differ")])
+                                              ("fuzz_direct.py", ["30", "2"], "0 of 30 cases differ"),
+                                              ("fuzz_poses.py", ["80", "3"], "0 of 80 cases differ")])
 def test_randomised_sweeps_of_the_widened_rows(script, args, done):
-    """Pre-processing (bit-exact) and MetricDirect / FBCC (1e-5 for both forms) on random configurations."""
+    """Pre-processing (bit-exact), MetricDirect / FBCC (1e-5 for both forms) and the batched pose evaluation (bit-identical to the
+    sequential evaluations of the same library: csrc/ecc_poses.hip) on random configurations."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + args, capture_output=True, text=True,
                        timeout=500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
