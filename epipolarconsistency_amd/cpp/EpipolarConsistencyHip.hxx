@@ -660,7 +660,9 @@ public:
     MetricRadonIntermediate& setSmallEval(bool on = true) { small_eval = on ? 1 : 0; push_params(); return *this; }
     /// Not in the reference: ecc_metric_evaluate_poses -- independent all-pairs evaluations of several sets of projection
     /// matrices (a sweep as in Gui/Visualization.h:78-98 plotCostFunction, the probes of a finite-difference gradient),
-    /// each value bit-identical to setProjectionMatrices(poses[k]) + evaluate().  The last pose stays current.
+    /// each value bit-identical to setProjectionMatrices(poses[k]) + evaluate().  Poses that differ from the current matrices
+    /// (or from the first pose) in a few views are evaluated as ONE batched record / pair / sum launch each (ecc_poses.hip:
+    /// two orders of magnitude above one call per pose).  The last pose stays current.
     std::vector<double> evaluatePoses(const std::vector<std::vector<Geometry::ProjectionMatrix> >& poses)
     {
         std::vector<double> means(poses.size(), 0.0);
