@@ -706,7 +706,7 @@ int evaluate_cached(ecc_metric* m, int64_t first, int64_t count, double* sum_d, 
                     ctx->ev_valid[0] = true;
                 }
             }
-            HIP_TRY(ecc_launch_sum_pairs(m->cache_values_d, count, sum_d, m->sum_scratch_d, ctx->stream));
+            if (sum_d) HIP_TRY(ecc_launch_sum_pairs(m->cache_values_d, count, sum_d, m->sum_scratch_d, ctx->stream));  // (null: the pose batch wants the values only)
             for (int v : changed) std::memcpy(m->cache_Ps.data() + 12 * v, Pcur + 12 * v, sizeof(double) * 12);
             m->last_evaluated_pairs = L;
             m->cache_valid = true;

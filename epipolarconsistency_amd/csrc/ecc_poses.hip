@@ -6,10 +6,11 @@
 // differs from a BASE set of matrices in one view changes n - 1 of the n (n - 1) / 2 pair values: ~1.5 us of pair-kernel work
 // at 400 views inside a ~37-us step of launches, polls and hand-overs.  When the poses are known up front (a sweep, a
 // gradient) nothing forces that cadence.  ecc_metric_evaluate_pose_deltas does, for K poses:
-//   base values   the pair values of the base matrices (evaluate_cached: kept between calls, only what changed is redone)
+//   base values   the pair values of the base matrices (evaluate_cached: kept between calls, only what changed is redone;
+//                 nothing is launched when nothing changed)
 //   pose_list     ONE launch: the index grid -- entry (partner u, column q) = pair {u, moved view of column q}, the moved view's
-//                 geometry taken from entry n + q of the EXTENDED arrays; a column per (pose, moved view)
-//   e1_kernel     ONE launch over the base views followed by all moved matrices (the reference's Householder QR, bit-identical)
+//                 geometry taken from entry n + q of the EXTENDED arrays; a column per (pose, moved view) -- and, in the same
+//                 launch, E1 of the base views followed by all moved matrices (the reference's Householder QR, bit-identical)
 //   k01_kernel    ONE launch over the n x Q grid
 //   pairs_kernel  ONE launch over it (partner-major: neighbours in the launch sample the same two Radon intermediates under
 //                 slightly different geometries -- their lines are shared in the L1 / L2)
@@ -48,10 +49,33 @@ struct PoseLists {
 //   when this pose moves it.  Holes -- u == v, and u < v when the pose moves u as well (that pair belongs to u's column) --
 //   become (0, 0, 0, 0): a pair of a view with itself, whose value (0) nobody reads.
 // Also copies the lists from the pinned block into device memory for sum_poses_kernel.
+// Workgroups past the poses': E1 of the extended matrices (e1_kernel's work, geometry_kernel.hip -- the same code, ecc_host_geometry.h,
+// the same bits; ref: ...RadonIntermediate.cpp:134-163): wave 0 of such a workgroup (P^+)^T of 64 views, wave 1 their source positions.
 __global__ __launch_bounds__(256) void pose_list_kernel(PoseLists in, int n, int n_poses, int Q, int32_t* __restrict__ idx,
-                                                        int32_t* __restrict__ lists_d)
+                                                        int32_t* __restrict__ lists_d, const double* __restrict__ Ps_ext,
+                                                        float* __restrict__ PinvTs, float* __restrict__ Cs)
 {
     __shared__ int M[ECC_POSE_BATCH_MAX_MOVED];
+    if ((int)blockIdx.x >= n_poses) {  // uniform over the workgroup
+        const int role = threadIdx.x >> 6;
+        const int v = ((int)blockIdx.x - n_poses) * 64 + (threadIdx.x & 63);
+        if (role > 1 || v >= n + Q) return;
+        double P[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) P[q] = Ps_ext[12 * (size_t)v + q];
+        if (role == 0) {
+            float pinvT[12];
+            ecc_host::pinv_transpose(P, pinvT);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) PinvTs[12 * (size_t)v + q] = pinvT[q];
+        } else {
+            float C[4];
+            ecc_host::source_position(P, C);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Cs[4 * (size_t)v + q] = C[q];
+        }
+        return;
+    }
     const int k = blockIdx.x;
     const int o0 = in.off[k], c = in.off[k + 1] - o0;
     if ((int)threadIdx.x < c) {
@@ -91,7 +115,8 @@ __global__ __launch_bounds__(256) void pose_list_kernel(PoseLists in, int n, int
 template <int SLICES>
 __global__ __launch_bounds__(SUM_THREADS) void sum_poses_kernel(const float* __restrict__ base, long long count, int n, int Q,
                                                                 const int32_t* __restrict__ lists_d, int n_poses,
-                                                                const float* __restrict__ vals, double* __restrict__ partial)
+                                                                const float* __restrict__ vals, double* __restrict__ partial,
+                                                                double* __restrict__ out_host)
 {
     __shared__ float stage[4 * STAGE_F4];
     __shared__ float tail[4];
@@ -148,7 +173,10 @@ __global__ __launch_bounds__(SUM_THREADS) void sum_poses_kernel(const float* __r
     if (t == 0) {
         double part = 0.0;
         for (int w = 0; w < SUM_THREADS / 64; w++) part += s[w];
-        partial[(size_t)k * SLICES + slice] = part;
+        if (SLICES == 1)  // sum_pairs_kernel's own last step: this IS the result (no finish_poses_kernel launch)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(out_host) + k, (unsigned long long)__double_as_longlong(part),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else partial[(size_t)k * SLICES + slice] = part;
     }
 }
 
@@ -221,10 +249,12 @@ int run_batch(ecc_metric* m, const double* base, const float* base_vals_d, int K
     rc = fill_pair_params(m, &p, n_pairs, /*need_e1=*/false);  // the sampling mode of an all-pairs evaluation
     if (rc) return rc;
     PoseLists in = {reinterpret_cast<const int32_t*>(m->pose_h_dev + b_off), reinterpret_cast<const int32_t*>(m->pose_h_dev + b_views)};
-    hipLaunchKernelGGL(pose_list_kernel, dim3((unsigned)K), dim3(256), 0, ctx->stream, in, (int)n, K, Q, m->pose_idx_d, m->pose_lists_d);
+    // index tuples + lists (K workgroups) and E1 of the n + Q extended matrices (the workgroups behind them): one launch
+    const unsigned e1_blocks = entries > 0 ? (unsigned)((n + Q + 63) / 64) : 0u;
+    hipLaunchKernelGGL(pose_list_kernel, dim3((unsigned)K + e1_blocks), dim3(256), 0, ctx->stream, in, (int)n, K, Q, m->pose_idx_d,
+                       m->pose_lists_d, reinterpret_cast<const double*>(m->pose_h_dev + b_Ps), m->pose_PinvTs_d, m->pose_Cs_d);
     HIP_TRY(hipGetLastError());
     if (entries > 0) {
-        HIP_TRY(ecc_launch_e1(reinterpret_cast<const double*>(m->pose_h_dev + b_Ps), (int)(n + Q), m->pose_PinvTs_d, m->pose_Cs_d, ctx->stream));
         p.PinvTs = m->pose_PinvTs_d;
         p.Cs = m->pose_Cs_d;
         p.indices = m->pose_idx_d;
@@ -241,16 +271,18 @@ int run_batch(ecc_metric* m, const double* base, const float* base_vals_d, int K
         }
     }
     const int slices = n_pairs >= 32768 ? SUM_SLICES : 1;  // ecc_launch_sum_pairs (pairs_kernel.hip)
+    double* out_dev = reinterpret_cast<double*>(m->pose_h_dev + b_out);
     if (slices == 1)
         hipLaunchKernelGGL(sum_poses_kernel<1>, dim3(1, (unsigned)K), dim3(SUM_THREADS), 0, ctx->stream, base_vals_d, (long long)n_pairs,
-                           (int)n, Q, m->pose_lists_d, K, m->pose_values_d, m->pose_partial_d);
+                           (int)n, Q, m->pose_lists_d, K, m->pose_values_d, m->pose_partial_d, out_dev);
     else
         hipLaunchKernelGGL(sum_poses_kernel<SUM_SLICES>, dim3(SUM_SLICES, (unsigned)K), dim3(SUM_THREADS), 0, ctx->stream, base_vals_d,
-                           (long long)n_pairs, (int)n, Q, m->pose_lists_d, K, m->pose_values_d, m->pose_partial_d);
+                           (long long)n_pairs, (int)n, Q, m->pose_lists_d, K, m->pose_values_d, m->pose_partial_d, out_dev);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(finish_poses_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, m->pose_partial_d, slices, K,
-                       reinterpret_cast<double*>(m->pose_h_dev + b_out));
-    HIP_TRY(hipGetLastError());
+    if (slices > 1) {
+        hipLaunchKernelGGL(finish_poses_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, ctx->stream, m->pose_partial_d, slices, K, out_dev);
+        HIP_TRY(hipGetLastError());
+    }
     // the results arrive in pinned memory a few microseconds before the stream is reported idle: poll the last one, then the rest
     double t0 = 0.0;
     for (unsigned spins = 0;; ++spins) {
@@ -369,7 +401,7 @@ int evaluate_deltas(ecc_metric* m, int n_poses, const int32_t* off, const int32_
     ecc_metric_get_object_radius(m, &base_radius);
     // the base's pair values: kept between calls (the pose-delta cache), only the pairs of views that changed since are redone
     float* base_vals_d = nullptr;
-    int rc = evaluate_cached(m, 0, n_pairs, m->sum_d, &base_vals_d);
+    int rc = evaluate_cached(m, 0, n_pairs, /*sum_d=*/nullptr, &base_vals_d);  // (the values only: the segmented sum adds them per pose)
     if (rc) return rc;
     std::vector<int32_t> b_off, b_views;
     std::vector<double> b_Ps, sums;
