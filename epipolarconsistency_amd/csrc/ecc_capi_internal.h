@@ -148,6 +148,9 @@ struct ecc_metric {
     float* quads_d = nullptr;                // row-quad copies of all dtrs (owned; sampled by the pairs with kappa_max > pi/4), or null
     const float** quads_table_d = nullptr;
     int64_t quad_floats = 0;                 // floats per row-quad copy
+    std::vector<const float*> quads_table_h; // host image of quads_table_d
+    bool quads_possible = false;             // offsets into a row-quad copy fit 32 bits
+    bool quads_decided = true;               // ECC_QUAD_COPIES_AUTO: false until the first large evaluation has looked at the matrices
     float* Cs_d = nullptr;
     float* PinvTs_d = nullptr;
     int geom_capacity = 0;
@@ -296,6 +299,7 @@ void arm_result(ecc_metric* m);
 hipError_t wait_result(ecc_metric* m, hipStream_t stream, double* value);
 int set_device(const ecc_ctx* ctx);
 int ensure_poly_tables(ecc_ctx* ctx);
+void decide_quad_copies(ecc_metric* m);  // ECC_QUAD_COPIES_AUTO: build the row-quad copies if the current matrices' pairs would read them
 int ensure_e1(ecc_metric* m);  // E1 on the device for the staged matrices, if the device arrays are behind them
 // ecc_evaluate.hip: the parameters of a launch; the stream-ordered launches over a pair range; the pose-delta path
 int fill_pair_params(ecc_metric* m, EccPairParams* p, int64_t mode_count, bool need_e1 = true);

@@ -369,6 +369,9 @@ int launch_range(ecc_metric* m, int64_t first, int64_t count, float* pair_values
         return fail(ECC_ERR_INVALID_ARGUMENT, "fewer Radon intermediates than projection matrices");
     if (first < 0 || count < 0 || first + count > n_pairs)
         return fail(ECC_ERR_INVALID_ARGUMENT, "pair range outside [0, n(n-1)/2)");
+    // ECC_QUAD_COPIES_AUTO: the first evaluation of a large pair set decides, from the matrices, whether the row-quad copies are
+    // worth their memory (stream-ordered in front of the launches below; the same bits either way)
+    if (!m->quads_decided && n_pairs >= 32768 && count > 0) decide_quad_copies(m);  // (the EVALUATION's size: every shard of it decides alike)
     EccPairParams p;
     int rc = fill_pair_params(m, &p, n_pairs, /*need_e1=*/false);
     if (rc) return rc;

@@ -9,6 +9,73 @@
 using namespace ecc_internal;
 
 // ---- metric ------------------------------------------------------------------------------------
+namespace {
+// The row-quad copies of all the metric's Radon intermediates: allocation, table, build launch on the context's stream (ordered
+// in front of whatever samples them).  On failure nothing is left behind.
+hipError_t build_quad_copies(ecc_metric* m)
+{
+    const int n_dtrs = (int)m->dtrs.size();
+    std::vector<const float*>& qtable = m->quads_table_h;  // (lives with the metric: the asynchronous upload below may read it after this returns)
+    qtable.assign((size_t)n_dtrs, nullptr);
+    hipError_t e = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
+    if (e == hipSuccess) e = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);
+    for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) qtable[k] = m->quads_d + (size_t)m->quad_floats * k;
+    if (e == hipSuccess) e = hipMemcpyAsync(m->quads_table_d, qtable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, m->ctx->stream);
+    if (e == hipSuccess) e = ecc_launch_build_quad(m->dtr_table_d, m->quads_d, m->quad_floats, n_dtrs, m->n_alpha + 1, m->pitch, m->ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (m->quads_d) (void)hipFree(m->quads_d);
+        if (m->quads_table_d) (void)hipFree((void*)m->quads_table_d);
+        m->quads_d = nullptr;
+        m->quads_table_d = nullptr;
+    }
+    return e;
+}
+}  // namespace
+
+namespace ecc_internal {
+// ECC_QUAD_COPIES_AUTO, decided once per metric by its first evaluation of at least 32 768 pairs (launch_range): the copies cost
+// 4x the stack and only the pairs with kappa_max > pi/4 read them (in practice those whose baseline passes through the object,
+// kappa_max = pi/2: 3.5 % of a 200-degree short scan's pairs, none of a 90-degree scan's).  Built when at least 2 % of the
+// current matrices' pairs are such pairs AND all copies together fit a quarter of the free device memory; an allocation that
+// fails after all means "none" (the same bits either way).  kappa_max from the source positions alone (ref: computeK01,
+// EpipolarConsistencyCommon.hxx:115-123,137-145), float64 on the host: ~0.3 ms for 79 800 pairs, once.
+void decide_quad_copies(ecc_metric* m)
+{
+    if (m->quads_decided) return;
+    m->quads_decided = true;
+    const int64_t n = m->n_views;
+    if (n < 2 || (int64_t)m->dtrs.size() < n) return;
+    double radius = 0;
+    ecc_metric_get_object_radius(m, &radius);
+    const double* Ps = m->Ps_h[m->set_generation & 1];
+    std::vector<double> C(4 * (size_t)n);
+    for (int64_t v = 0; v < n; ++v) {
+        float c4[4];
+        ecc_host::source_position(Ps + 12 * (size_t)v, c4);
+        for (int k = 0; k < 4; ++k) C[4 * (size_t)v + k] = c4[k];
+    }
+    int64_t wide = 0;
+    const double sin_quarter = 0.70710678118654752;  // kappa_max > pi/4  <=>  radius / dist > sin(pi/4)
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = i + 1; j < n; ++j) {
+            const double *a = &C[4 * (size_t)i], *b = &C[4 * (size_t)j];
+            const double B01 = a[0] * b[1] - a[1] * b[0], B02 = a[0] * b[2] - a[2] * b[0], B03 = a[0] * b[3] - a[3] * b[0];
+            const double B12 = a[1] * b[2] - a[2] * b[1], B13 = a[1] * b[3] - a[3] * b[1], B23 = a[2] * b[3] - a[3] * b[2];
+            const double s2 = std::sqrt(B12 * B12 + B02 * B02 + B01 * B01), s3 = std::sqrt(B03 * B03 + B13 * B13 + B23 * B23);
+            if (!(s2 * sin_quarter > radius * s3)) ++wide;  // dist = s2 / s3 (also NaN geometry)
+        }
+    if (wide * 50 < n * (n - 1) / 2) return;  // under 2 %
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if ((uint64_t)m->quad_floats * 4u * (uint64_t)m->dtrs.size() > (uint64_t)free_b / 4u) return;
+    (void)build_quad_copies(m);  // (failure: no copies; the error state is cleared)
+}
+}  // namespace ecc_internal
+
 ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs, ecc_metric** out)
 {
     if (!ctx || !dtrs || !out) return fail(ECC_ERR_INVALID_ARGUMENT, "null argument");
@@ -58,38 +125,12 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     for (int k = 0; k < n_dtrs && e == hipSuccess; ++k) ptable[k] = m->paired_d + (size_t)paired_floats * k;
     if (e == hipSuccess)
         e = hipMemcpyAsync(m->paired_table_d, ptable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
-    // row-quad copies (ecc_ctx_set_quad_copies; 4x the slab memory, see pair_accumulate): offsets must fit 32 bits; by default
-    // they are built while all of them together take at most a quarter of the device memory that is free now (400 views
-    // of 768 x 768 bins: 3.9 GB) -- the same bits with or without them
-    std::vector<const float*> qtable(n_dtrs);
+    // row-quad copies (ecc_ctx_set_quad_copies; 4x the slab memory, see pair_accumulate): offsets must fit 32 bits.
+    // ECC_QUAD_COPIES_ON: built here.  ECC_QUAD_COPIES_AUTO (default): decided by the first large evaluation, when the matrices
+    // say whether the scan has pairs that read them at all (ecc_internal::decide_quad_copies); _OFF: never.
     m->quad_floats = (int64_t)((m->n_alpha + 1 + 3) / 4) * m->pitch * 16;
-    bool want_quads = m->quad_floats * 4 < ((int64_t)1 << 32) && ctx->quad_copies != ECC_QUAD_COPIES_OFF;
-    if (want_quads && ctx->quad_copies == ECC_QUAD_COPIES_AUTO) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
-            (void)hipGetLastError();
-            free_b = 0;
-        }
-        want_quads = (uint64_t)m->quad_floats * 4u * (uint64_t)n_dtrs <= (uint64_t)free_b / 4u;
-    }
-    if (e == hipSuccess && want_quads) {
-        hipError_t eq = hipMalloc((void**)&m->quads_table_d, sizeof(float*) * n_dtrs);
-        if (eq == hipSuccess) eq = hipMalloc((void**)&m->quads_d, sizeof(float) * (size_t)m->quad_floats * n_dtrs);
-        for (int k = 0; k < n_dtrs && eq == hipSuccess; ++k) qtable[k] = m->quads_d + (size_t)m->quad_floats * k;
-        if (eq == hipSuccess)
-            eq = hipMemcpyAsync(m->quads_table_d, qtable.data(), sizeof(float*) * n_dtrs, hipMemcpyHostToDevice, ctx->stream);
-        if (eq != hipSuccess && ctx->quad_copies == ECC_QUAD_COPIES_AUTO && (eq == hipErrorOutOfMemory || eq == hipErrorMemoryAllocation)) {
-            // The copies are optional (the same bits without them): in the automatic mode an allocation that fails after all --
-            // fragmentation, another process on the device between hipMemGetInfo and here -- means "no row-quad copies", not
-            // "no metric" (advisor, round 5).  ECC_QUAD_COPIES_ON keeps the error: the caller asked for them.
-            (void)hipGetLastError();
-            if (m->quads_d) (void)hipFree(m->quads_d);
-            if (m->quads_table_d) (void)hipFree((void*)m->quads_table_d);
-            m->quads_d = nullptr;
-            m->quads_table_d = nullptr;
-        } else
-            e = eq;
-    }
+    m->quads_possible = m->quad_floats * 4 < ((int64_t)1 << 32);
+    m->quads_decided = !(m->quads_possible && ctx->quad_copies == ECC_QUAD_COPIES_AUTO);
     if (e == hipSuccess) e = hipMalloc((void**)&m->sum_d, sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&m->sum_scratch_d, ecc_sum_scratch_bytes());
     if (e == hipSuccess) e = hipMemsetAsync(m->sum_scratch_d, 0, ecc_sum_scratch_bytes(), ctx->stream);
@@ -102,8 +143,7 @@ ECC_EXPORT int ecc_metric_create(ecc_ctx* ctx, int n_dtrs, ecc_dtr* const* dtrs,
     // the paired copies are built once, here
     if (e == hipSuccess)
         e = ecc_launch_build_paired(m->dtr_table_d, m->paired_d, paired_floats, n_dtrs, m->n_alpha + 1, m->pitch, ctx->stream);
-    if (e == hipSuccess && m->quads_d)
-        e = ecc_launch_build_quad(m->dtr_table_d, m->quads_d, m->quad_floats, n_dtrs, m->n_alpha + 1, m->pitch, ctx->stream);
+    if (e == hipSuccess && m->quads_possible && ctx->quad_copies == ECC_QUAD_COPIES_ON) e = build_quad_copies(m);  // (behind the table's upload)
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ecc_metric_destroy(m);

@@ -615,9 +615,12 @@ int ecc_debug_set_quad_copies(ecc_ctx* ctx, int on);
  * memory: 3.9 GB for 400 views of 768 x 768 bins).  The pairs whose baseline passes through the object (kappa_max = pi/2,
  * 3.5 % of a short scan's pairs, a fifth of its evaluation time) cross the Radon intermediates diagonally, a new angle row
  * every sample or two; the exact part of their sampling reads the row-quad copies: +2 % evaluations/s on the 400-view
- * benchmark, bit-identical values (tests/test_gpu_sampling_modes.py).  ECC_QUAD_COPIES_AUTO (default): built while all of
- * them together take at most a quarter of the device memory free at the time (and dropped silently if their allocation then
- * fails after all); _OFF: never; _ON: always (offsets permitting; an allocation failure is the metric's failure).
+ * benchmark, bit-identical values (tests/test_gpu_sampling_modes.py).  ECC_QUAD_COPIES_AUTO (default): decided ONCE per metric
+ * by its first all-pairs evaluation (or shard of one) over at least 32 768 pairs, from the matrices it runs with -- built when at least 2 % of their pairs have
+ * kappa_max > pi/4 (a 200-degree short scan: 3.5 %; a 90-degree scan: none, and no memory is spent) and all copies together
+ * take at most a quarter of the device memory free at that time (an allocation that fails after all means "none"); that
+ * evaluation is ~1.5 ms longer.  _OFF: never; _ON: always, at ecc_metric_create (offsets permitting; an allocation failure is
+ * the metric's failure).
  * MEMORY a metric owns per Radon intermediate of n_alpha x n_t bins, pitch = roundup(n_t + 2, 32) floats (ecc_metric_device_bytes
  * reports the totals; the Radon intermediates themselves, (n_alpha + 2) x pitch x 4 bytes each, belong to their ecc_dtr):
  *   row-paired copy (always):  (n_alpha + 1) x pitch x 8 bytes                   768 x 768 bins: 4.92 MB, 400 views 1.97 GB

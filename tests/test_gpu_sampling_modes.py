@@ -243,3 +243,41 @@ def test_auto_resolves_from_the_evaluation_not_the_shard(gpu_ctx):
         m.close()
     for d in base:
         d.close()
+
+
+def test_automatic_row_quad_copies_follow_the_scan(gpu_ctx):
+    """ECC_QUAD_COPIES_AUTO (the default) decides once per metric, at its first evaluation of >= 32 768 pairs, from the matrices:
+    a 200-degree short scan has pairs whose baseline passes through the object (kappa_max = pi/2: the only readers of the row-quad
+    copies) -- built; a 60-degree scan has none -- 4x the stack's memory is not spent.  Small
+    evaluations never build them.  The values are those of a metric without the copies either way."""
+    import epipolarconsistency_amd as E
+    from epipolarconsistency_amd import synthetic
+    rng = np.random.default_rng(23)
+    n, S, B = 260, 128, 32   # 33 670 pairs
+    base = [E.RadonIntermediate.from_host(gpu_ctx, rng.standard_normal((B, B)).astype(np.float32), S, S) for _ in range(5)]
+    dtrs = [base[v % 5] for v in range(n)]
+    for span, expect in ((200.0, True), (60.0, False)):
+        Ps = synthetic.short_scan(n, S, S, 0.308 * 1024 / S, span_deg=span)
+        gpu_ctx.setQuadCopies("off")
+        try:
+            off = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+        finally:
+            gpu_ctx.setQuadCopies("auto")
+        m = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+        assert m.device_bytes()["quad_copies"] == 0            # nothing before the first large evaluation
+        assert m.evaluate(set(range(40))) == off.evaluate(set(range(40)))
+        assert m.device_bytes()["quad_copies"] == 0            # a 780-pair index list does not decide
+        a, va = m.evaluate_range(0, n * (n - 1) // 2, want_pairs=True)
+        b, vb = off.evaluate_range(0, n * (n - 1) // 2, want_pairs=True)
+        assert a == b and np.array_equal(va, vb)
+        q = m.device_bytes()["quad_copies"]
+        assert (q == n * ((B + 1 + 3) // 4) * 64 * 64) if expect else (q == 0), (span, q)   # pitch 64 floats for 32 bins
+        assert m.evaluate() == off.evaluate() and m.device_bytes()["quad_copies"] == q     # decided once
+        assert off.device_bytes()["quad_copies"] == 0
+        m.close(); off.close()
+    small = E.MetricRadonIntermediate(gpu_ctx, synthetic.short_scan(60, S, S, 0.308 * 1024 / S), dtrs[:60])
+    small.evaluate()
+    assert small.device_bytes()["quad_copies"] == 0            # 1 770 pairs: never
+    small.close()
+    for d in base:
+        d.close()
