@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libecc_hip.so")
 SOURCES = ["radon_kernel.hip", "ramp_kernel.hip", "preprocess_kernel.hip", "direct_kernel.hip", "pairs_kernel.hip", "small_eval_kernel.hip", "geometry_kernel.hip", "ecc_capi.hip", "ecc_radon_api.hip", "ecc_metric_api.hip", "ecc_preprocess_api.hip", "ecc_direct_api.hip", "ecc_evaluate.hip", "ecc_poses.hip",
            "ecc_exchange.cpp", "ecc_group.cpp", "ecc_rccl.cpp"]  # .cpp: host-only code (no device code), still built by hipcc for the HIP headers
-HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", "ecc_sampling.h", "ecc_worker_pool.h", "ecc_slab_tile.h", "ecc_pairs_device.h", "ecc_capi_internal.h", os.path.join("..", "..", "include", "ecc_hip.h")]
+HEADERS = ["ecc_layout.h", "ecc_host_geometry.h", "ecc_sampling.h", "ecc_worker_pool.h", "ecc_pose_diff.h", "ecc_slab_tile.h", "ecc_pairs_device.h", "ecc_capi_internal.h", os.path.join("..", "..", "include", "ecc_hip.h")]
 # radon_kernel.hip: the SLP vectoriser packs the two samples of the derivative pair into v_pk_*_f32 pairs, which
 # cost two issue slots each on gfx950 (no gain, scripts/micro/valu_rate.hip) plus ~12 v_mov per iteration to
 # arrange operands -- scalar code is ~15 % faster there; the pair kernel gains 7 % the same way (0.548 -> 0.512 ms).

@@ -21,8 +21,7 @@
 // an evaluation of n (n - 1) / 2 pairs resolves to, and the sum's order is reproduced: every mean has the bits of
 // ecc_metric_set_projections + ecc_metric_evaluate_all for that pose (tests/test_gpu_pose_batch.py).
 #include "ecc_capi_internal.h"
-
-#include <thread>
+#include "ecc_pose_diff.h"
 
 using namespace ecc_internal;
 
@@ -535,63 +534,11 @@ ECC_EXPORT int ecc_metric_evaluate_poses_strided(ecc_metric* m, int n_poses, con
 
     // The poses as deltas of a base: the metric's current matrices if at least half of the poses differ from them in a few
     // views, else the first pose (a sweep around an estimate the metric has not seen yet).
-    // (600 poses of 400 views are 23 MB to compare: one thread reads them in ~2 ms, which is what the whole batch takes on the
-    // device -- so the comparison runs on up to eight threads, a contiguous run of poses each)
-    std::vector<int32_t> off, views;
-    std::vector<int> batch_pose, rest;
-    auto diff_against = [&](const double* base) {
-        const size_t count = mine.size();
-        const size_t bytes = count * pose_doubles * sizeof(double);
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const size_t T = bytes < ((size_t)4 << 20) ? 1 : std::min<size_t>({(size_t)8, (size_t)hw, count / 32 + 1});
-        std::vector<std::vector<int32_t>> part_views(T);
-        std::vector<std::vector<int32_t>> part_count(T);  // per pose of the part: moved views, or -1 = not a small delta
-        auto work = [&](size_t t) {
-            const size_t lo = count * t / T, hi = count * (t + 1) / T;
-            std::vector<int32_t>&pv = part_views[t], &pc = part_count[t];
-            pc.reserve(hi - lo);
-            for (size_t q = lo; q < hi; ++q) {
-                const double* Pp = Ps_batch + pose_doubles * (size_t)mine[q];
-                const size_t before = pv.size();
-                // blocks of eight views first: a sweep's poses differ from the base in one view or two
-                for (int v0 = 0; v0 < n_views && pv.size() - before <= (size_t)ECC_POSE_BATCH_MAX_MOVED; v0 += 8) {
-                    const int v1 = std::min(n_views, v0 + 8);
-                    if (std::memcmp(Pp + 12 * (size_t)v0, base + 12 * (size_t)v0, sizeof(double) * 12 * (size_t)(v1 - v0)) == 0) continue;
-                    for (int v = v0; v < v1; ++v)
-                        if (std::memcmp(Pp + 12 * (size_t)v, base + 12 * (size_t)v, sizeof(double) * 12) != 0) pv.push_back(v);
-                }
-                if (pv.size() - before > (size_t)ECC_POSE_BATCH_MAX_MOVED) {
-                    pv.resize(before);
-                    pc.push_back(-1);
-                } else pc.push_back((int32_t)(pv.size() - before));
-            }
-        };
-        if (T == 1) work(0);
-        else {
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
-            work(0);
-            for (std::thread& x : th) x.join();
-        }
-        off.assign(1, 0);
-        views.clear();
-        batch_pose.clear();
-        rest.clear();
-        for (size_t t = 0; t < T; ++t) {
-            const size_t lo = count * t / T;
-            size_t at = 0;
-            for (size_t q = 0; q < part_count[t].size(); ++q) {
-                const int32_t c = part_count[t][q];
-                if (c < 0) rest.push_back(mine[lo + q]);
-                else {
-                    views.insert(views.end(), part_views[t].begin() + at, part_views[t].begin() + at + c);
-                    at += (size_t)c;
-                    batch_pose.push_back(mine[lo + q]);
-                    off.push_back((int32_t)views.size());
-                }
-            }
-        }
-    };
+    // (the comparison: ecc_pose_diff.h, up to eight host threads)
+    ecc_pose_diff::Result d;
+    std::vector<int32_t>&off = d.off, &views = d.views;
+    std::vector<int>&batch_pose = d.batch_pose, &rest = d.rest;
+    auto diff_against = [&](const double* base) { ecc_pose_diff::diff(Ps_batch, n_views, mine, base, ECC_POSE_BATCH_MAX_MOVED, 8, &d); };
     bool have_base = m->n_views == n_views && m->set_generation > 0 && (int)m->dtrs.size() >= n_views;
     if (have_base) diff_against(m->Ps_h[m->set_generation & 1]);
     if (!have_base || 2 * batch_pose.size() < mine.size()) {

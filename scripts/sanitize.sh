@@ -3,6 +3,7 @@
 #   1. oracle under AddressSanitizer + UndefinedBehaviorSanitizer: tests/test_oracle_*.py, tests/test_golden.py
 #   2. the shared-memory exchange (csrc/ecc_exchange.cpp) under ThreadSanitizer: 4 ranks as threads, 2000 generations
 #   3. the group's worker hand-off (csrc/ecc_worker_pool.h) under ThreadSanitizer: 8 ranks, 20 000 jobs, sleeps, failures
+#   3b. the pose batch's host-side comparison (csrc/ecc_pose_diff.h) under ThreadSanitizer: 1 and 8 threads, the same result
 #   4. host code of libecc_hip.so under UndefinedBehaviorSanitizer: the no-GPU ABI / host-function tests
 # usage: scripts/sanitize.sh [logfile]     (default profiles/r03_sanitize.log)
 set -u
@@ -28,6 +29,10 @@ g++ -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer -Iinclude tests/
 echo; echo "== 3. ecc_worker_pool.h: -fsanitize=thread (tests/c/tsan_worker_pool.cpp)"
 g++ -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer tests/c/tsan_worker_pool.cpp -lpthread -o $TMP/tsan_worker_pool \
   && TSAN_OPTIONS=halt_on_error=1 $TMP/tsan_worker_pool || fail=1
+
+echo; echo "== 3b. ecc_pose_diff.h: -fsanitize=thread (tests/c/tsan_pose_diff.cpp)"
+g++ -std=c++17 -O1 -g -fsanitize=thread -fno-omit-frame-pointer tests/c/tsan_pose_diff.cpp -lpthread -o $TMP/tsan_pose_diff \
+  && TSAN_OPTIONS=halt_on_error=1 $TMP/tsan_pose_diff || fail=1
 
 echo; echo "== 4. libecc_hip.so host code: -Xarch_host -fsanitize=undefined (ECC_HIP_LIB), no-GPU ABI and host-function tests"
 python - <<PY || fail=1

@@ -127,3 +127,16 @@ def test_rccl_is_bound_at_run_time_and_makes_an_id():
     assert any(b != b"\x00" for b in buf)
     assert L.ecc_comm_unique_id(None) == 1  # ECC_ERR_INVALID_ARGUMENT
     assert L.ecc_comm_destroy(None) == 0
+
+
+def test_pose_diff_finds_the_moved_views_whatever_the_thread_count(tmp_path):
+    """csrc/ecc_pose_diff.h (host only): the comparison that turns full matrix sets into (moved view, matrix) lists for the
+    batched pose evaluation (ecc_metric_evaluate_poses; ref for the caller's pattern: Gui/Visualization.h:59-112) -- 0, 1, 2, 7,
+    33 and all views moved, strides 1-3, one thread against eight.  The same driver runs under ThreadSanitizer in
+    scripts/sanitize.sh."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "pose_diff")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "c", "tsan_pose_diff.cpp"), "-lpthread",
+                    "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
