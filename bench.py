@@ -438,6 +438,18 @@ def sweep_poses(args, E, geometry, synthetic, dist, torch, np, ctx, metric, Ps, 
                       "pose_delta_mode": {"value": len(mine) * world / elapsed_delta, "ms_per_pose": 1e3 * elapsed_delta / len(mine),
                                           "note": "the same with ecc_metric_set_incremental: only the moved view's pairs per step"},
                       "all_forms_bit_identical": True},
+           # the batch's dominant kernel: pairs_kernel over the (pose, moved view) x partner grid -- the same per-pair bytes as the
+           # all-pairs launch, priced against the CU's vector L1 like there (the grid launch is L2-resident:
+           # profiles/r06_pmc_pose_batch.txt, hit rate 0.97 -- HBM is not what it crosses)
+           "roofline": ({"bound": "l1", "kernel": "pairs_kernel<true, false> over %d grid entries" % (len(mine) * n),
+                         "kernel_ms": batch_pairs_ms,
+                         "achieved": (64 * n_kappa_auto(S, S, B) + 68) * len(mine) * (n - 1) / (batch_pairs_ms * 1e-3) / 1e9,
+                         "peak": L1_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ, "unit": "GB/s",
+                         "frac": (64 * n_kappa_auto(S, S, B) + 68) * len(mine) * (n - 1) / (batch_pairs_ms * 1e-3) / 1e9
+                                 / (L1_BYTES_PER_CLK_CU * N_CU * ENGINE_CLOCK_GHZ),
+                         "traffic": None,
+                         "note": "algorithmic gather bytes of the %d real pairs of the launch (holes excluded) through the vector L1"
+                                 % (len(mine) * (n - 1))} if batch_pairs_ms > 0 else None),
            "min_at_step": [int(np.argmin(values[p])) for p in range(6)],
            "values_checksum": float(values.sum())}
     if rank == 0 and not args.no_cpu_baseline:
