@@ -55,17 +55,20 @@ void decide_quad_copies(ecc_metric* m)
         ecc_host::source_position(Ps + 12 * (size_t)v, c4);
         for (int k = 0; k < 4; ++k) C[4 * (size_t)v + k] = c4[k];
     }
-    int64_t wide = 0;
+    int64_t wide = 0, looked = 0;
     const double sin_quarter = 0.70710678118654752;  // kappa_max > pi/4  <=>  radius / dist > sin(pi/4)
+    // (a sample of the pairs when there are millions: every `step`-th partner of every view, at most ~500 000 pairs)
+    const int64_t step = std::max<int64_t>(1, n * (n - 1) / 2 / 500000);
     for (int64_t i = 0; i < n; ++i)
-        for (int64_t j = i + 1; j < n; ++j) {
+        for (int64_t j = i + 1 + (i % step); j < n; j += step) {
+            ++looked;
             const double *a = &C[4 * (size_t)i], *b = &C[4 * (size_t)j];
             const double B01 = a[0] * b[1] - a[1] * b[0], B02 = a[0] * b[2] - a[2] * b[0], B03 = a[0] * b[3] - a[3] * b[0];
             const double B12 = a[1] * b[2] - a[2] * b[1], B13 = a[1] * b[3] - a[3] * b[1], B23 = a[2] * b[3] - a[3] * b[2];
             const double s2 = std::sqrt(B12 * B12 + B02 * B02 + B01 * B01), s3 = std::sqrt(B03 * B03 + B13 * B13 + B23 * B23);
             if (!(s2 * sin_quarter > radius * s3)) ++wide;  // dist = s2 / s3 (also NaN geometry)
         }
-    if (wide * 50 < n * (n - 1) / 2) return;  // under 2 %
+    if (wide * 50 < looked) return;  // under 2 %
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();

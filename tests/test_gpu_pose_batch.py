@@ -210,3 +210,27 @@ def test_argument_checks(gpu_ctx):
     a.close()
     for d in base:
         d.close()
+
+
+def test_deltas_with_batching_off_and_large_moved_sets(gpu_ctx):
+    """ecc_metric_evaluate_pose_deltas is a complete entry point whatever the batch takes: with ecc_metric_set_pose_batching(0),
+    and for poses that move more views than the batch handles (33 and 40 > 32), the poses are expanded and evaluated the
+    sequential way inside the call -- the same values, and the current matrices are the base again afterwards."""
+    import epipolarconsistency_amd as E
+    n = 50
+    Ps, base, dtrs = _scan(gpu_ctx, n)
+    P0 = E.pack_projection_matrices(Ps)
+    poses, views, rows = _poses(P0, n, 7, lambda k: [list(range(1, 34)), [4], list(range(5, 45)), [], [9, 30], [49], list(range(0, 50, 2))][k])
+    ref = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setPoseBatching(False)
+    want = np.array([ref.setProjectionMatrices(P).evaluate() for P in poses])
+    base_value = ref.setProjectionMatrices(P0).evaluate()
+    a = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    assert np.array_equal(a.evaluate_pose_deltas(views, rows), want)
+    # 33 and 40 moved views: sequential; so is the last pose (25 views, view 0 among them: the automatic object radius changes)
+    assert a.last_batched_poses() == 4 and a.evaluate() == base_value
+    a.setPoseBatching(False)
+    assert np.array_equal(a.evaluate_pose_deltas(views, rows), want)
+    assert a.last_batched_poses() == 0 and a.evaluate() == base_value
+    a.close(); ref.close()
+    for d in base:
+        d.close()
