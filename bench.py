@@ -871,16 +871,16 @@ def main():
     # north_star names; the shared-memory exchange is reported next to it under timing.other_exchange
     # the headline is the RCCL all-reduce: issued by the library where its communicator exists (one call per step, everything
     # stream-ordered), else through torch.distributed
-    # (Round 6, advisor: the library-issued form has only ever run with ONE rank -- torch.distributed's all-reduce is the headline
-    # until a run on two or more GPUs has shown the library's agrees with it; with one rank, the rehearsal, the library's form is.)
-    if world > 1:
-        best = "collective" if "collective" in modes else ("rccl" if "rccl" in modes else modes[0])
-    else:
-        best = "rccl" if "rccl" in modes else ("collective" if "collective" in modes else modes[0])
-    same_step = {m: results[m]["step"](3) for m in modes}  # the same pose through every exchange (every rank, the same order)
+    # Which exchange is the headline.  The library-issued RCCL all-reduce (one call per step, everything stream-ordered) when its
+    # communicator exists on every rank -- but only after THIS run has shown, below, that it returns what torch.distributed's
+    # all-reduce and the shared-memory exchange return for the same step (round 5's advisor: it had only ever run with one
+    # rank; the ranks now agree on its availability first, its creation is under a watchdog, and a disagreement ends the run).
+    best = "rccl" if "rccl" in modes else ("collective" if "collective" in modes else modes[0])
+    same_step = {m: [results[m]["step"](k) for k in (3, 4, 11)] for m in modes}  # the same poses through every exchange (every rank, the same order)
     for m in modes:
-        if abs(same_step[m] - same_step[modes[0]]) > 1e-12 * abs(same_step[modes[0]]):
-            raise SystemExit("the exchanges disagree on the same step: %r" % (same_step,))
+        for x, y in zip(same_step[m], same_step[modes[0]]):
+            if not abs(x - y) <= 1e-12 * abs(y):
+                raise SystemExit("the exchanges disagree on the same step: %r" % (same_step,))
     res = results[best]
     elapsed, last, step = res["steady"], res["last"], res["step"]
     # pair-kernel duration: HIP events on the context's stream around the pair kernel alone, averaged over a
