@@ -335,9 +335,9 @@ int ecc_metric_evaluate_all(ecc_metric* m, float* cost_nxn, double* mean);
  *
  * ecc_metric_evaluate_pose_deltas: pose k = the metric's CURRENT matrices (the base: the last ecc_metric_set_projections)
  * with the views moved_views[moved_offsets[k] .. moved_offsets[k + 1]) (strictly ascending within a pose) replaced by the
- * matrices moved_Ps[12 * q ..] of the same entries q.  All poses of the call are ONE e1 launch over the moved matrices, ONE
- * record launch and ONE pair launch over the (pose, moved view) x partner grid -- n_views - 1 pairs per moved view instead of
- * n (n - 1) / 2 per pose -- and ONE segmented float64 sum that walks, per pose, the base's pair values with the pose's own
+ * matrices moved_Ps[12 * q ..] of the same entries q.  All poses of the call are ONE launch that lists the pairs and does E1
+ * of the moved matrices, ONE record launch and ONE pair launch over the (pose, moved view) x partner grid -- n_views - 1 pairs
+ * per moved view instead of n (n - 1) / 2 per pose -- and ONE segmented float64 sum that walks, per pose, the base's pair values with the pose's own
  * substituted in exactly the order the all-pairs sum adds them: every mean has the bits of ecc_metric_set_projections +
  * ecc_metric_evaluate_all on that pose's matrices (tests/test_gpu_pose_batch.py).  The base's pair values are kept between
  * calls (only the pairs of views that changed since are redone).  The metric's current matrices are unchanged by the call.
