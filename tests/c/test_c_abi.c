@@ -80,6 +80,36 @@ int main(int argc, char** argv)
     if (!(mean_full > 0) || mean_inc != mean_full || mean_moved_inc != mean_moved_full || mean_moved_full == mean_full ||
         recomputed != N - 1)
         return 1;
+    {   /* many poses per call (csrc/ecc_poses.hip; ref for the pattern: Gui/Visualization.h:59-112): three poses as deltas of the
+           current matrices -- view 3 back at its first angle, view 1 moved, both -- against one ecc_metric_set_projections +
+           ecc_metric_evaluate_all each: the same bits; then the same three as full matrix sets */
+        int32_t off[4] = {0, 1, 2, 4}, views[4] = {3, 1, 1, 3};
+        double moved[4 * 12], batch[3 * N * 12], means[3], dense[3], one[3], keep[N * 12];
+        int64_t batched = 0;
+        int k;
+        memcpy(keep, Ps, sizeof(keep));
+        make_P(0.55 * 3, NU, NV, moved + 0);
+        make_P(0.55 * 1 - 0.02, NU, NV, moved + 12);
+        memcpy(moved + 24, moved + 12, sizeof(double) * 12);
+        memcpy(moved + 36, moved + 0, sizeof(double) * 12);
+        CHECK(ecc_metric_evaluate_pose_deltas(m, 3, off, views, moved, means));
+        CHECK(ecc_metric_last_batched_poses(m, &batched));
+        for (k = 0; k < 3; ++k) {
+            int q;
+            memcpy(batch + k * N * 12, keep, sizeof(keep));
+            for (q = off[k]; q < off[k + 1]; ++q) memcpy(batch + k * N * 12 + 12 * views[q], moved + 12 * q, sizeof(double) * 12);
+        }
+        CHECK(ecc_metric_evaluate_poses(m, 3, batch, N, dense));
+        CHECK(ecc_metric_set_pose_batching(m, 0));
+        for (k = 0; k < 3; ++k) {
+            CHECK(ecc_metric_set_projections(m, batch + k * N * 12, N));
+            CHECK(ecc_metric_evaluate_all(m, NULL, &one[k]));
+        }
+        printf("poses %.17g %.17g %.17g batched %lld\n", means[0], means[1], means[2], (long long)batched);
+        for (k = 0; k < 3; ++k)
+            if (means[k] != one[k] || dense[k] != one[k]) return 1;
+        if (batched != 3 || means[0] != mean_full || means[1] == means[0]) return 1;
+    }
     CHECK(ecc_metric_destroy(m));
     for (v = 0; v < N; ++v) CHECK(ecc_dtr_destroy(dtrs[v]));
     CHECK(ecc_ctx_destroy(ctx));

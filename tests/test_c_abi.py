@@ -1,6 +1,6 @@
 """include/ecc_hip.h from plain C: tests/c/test_c_abi.c compiles with gcc -std=c99 -pedantic against the header and links
 libecc_hip.so -- the boundary has no C++ or torch types in it.  CPU: the host-side entry points run and context creation
-fails loudly without a device.  GPU: images -> Radon intermediates -> all-pairs metric -> pose-delta evaluation."""
+fails loudly without a device.  GPU: images -> Radon intermediates -> all-pairs metric -> pose-delta evaluation -> many poses per call."""
 import os
 import subprocess
 
@@ -33,3 +33,4 @@ def test_c_program_runs_the_path(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().endswith("ok") and "recomputed 5" in r.stdout
+    assert "batched 3" in r.stdout  # ecc_metric_evaluate_pose_deltas / ecc_metric_evaluate_poses from plain C: the sequential bits
