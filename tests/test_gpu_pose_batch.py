@@ -234,3 +234,24 @@ def test_deltas_with_batching_off_and_large_moved_sets(gpu_ctx):
     a.close(); ref.close()
     for d in base:
         d.close()
+
+
+@pytest.mark.parametrize("n", [520, 1030])
+def test_many_views_stage_a_slice_in_several_chunks(gpu_ctx, n):
+    """134 940 / 529 935 pairs: a slice of the sixteen-slice sum is 8 434 / 33 121 floats -- more than the 8 192 the segmented sum
+    stages at a time (two / five chunks per slice; a thread's own order k, k + 1024, ... runs across the chunk boundaries), and more
+    than 512 views: launch_range's skip mask no longer applies, the base evaluation refits on one stream."""
+    import epipolarconsistency_amd as E
+    Ps, base, dtrs = _scan(gpu_ctx, n, S=96, B=32)
+    P0 = E.pack_projection_matrices(Ps)
+    poses, views, rows = _poses(P0, n, 7, lambda k: [[n - 1], [1, n // 2], [], [n // 3], [7, 8, 9, n - 2], [n // 2], [2]][k])
+    a = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    b = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setPoseBatching(False)
+    want = np.array([b.setProjectionMatrices(P).evaluate() for P in poses])
+    got = a.evaluate_pose_deltas(views, rows)
+    assert np.array_equal(got, want), (n, got - want)
+    assert a.last_batched_poses() == 7 and len(set(want.tolist())) == 7
+    assert np.array_equal(a.evaluate_poses(poses, first=1, stride=2)[1::2], want[1::2])
+    a.close(); b.close()
+    for d in base:
+        d.close()
