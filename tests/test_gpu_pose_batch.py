@@ -255,3 +255,31 @@ def test_many_views_stage_a_slice_in_several_chunks(gpu_ctx, n):
     a.close(); b.close()
     for d in base:
         d.close()
+
+
+def test_more_entries_than_one_batch_takes(gpu_ctx):
+    """3 600 poses of 300 views are 1 080 000 grid entries: more than ECC_POSE_BATCH_MAX_ENTRIES (2^20) -- the call runs them as two
+    batches (3 495 + 105 columns) over the same base values.  Reference: the pose-delta mode, one pose at a time (bit-identical to
+    full evaluations: tests/test_gpu_incremental.py)."""
+    import epipolarconsistency_amd as E
+    n, K = 300, 3600
+    Ps, base, dtrs = _scan(gpu_ctx, n, S=96, B=32)
+    P0 = E.pack_projection_matrices(Ps)
+    rng = np.random.default_rng(2)
+    moved = rng.integers(1, n, size=K)
+    rows = np.stack([_perturb(P0[v], k % 97, int(v)) for k, v in enumerate(moved)])
+    a = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs)
+    got = a.evaluate_pose_deltas_packed(np.arange(K + 1, dtype=np.int32), moved.astype(np.int32), rows)
+    assert a.last_batched_poses() == K
+    b = E.MetricRadonIntermediate(gpu_ctx, Ps, dtrs).setPoseBatching(False).setIncremental(True)
+    b.evaluate()
+    P = P0.copy()
+    want = np.empty(K)
+    for k in range(K):
+        P[moved[k]] = rows[k]
+        want[k] = b.setProjectionMatrices(P).evaluate()
+        P[moved[k]] = P0[moved[k]]
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+    a.close(); b.close()
+    for d in base:
+        d.close()
